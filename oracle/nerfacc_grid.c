@@ -1,0 +1,298 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.  Never linked, imported or executed by the
+ * product path (the package under active-perception-using-neural-radiance-fields_amd/);
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Plain-C, single-threaded restatement of the reference's occupancy-grid ray
+ * marcher and packed scans (the nerfacc 0.5.3 fork vendored by the reference):
+ *
+ *   orc_ray_aabb_intersect  <- perception/nerfacc/nerfacc/cuda/csrc/include/utils_grid.cuh:10-55,
+ *                              cuda/csrc/grid.cu:284-313
+ *   orc_traverse_grids      <- cuda/csrc/grid.cu:23-28, 68-282 (kernel body),
+ *                              include/utils_grid.cuh:58-142 (setup_traversal, single_traversal),
+ *                              include/utils_contraction.cuh:19-24 (roi_to_unit),
+ *                              include/data_spec_packed.cuh:42-56 (SingleRaySpec: inv_dir = 1/d),
+ *                              include/utils_math.cuh:177-180 (int() truncation)
+ *   orc_exclusive_sum       <- include/utils_scan.cuh:146-263 / cuda/csrc/scan.cu:68-125
+ *                              (semantics only: a per-chunk exclusive prefix sum; the
+ *                              reference's 32-wide Blelloch tree order is NOT reproduced —
+ *                              sums are sequential fp32, compared with a tolerance)
+ *
+ * Parity status: the reference implementation of these functions is CUDA-only and
+ * cannot run in the build container (no nvcc, no GPU), and the reference's tests for
+ * it are property tests with CUDA-RNG inputs.  The oracle is therefore pinned by
+ * (a) the CPU-runnable pure-torch twin `_ray_aabb_intersect` (grid.py:54-90) through
+ * golden vectors, (b) the reference's own property tests re-run on this code
+ * (samples lie in occupied cells per the reference's `_query`, near/far bounds,
+ * chunked == two-pass), see tests/test_oracle_marcher.py.  The build must use
+ * -ffp-contract=off: the marcher's t values come from chains of fp32 adds whose
+ * rounding must not be altered by FMA contraction (nvcc's default -fmad=true may
+ * contract some of them in the reference build; that choice is compiler-internal and
+ * cannot be reproduced, so "bit-exact" here means HIP kernel == this file).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct { float x, y, z; } f3;
+typedef struct { int x, y, z; } i3;
+
+static inline float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+static inline int clampi(int f, int a, int b) { int m = f < b ? f : b; return a > m ? a : m; }
+
+/* utils_grid.cuh:10-55 */
+static int ray_aabb(const float *o, const float *d, float ray_tmin, float ray_tmax,
+                    const float *aabb, float *tmin_out, float *tmax_out)
+{
+    float inv_x = 1.0f / d[0], inv_y = 1.0f / d[1], inv_z = 1.0f / d[2];
+    float tmin, tmax, tmin_t, tmax_t;
+    if (inv_x >= 0) { tmin = (aabb[0] - o[0]) * inv_x; tmax = (aabb[3] - o[0]) * inv_x; }
+    else            { tmin = (aabb[3] - o[0]) * inv_x; tmax = (aabb[0] - o[0]) * inv_x; }
+    if (inv_y >= 0) { tmin_t = (aabb[1] - o[1]) * inv_y; tmax_t = (aabb[4] - o[1]) * inv_y; }
+    else            { tmin_t = (aabb[4] - o[1]) * inv_y; tmax_t = (aabb[1] - o[1]) * inv_y; }
+    if (tmin > tmax_t || tmin_t > tmax) return 0;
+    if (tmin_t > tmin) tmin = tmin_t;
+    if (tmax_t < tmax) tmax = tmax_t;
+    if (inv_z >= 0) { tmin_t = (aabb[2] - o[2]) * inv_z; tmax_t = (aabb[5] - o[2]) * inv_z; }
+    else            { tmin_t = (aabb[5] - o[2]) * inv_z; tmax_t = (aabb[2] - o[2]) * inv_z; }
+    if (tmin > tmax_t || tmin_t > tmax) return 0;
+    if (tmin_t > tmin) tmin = tmin_t;
+    if (tmax_t < tmax) tmax = tmax_t;
+    if (tmax <= 0) return 0;
+    *tmin_out = fmaxf(tmin, ray_tmin);
+    *tmax_out = fminf(tmax, ray_tmax);
+    return 1;
+}
+
+/* grid.cu:284-313: one (ray, aabb) pair per element, miss -> miss_value */
+void orc_ray_aabb_intersect(int32_t n_rays, const float *rays_o, const float *rays_d,
+                            float near_plane, float far_plane,
+                            int32_t n_aabbs, const float *aabbs, float miss_value,
+                            float *t_mins, float *t_maxs, uint8_t *hits)
+{
+    for (int64_t tid = 0; tid < (int64_t)n_rays * n_aabbs; ++tid) {
+        int64_t r = tid / n_aabbs, a = tid % n_aabbs;
+        float t0, t1;
+        int hit = ray_aabb(rays_o + 3 * r, rays_d + 3 * r, near_plane, far_plane, aabbs + 6 * a, &t0, &t1);
+        t_mins[tid] = hit ? t0 : miss_value;
+        t_maxs[tid] = hit ? t1 : miss_value;
+        hits[tid] = (uint8_t)hit;
+    }
+}
+
+/* grid.cu:23-28 */
+static inline float calc_dt(float t, float cone_angle, float dt_min, float dt_max)
+{
+    return clampf(t * cone_angle, dt_min, dt_max);
+}
+
+typedef struct {
+    float   *vals;
+    int64_t *ray_indices;
+    uint8_t *is_left;
+    uint8_t *is_right;
+    uint8_t *is_valid;
+    int64_t *chunk_starts;
+    int64_t *chunk_cnts;   /* NULL -> this output is disabled */
+} orc_segments;
+
+/*
+ * grid.cu:68-282.  One call == one kernel launch of the reference:
+ *   first_pass != 0 : count only (writes chunk_cnts)
+ *   first_pass == 0 : fill at chunk_starts[ray] (+ rewrites chunk_cnts with the actual count)
+ * rays_mask may be NULL.  terminate_planes may be NULL.
+ */
+void orc_traverse_grids(int32_t n_rays, const float *rays_o, const float *rays_d,
+                        const uint8_t *rays_mask,
+                        int32_t n_grids, const int32_t *resolution, const uint8_t *binaries,
+                        const float *aabbs,
+                        const uint8_t *hits, const float *t_sorted, const int64_t *t_indices,
+                        const float *near_planes, const float *far_planes,
+                        float step_size, float cone_angle, int32_t traverse_steps_limit,
+                        int32_t first_pass,
+                        orc_segments *intervals, orc_segments *samples,
+                        float *terminate_planes)
+{
+    const float eps = 1e-6f;
+    const i3 res = { resolution[0], resolution[1], resolution[2] };
+    const int has_iv = intervals && intervals->chunk_cnts;
+    const int has_sm = samples && samples->chunk_cnts;
+
+    for (int32_t tid = 0; tid < n_rays; ++tid) {
+        if (rays_mask && !rays_mask[tid]) continue;
+        if (has_iv && !first_pass && intervals->chunk_cnts[tid] == 0) continue;
+        if (has_sm && !first_pass && samples->chunk_cnts[tid] == 0) continue;
+
+        int64_t chunk_start = 0, chunk_start_bin = 0;
+        if (!first_pass) {
+            if (has_iv) chunk_start = intervals->chunk_starts[tid];
+            if (has_sm) chunk_start_bin = samples->chunk_starts[tid];
+        }
+        const float near_plane = near_planes[tid], far_plane = far_planes[tid];
+        const float *o = rays_o + 3 * tid, *d = rays_d + 3 * tid;
+        const f3 org = { o[0], o[1], o[2] }, dir = { d[0], d[1], d[2] };
+        const f3 inv = { 1.0f / d[0], 1.0f / d[1], 1.0f / d[2] };
+
+        const int32_t base_hits = tid * n_grids;
+        const int32_t base_t = tid * n_grids * 2;
+
+        int64_t n_intervals = 0, n_samples = 0;
+        float t_last = near_plane;
+        int continuous = 0;
+
+        for (int32_t i = base_t; i < base_t + n_grids * 2 - 1; ++i) {
+            int is_entering = t_indices[i] < n_grids;
+            int64_t level = t_indices[i] % n_grids;
+            if (!hits[base_hits + level]) continue;
+            if (!is_entering) {
+                int next_is_entering = t_indices[i + 1] < n_grids;
+                if (next_is_entering) continue;
+                level = t_indices[i + 1] % n_grids;
+                if (!hits[base_hits + level]) continue;
+            }
+            float this_tmin = fmaxf(t_sorted[i], near_plane);
+            float this_tmax = fminf(t_sorted[i + 1], far_plane);
+            if (this_tmin >= this_tmax) continue;
+
+            if (!continuous) {
+                if (step_size <= 0.0f) {
+                    t_last = this_tmin;
+                } else {
+                    float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                    for (;;) {
+                        if (t_last + dt * 0.5f >= this_tmin) break;
+                        t_last += dt;
+                    }
+                }
+            }
+
+            /* setup_traversal, utils_grid.cuh:58-114 */
+            const float *ab = aabbs + level * 6;
+            const f3 amin = { ab[0], ab[1], ab[2] }, amax = { ab[3], ab[4], ab[5] };
+            const f3 resf = { (float)res.x, (float)res.y, (float)res.z };
+            const f3 vox = { (amax.x - amin.x) / resf.x, (amax.y - amin.y) / resf.y, (amax.z - amin.z) / resf.z };
+            const float ts = this_tmin + eps, te = this_tmax - eps;
+            const f3 rs = { org.x + dir.x * ts, org.y + dir.y * ts, org.z + dir.z * ts };
+            const f3 re = { org.x + dir.x * te, org.y + dir.y * te, org.z + dir.z * te };
+            i3 cur = { (int)(((rs.x - amin.x) / (amax.x - amin.x)) * resf.x),
+                       (int)(((rs.y - amin.y) / (amax.y - amin.y)) * resf.y),
+                       (int)(((rs.z - amin.z) / (amax.z - amin.z)) * resf.z) };
+            cur.x = clampi(cur.x, 0, res.x - 1); cur.y = clampi(cur.y, 0, res.y - 1); cur.z = clampi(cur.z, 0, res.z - 1);
+            i3 fin = { (int)(((re.x - amin.x) / (amax.x - amin.x)) * resf.x),
+                       (int)(((re.y - amin.y) / (amax.y - amin.y)) * resf.y),
+                       (int)(((re.z - amin.z) / (amax.z - amin.z)) * resf.z) };
+            fin.x = clampi(fin.x, 0, res.x - 1); fin.y = clampi(fin.y, 0, res.y - 1); fin.z = clampi(fin.z, 0, res.z - 1);
+
+            const i3 start = { cur.x + (dir.x > 0 ? 1 : 0), cur.y + (dir.y > 0 ? 1 : 0), cur.z + (dir.z > 0 ? 1 : 0) };
+            const f3 tmx = { ((amin.x + (((float)start.x * vox.x) - rs.x)) * inv.x) + this_tmin,
+                             ((amin.y + (((float)start.y * vox.y) - rs.y)) * inv.y) + this_tmin,
+                             ((amin.z + (((float)start.z * vox.z) - rs.z)) * inv.z) + this_tmin };
+            f3 tdist = { dir.x == 0.0f ? this_tmax : tmx.x, dir.y == 0.0f ? this_tmax : tmx.y, dir.z == 0.0f ? this_tmax : tmx.z };
+            const f3 stepf = { dir.x == 0.0f ? 0.0f : (dir.x > 0.0f ? 1.0f : -1.0f),
+                               dir.y == 0.0f ? 0.0f : (dir.y > 0.0f ? 1.0f : -1.0f),
+                               dir.z == 0.0f ? 0.0f : (dir.z > 0.0f ? 1.0f : -1.0f) };
+            const i3 step = { (int)stepf.x, (int)stepf.y, (int)stepf.z };
+            const f3 dtmp = { vox.x * inv.x * stepf.x, vox.y * inv.y * stepf.y, vox.z * inv.z * stepf.z };
+            const f3 delta = { dir.x == 0.0f ? this_tmax : dtmp.x, dir.y == 0.0f ? this_tmax : dtmp.y, dir.z == 0.0f ? this_tmax : dtmp.z };
+            const i3 overflow = { fin.x + step.x, fin.y + step.y, fin.z + step.z };
+
+            while (traverse_steps_limit <= 0 || n_samples < traverse_steps_limit) {
+                float t_traverse = fminf(tdist.x, fminf(tdist.y, tdist.z));
+                t_traverse = fminf(t_traverse, this_tmax);
+                int64_t cell_id = (int64_t)cur.x * res.y * res.z + (int64_t)cur.y * res.z + cur.z
+                                  + level * (int64_t)res.x * res.y * res.z;
+                if (!binaries[cell_id]) {
+                    if (step_size <= 0.0f) {
+                        t_last = t_traverse;
+                    } else {
+                        float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                        for (;;) {
+                            if (t_last + dt * 0.5f >= t_traverse) break;
+                            t_last += dt;
+                        }
+                    }
+                    continuous = 0;
+                } else {
+                    while (traverse_steps_limit <= 0 || n_samples < traverse_steps_limit) {
+                        float t_next;
+                        if (step_size <= 0.0f) {
+                            t_next = t_traverse;
+                        } else {
+                            float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                            if (t_last + dt * 0.5f >= t_traverse) break;
+                            t_next = t_last + dt;
+                        }
+                        if (has_iv) {
+                            if (!continuous) {
+                                if (!first_pass) {
+                                    int64_t idx = chunk_start + n_intervals;
+                                    intervals->vals[idx] = t_last;
+                                    intervals->ray_indices[idx] = tid;
+                                    intervals->is_left[idx] = 1;
+                                }
+                                n_intervals++;
+                                if (!first_pass) {
+                                    int64_t idx = chunk_start + n_intervals;
+                                    intervals->vals[idx] = t_next;
+                                    intervals->ray_indices[idx] = tid;
+                                    intervals->is_right[idx] = 1;
+                                }
+                                n_intervals++;
+                            } else {
+                                if (!first_pass) {
+                                    int64_t idx = chunk_start + n_intervals;
+                                    intervals->vals[idx] = t_next;
+                                    intervals->ray_indices[idx] = tid;
+                                    intervals->is_left[idx - 1] = 1;
+                                    intervals->is_right[idx] = 1;
+                                }
+                                n_intervals++;
+                            }
+                        }
+                        if (has_sm) {
+                            if (!first_pass) {
+                                int64_t idx = chunk_start_bin + n_samples;
+                                samples->vals[idx] = (t_next + t_last) * 0.5f;
+                                samples->ray_indices[idx] = tid;
+                                if (samples->is_valid) samples->is_valid[idx] = 1;
+                            }
+                        }
+                        n_samples++;
+                        continuous = 1;
+                        t_last = t_next;
+                        if (t_next >= t_traverse) break;
+                    }
+                }
+                /* single_traversal, utils_grid.cuh:116-142 */
+                if (tdist.x < tdist.y && tdist.x < tdist.z) {
+                    cur.x += step.x; tdist.x += delta.x;
+                    if (cur.x == overflow.x) break;
+                } else if (tdist.y < tdist.z) {
+                    cur.y += step.y; tdist.y += delta.y;
+                    if (cur.y == overflow.y) break;
+                } else {
+                    cur.z += step.z; tdist.z += delta.z;
+                    if (cur.z == overflow.z) break;
+                }
+            }
+        }
+        if (terminate_planes) terminate_planes[tid] = t_last;
+        if (has_iv) intervals->chunk_cnts[tid] = n_intervals;
+        if (has_sm) samples->chunk_cnts[tid] = n_samples;
+    }
+}
+
+/* scan.cu:68-125 semantics (forward / backward = reverse-direction scan of each chunk) */
+void orc_exclusive_sum(int32_t n_rays, const int64_t *chunk_starts, const int64_t *chunk_cnts,
+                       const float *inputs, float *outputs, int32_t backward)
+{
+    for (int32_t r = 0; r < n_rays; ++r) {
+        int64_t s = chunk_starts[r], c = chunk_cnts[r];
+        float acc = 0.0f;
+        if (!backward) {
+            for (int64_t k = 0; k < c; ++k) { outputs[s + k] = acc; acc += inputs[s + k]; }
+        } else {
+            for (int64_t k = c - 1; k >= 0; --k) { outputs[s + k] = acc; acc += inputs[s + k]; }
+        }
+    }
+}

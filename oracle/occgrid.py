@@ -1,0 +1,56 @@
+"""ORACLE (test infrastructure only): occupancy-grid state and EMA update,
+perception/nerfacc/nerfacc/estimators/occ_grid.py:28-78 (state), :328-375 (cell selection),
+:377-437 (`_update`), grid.py:195-198 (`_enlarge_aabb`), pipeline.py:113-120 (resolution).
+
+The reference draws cell indices and in-cell jitter from the torch RNG on the CUDA device;
+that stream is not reproducible anywhere else, so the update takes the drawn `indices`
+and `jitter` as explicit inputs.  numpy fp32.
+"""
+import numpy as np
+
+
+def grid_resolution(aabb, cell_size):
+    """pipeline.py:113-120: float32 subtraction and division, then int truncation
+    (this is what yields Y=21 rather than 22 for scenes 102344529 / 102344280)."""
+    aabb = np.asarray(aabb, np.float32)
+    return ((aabb[3:] - aabb[:3]) / cell_size).astype(int).tolist()
+
+
+def enlarge_aabb(aabb, factor):
+    aabb = np.asarray(aabb, np.float32)
+    center = (aabb[:3] + aabb[3:]) / 2
+    extent = (aabb[3:] - aabb[:3]) / 2
+    return np.concatenate([center - extent * np.float32(factor), center + extent * np.float32(factor)]).astype(np.float32)
+
+
+def grid_coords(resolution):
+    """occ_grid.py:440-455 `_meshgrid3d(...).reshape(cells, 3)`: 'ij' order, z fastest."""
+    r = np.asarray(resolution, int)
+    g = np.stack(np.meshgrid(np.arange(r[0]), np.arange(r[1]), np.arange(r[2]), indexing="ij"), -1)
+    return g.reshape(-1, 3).astype(np.int64)
+
+
+def cell_sample_points(indices, jitter, resolution, aabb):
+    """occ_grid.py:395-401: x = (coord + U[0,1)) / res ; world = aabb_min + x * (aabb_max - aabb_min)."""
+    coords = grid_coords(resolution)[indices].astype(np.float32)
+    x = (coords + np.asarray(jitter, np.float32)) / np.asarray(resolution, np.float32)
+    aabb = np.asarray(aabb, np.float32)
+    return (aabb[:3] + x * (aabb[3:] - aabb[:3])).astype(np.float32)
+
+
+def ema_update(occs, indices, occ, ema_decay=0.95):
+    """occ_grid.py:407-434: occs[ids] = max(occs[ids]*decay, occ) then NaN roll-back.
+    (Duplicate indices: last write wins, as in torch index assignment.)"""
+    occs = np.asarray(occs, np.float32).copy()
+    backup = occs.copy()
+    occs[indices] = np.maximum(occs[indices] * np.float32(ema_decay), np.asarray(occ, np.float32))
+    nan = np.isnan(occs)
+    occs[nan] = backup[nan]
+    return occs
+
+
+def binarize(occs, occ_thre):
+    """occ_grid.py:436-437."""
+    occs = np.asarray(occs, np.float32)
+    thre = min(np.float32(occs[occs >= 0].mean(dtype=np.float32)), np.float32(occ_thre))
+    return occs > thre, thre

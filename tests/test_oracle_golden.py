@@ -1,0 +1,213 @@
+"""The oracle against the golden vectors captured from the reference (tests/golden/make_golden.py)
+and against the reference tests' known answers.  CPU only."""
+import numpy as np
+import torch
+
+from oracle import marcher as M
+from oracle import occgrid as OG
+from oracle import render as R
+from oracle import vanilla as V
+
+
+def test_ray_aabb_vs_reference_twin(golden):
+    g = golden("aabb")
+    t0, t1, h = M.ray_aabb_intersect(g["rays_o"], g["rays_d"], g["aabbs"])
+    ref_h = g["hits_inf"]
+    assert (h == ref_h).mean() > 0.999  # the twin (grid.py:54-90) and the kernel differ only on exact ties
+    both = h & ref_h
+    np.testing.assert_allclose(t0[both], g["t_mins_inf"][both], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(t1[both], g["t_maxs_inf"][both], rtol=1e-5, atol=1e-6)
+    assert np.isinf(t0[~h]).all() and np.isinf(t1[~h]).all()
+    # near/far: the kernel clips tmin from below and tmax from above only (utils_grid.cuh:52-53);
+    # the twin clamps both ends to [near, far] (grid.py:80-81), so derive the expectation from
+    # the unclipped golden instead of the twin's clipped output.
+    c0, c1, ch = M.ray_aabb_intersect(g["rays_o"], g["rays_d"], g["aabbs"], 0.1, 1.5)
+    np.testing.assert_array_equal(ch, h)
+    np.testing.assert_allclose(c0[both], np.maximum(g["t_mins_inf"][both], 0.1), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c1[both], np.minimum(g["t_maxs_inf"][both], 1.5), rtol=1e-5, atol=1e-6)
+    inside = both & (g["t_mins_inf"] < 1.5) & (g["t_maxs_inf"] > 0.1)
+    np.testing.assert_allclose(c0[inside], g["t_mins_clip"][inside], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c1[inside], g["t_maxs_clip"][inside], rtol=1e-5, atol=1e-6)
+
+
+def test_pack_info_known_answer():
+    # perception/nerfacc/tests/test_pack.py:11-18
+    np.testing.assert_array_equal(M.pack_info(np.array([0, 2, 2, 2, 2]), 3), [[0, 1], [1, 0], [1, 4]])
+
+
+def test_exclusive_sum_docstring_vectors():
+    # perception/nerfacc/nerfacc/scan.py:77-80
+    x = np.arange(1, 10, dtype=np.float32)
+    pk = np.array([[0, 2], [2, 3], [5, 4]])
+    np.testing.assert_array_equal(M.exclusive_sum(x, pk), [0, 1, 0, 3, 7, 0, 6, 13, 21])
+    np.testing.assert_array_equal(M.exclusive_sum(x, pk, backward=True), [2, 0, 9, 5, 0, 24, 17, 9, 0])
+
+
+def test_weights_and_grads_known_answers():
+    # perception/nerfacc/tests/test_rendering.py:117-133
+    ri = np.array([0, 2, 2, 2, 2])
+    pk = M.pack_info(ri, 3)
+    sig = torch.tensor([0.4, 0.8, 0.1, 0.8, 0.1])
+    ts = torch.rand(5)
+    te = ts + 1.0
+    w, tr, al = R.render_weight_from_density(ts, te, sig, pk)
+    np.testing.assert_allclose(w.numpy(), [0.3297, 0.5507, 0.0428, 0.2239, 0.0174], atol=1e-4)
+    # d(sum w)/d sigma via the reference's backward rule (scan.py:226-228): reverse scan of grads
+    dt = (te - ts)
+    sdt = sig * dt
+    g_excl = torch.from_numpy(M.exclusive_sum((-(tr * al)).numpy(), pk, backward=True))  # d/d(excl_sum)
+    grad = (tr * torch.exp(-sdt) + g_excl) * dt
+    np.testing.assert_allclose(grad.numpy(), [0.6703, 0.1653, 0.1653, 0.1653, 0.1653], atol=1e-4)
+
+
+def test_visibility_known_answers():
+    # volrend.py:464-474 docstring (density form)
+    ts = torch.arange(0.0, 7.0)
+    te = ts + 1
+    sig = torch.tensor([0.4, 0.8, 0.1, 0.8, 0.1, 0.0, 0.9])
+    pk = M.pack_info(np.array([0, 0, 0, 1, 1, 2, 2]), 3)
+    vis = R.render_visibility_from_density(ts, te, sig, pk, early_stop_eps=0.3, alpha_thre=0.2)
+    np.testing.assert_array_equal(vis.numpy(), [True, True, False, True, False, False, True])
+
+
+def test_volrend_packed_equals_reference_batched(golden):
+    g = golden("volrend")
+    Rn, S = g["sigmas"].shape
+    ri = np.repeat(np.arange(Rn), S)
+    pk = M.pack_info(ri, Rn)
+    ts, te, sg = (torch.from_numpy(g[k].reshape(-1)) for k in ("t_starts", "t_ends", "sigmas"))
+    w, tr, al = R.render_weight_from_density(ts, te, sg, pk)
+    np.testing.assert_allclose(w.numpy().reshape(Rn, S), g["weights"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(tr.numpy().reshape(Rn, S), g["trans"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(al.numpy().reshape(Rn, S), g["alphas"], rtol=1e-6, atol=1e-7)
+    vis = R.render_visibility_from_density(ts, te, sg, pk, 1e-2, 0.05)
+    assert (vis.numpy().reshape(Rn, S) == g["vis"]).mean() > 0.9995  # threshold ties only
+    rgbs = torch.from_numpy(g["rgbs"].reshape(-1, 3))
+    rit = torch.from_numpy(ri)
+    colors = R.accumulate_along_rays(w, rgbs, rit, Rn)
+    opac = R.accumulate_along_rays(w, None, rit, Rn)
+    depth = R.accumulate_along_rays(w, (ts + te)[:, None] / 2.0, rit, Rn) / opac.clamp_min(torch.finfo(torch.float32).eps)
+    colors = colors + torch.from_numpy(g["bkgd"]) * (1 - opac)
+    np.testing.assert_allclose(colors.numpy(), g["colors"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(opac.numpy(), g["opacities"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(depth.numpy(), g["depths"], rtol=1e-4, atol=1e-5)
+
+
+def test_occgrid_update_trajectory(golden):
+    g = golden("occgrid")
+    res, aabb = g["resolution"], g["roi_aabb"]
+    np.testing.assert_array_equal(OG.grid_coords(res), g["grid_coords"])
+    np.testing.assert_allclose(OG.enlarge_aabb(aabb, 1)[None], g["aabbs"], rtol=0, atol=0)
+    for i in range(4):
+        np.testing.assert_allclose(OG.enlarge_aabb([-1, -1, -1, 1, 1, 1], 2 ** i), g["levels4_aabbs"][i])
+    cells = int(np.prod(res))
+    occs = np.zeros(cells, np.float32)
+    binaries = np.zeros(cells, bool)
+
+    def occ_eval(x):
+        return (np.maximum(np.sin(x[:, 0] * np.float32(1.3)) * np.cos(x[:, 2] * np.float32(0.7)) + np.float32(0.2) * x[:, 1], 0)
+                * np.float32(0.02)).astype(np.float32)
+
+    for k in range(5):
+        step = int(g[f"s{k}_step"])
+        draws = [g[[n for n in g.files if n.startswith(f"s{k}_draw{j}_")][0]] for j in range(int(g[f"s{k}_ndraws"]))]
+        if step < 256:
+            indices = np.arange(cells)[occs >= 0]               # occ_grid.py:334-343
+            jitter = draws[0]
+        else:
+            uni = draws[0]                                      # occ_grid.py:351-353
+            uni = uni[occs[uni] >= 0]
+            occupied = np.nonzero(binaries)[0]
+            n = cells // 4
+            if n < len(occupied):                               # occ_grid.py:358-363
+                occupied = occupied[draws[1]]
+                jitter = draws[2]
+            else:
+                jitter = draws[1]
+            indices = np.concatenate([uni, occupied])
+        x = OG.cell_sample_points(indices, jitter, res, aabb)
+        occs = OG.ema_update(occs, indices, occ_eval(x))
+        binaries, _ = OG.binarize(occs, 1e-2)
+        np.testing.assert_allclose(occs, g[f"s{k}_occs"], rtol=2e-5, atol=1e-7)
+        assert (binaries.reshape(res) == g[f"s{k}_binaries"][0]).mean() > 0.995  # threshold ties
+    assert int(g["mark_invisible_neg1"]) == 77660 and int(g["mark_invisible_zero"]) == 53412
+
+
+def test_grid_resolution_float32_trap():
+    # BASELINE.md §3 / pipeline.py:113-120
+    assert OG.grid_resolution([-19.1, -0.2, -19.1, 0.5, 3.2, 0.5], 0.2) == [98, 17, 98]
+    assert OG.grid_resolution([-12, -0.2, -12, 12, 4.2, 12], 0.2) == [120, 21, 120]
+    assert OG.grid_resolution([-13, -0.2, -13, 14, 4.2, 15], 0.2) == [135, 21, 140]
+
+
+def test_marcher_samples_in_occupied_cells(golden):
+    """tests/test_grid.py:39-68, evaluated by the reference's `_query` at golden time."""
+    g = golden("query")
+    assert bool(g["ref_query_all_occupied"]) and bool(g["ref_query_all_selected"])
+    binaries = np.unpackbits(g["binaries"])[: int(np.prod(g["binaries_shape"]))].reshape(g["binaries_shape"]).astype(bool)
+    iv, sm, _ = M.traverse_grids(g["rays_o"], g["rays_d"], binaries, g["aabbs"])
+    np.testing.assert_array_equal(sm.packed_info[:, 1], g["chunk_cnts"])
+    assert int(g["n_samples"]) == iv.is_left.sum() == iv.is_right.sum() == len(sm.vals)
+    np.testing.assert_allclose(iv.vals[iv.is_left].astype(np.float64).sum(), g["t_starts_sum"], rtol=1e-9)
+
+
+def test_marcher_chunked_equals_two_pass():
+    """tests/test_grid.py:72-131 (chunked traversal == two-pass) and :135-159 (near/far)."""
+    rng = np.random.default_rng(1)
+    n = 64
+    o = rng.normal(size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    aabbs = np.stack([OG.enlarge_aabb([-1, -1, -1, 1, 1, 1], 2 ** i) for i in range(2)])
+    binaries = rng.random((2, 16, 16, 16)) > 0.5
+    iv, sm, _ = M.traverse_grids(o, d, binaries, aabbs, step_size=1e-2)
+    ts_ref = np.bincount(sm.ray_indices, iv.vals[iv.is_left].astype(np.float64), n)
+    acc = np.zeros(n)
+    term, mask, cnt = None, None, 0
+    for _ in range(40):
+        iv2, sm2, term = M.traverse_grids(o, d, binaries, aabbs, near_planes=term, step_size=1e-2,
+                                          traverse_steps_limit=64, over_allocate=True, rays_mask=mask)
+        ri = sm2.ray_indices[sm2.is_valid]
+        acc += np.bincount(ri, iv2.vals[iv2.is_left].astype(np.float64), n)
+        cnt += len(ri)
+        mask = sm2.packed_info[:, 1] == 64
+        if not mask.any():
+            break
+    assert not mask.any()
+    np.testing.assert_allclose(acc, ts_ref, atol=1e-1)
+    # near/far
+    iv, sm, _ = M.traverse_grids(np.array([[-1.0, 0, 0]]), np.array([[1.0, 0.01, 0.01]]) / np.linalg.norm([1, 0.01, 0.01]),
+                                 np.ones((1, 1, 1, 1), bool), np.array([[0.0, 0, 0, 1, 1, 1]]),
+                                 near_planes=np.array([1.2]), far_planes=np.array([1.5]), step_size=0.05)
+    assert (iv.vals >= 1.2 - 0.025).all() and (iv.vals <= 1.5 + 0.025).all() and len(iv.vals) > 0
+
+
+def test_vanilla_field_matches_reference(golden):
+    g = golden("vanilla")
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    f = V.VanillaField(sd)
+    np.testing.assert_allclose(V.sinusoidal_encode(g["posenc_in"], 0, 10), g["posenc_out"], rtol=1e-5, atol=1e-5)
+    o, d, e = g["rays_o"], g["rays_d"], g["t_edges"]
+    ts = np.broadcast_to(e[:-1], (o.shape[0], 32)).astype(np.float32)
+    te = np.broadcast_to(e[1:], (o.shape[0], 32)).astype(np.float32)
+    pos = o[:, None, :] + d[:, None, :] * ((ts + te) / 2.0)[..., None]
+    rgb, sigma = f.forward(pos, np.broadcast_to(d[:, None, :], pos.shape))
+    colors, opac, depth, _ = V.render_batched(rgb, sigma[..., 0], ts, te, np.zeros(3, np.float32))
+    np.testing.assert_allclose(colors, g["colors"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(opac, g["opacities"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(depth, g["depths"], rtol=1e-4, atol=1e-5)
+
+
+def test_raygen_matches_reference(golden):
+    """bit-exact against Dataset.generate_image_rays + the linspace sub-sampler"""
+    g = golden("raygen")
+    for k in range(3):
+        W, H, scale = g[f"c{k}_whs"]
+        W, H = int(W), int(H)
+        c2w = R.pose_to_c2w(g[f"c{k}_pose"])
+        np.testing.assert_array_equal(c2w.numpy(), g[f"c{k}_c2w"])
+        idx = R.subsample_indices(W * H, int(H * scale) * int(W * scale))
+        np.testing.assert_array_equal(idx, g[f"c{k}_idx"])
+        o, d = R.generate_image_rays(c2w, W, H, float(g[f"c{k}_focal"]), idx)
+        np.testing.assert_array_equal(o.numpy(), g[f"c{k}_origins"])
+        np.testing.assert_array_equal(d.numpy(), g[f"c{k}_viewdirs"])
