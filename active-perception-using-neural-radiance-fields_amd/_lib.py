@@ -1,0 +1,107 @@
+"""ctypes binding of libmi355nerf.so (include/mi355nerf.h).  PyTorch is used only to own device
+memory and streams; tensors cross the boundary as raw device pointers."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_FILE = os.path.join(_HERE, "libmi355nerf.so")
+_lib = None
+
+
+class MnfError(RuntimeError):
+    """Raised for any non-zero return code of the C ABI (mirrors TORCH_CHECK -> RuntimeError)."""
+
+
+class FieldConfig(ctypes.Structure):
+    _fields_ = [("aabb", c_float * 6), ("neurons", c_int32), ("layers", c_int32),
+                ("num_semantic_classes", c_int32), ("n_levels", c_int32), ("n_features", c_int32),
+                ("log2_hashmap_size", c_int32), ("base_resolution", c_int32), ("max_resolution", c_int32)]
+
+
+class RenderOpts(ctypes.Structure):
+    _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float),
+                ("cone_angle", c_float), ("alpha_thre", c_float), ("early_stop_eps", c_float),
+                ("render_bkgd", c_float * 3), ("max_samples", c_int32), ("probabilistic", c_int32),
+                ("rays_per_view", c_int32), ("sync_every", c_int32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/mi355nerf.h
+SIGNATURES = {
+    "mnf_last_error": (c_char_p, []),
+    "mnf_version": (c_int32, []),
+    "mnf_device_count": (c_int32, []),
+    "mnf_ray_aabb_intersect": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_float, c_float, c_float,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_traverse_grids": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
+                                     c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_float, c_float, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_exclusive_sum": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "mnf_render_weight_from_density": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_generate_rays": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mnf_field_create": (c_int32, [POINTER(FieldConfig), POINTER(c_void_p)]),
+    "mnf_field_destroy": (c_int32, [c_void_p]),
+    "mnf_field_param_count": (c_int64, [c_void_p, c_int32]),
+    "mnf_field_grid_meta_host": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_field_set_params": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_field_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_field_density": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mnf_field_forward_samples": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                            c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_render_workspace_bytes": (c_int64, [c_int64, c_int32]),
+    "mnf_render_test": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p, c_void_p,
+                                  c_int64, POINTER(RenderOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_score_views": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+}
+
+
+def lib_path() -> str:
+    return _LIB_FILE
+
+
+def load_library():
+    """dlopen the in-tree library and bind every symbol; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_FILE):
+            raise MnfError(f"{_LIB_FILE} is missing: build it with `python __graft_entry__.py build` "
+                           "(hipcc, gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(_LIB_FILE)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise MnfError(load_library().mnf_last_error().decode() or f"libmi355nerf error {rc}")
+
+
+def require_gpu(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MnfError("libmi355nerf operates on GPU tensors only (got a CPU tensor); there is no CPU fallback")
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def contig(t, dtype=None):
+    if t is None:
+        return None
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()

@@ -1,0 +1,45 @@
+// Shared host-side helpers for libmi355nerf.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "mi355nerf.h"
+
+namespace mnf {
+
+void set_error(const char *fmt, ...);
+
+#define MNF_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            mnf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MNF_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define MNF_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            mnf::set_error(__VA_ARGS__);      \
+            return MNF_ERR_INVALID;           \
+        }                                     \
+    } while (0)
+
+inline int launch_status(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return MNF_ERR_HIP;
+    }
+    return MNF_OK;
+}
+
+inline hipStream_t as_stream(mnf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace mnf

@@ -1,0 +1,58 @@
+// Radiance-field handle shared between field.hip (kernels) and render.hip (fused renderer).
+#pragma once
+#include <vector>
+
+#include "common.h"
+
+namespace mnf {
+
+struct LevelMeta {
+    float scale;
+    uint32_t res;
+    uint32_t size;    // entries in this level (tcnn params_in_level)
+    uint32_t offset;  // first entry of this level in the table
+    uint32_t hashed;  // 1: spatial hash, 0: dense
+};
+
+struct FieldShape {
+    int W, NH, Wh, C;
+    int blocks_total;  // 1 KiB fragment blocks of all nine weight matrices
+};
+
+}  // namespace mnf
+
+struct mnf_field_s {
+    mnf_field_config cfg;
+    mnf::FieldShape shape;
+    mnf::LevelMeta levels[16];
+    int64_t table_entries;
+    int64_t n_base_mlp, n_base, n_head, n_sem;  // fp32 parameter counts
+    // device buffers owned by the handle
+    void *d_table;       // fp16 [table_entries][4]
+    void *d_frags;       // fp16 fragment-ordered MLP weights, blocks_total KiB
+    int32_t *d_frag_src; // gather table: (buffer << 28) | index, or -1 for a structural zero
+    bool params_loaded;
+};
+
+namespace mnf {
+
+// What the fused kernel reads / writes.  mode 0: explicit positions+directions; mode 1: packed samples
+// with int64 ray indices; mode 2: renderer columns (int32 ray id, -1 = unused column).
+struct FieldIO {
+    int mode;
+    const float *positions, *directions;     // mode 0
+    const float *rays_o, *rays_d;            // mode 1, 2
+    const int64_t *ray_idx64;                // mode 1
+    const int32_t *col_ray;                  // mode 2
+    const float *t_starts, *t_ends;          // mode 1, 2
+    int64_t n;                               // modes 0, 1
+    const int32_t *n_dev;                    // mode 2: number of columns (device)
+    // outputs: user layout (modes 0,1) ...
+    float *rgb, *density, *sem;
+    // ... or the renderer's padded per-column layout (mode 2): float4 {sigma,r,g,b}, sem[32]
+    float *col_srgb, *col_sem;
+};
+
+int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream);
+
+}  // namespace mnf

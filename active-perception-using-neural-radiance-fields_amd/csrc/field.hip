@@ -1,0 +1,633 @@
+// Fused radiance-field forward for gfx950: multiresolution hash-grid gather -> base MLP ->
+// {trunc_exp density, SH + rgb head, semantic head}, one wave per 64 samples.
+//
+// Replaces the tiny-cuda-nn modules the reference builds at
+// perception/models/radiance_fields/ngp.py:108-169 and the Python glue of ngp.py:171-238.
+//
+// Data flow per wave (64 lanes, 64 samples = two 32-column tiles "ct"):
+//   * lane (c = lane&31, h = lane>>5) gathers 8 of the 16 hash levels for samples c and c+32:
+//     exactly the fp16 B-operand fragments of v_mfma_f32_32x32x16_f16 for the first layer
+//     (feature k = 16*ks + 8*h + j lives in element j of k-step ks), so encoded features never
+//     touch LDS or HBM;
+//   * every layer computes H_out^T[n][c] = sum_k W[n][k] * H_in^T[k][c]: the weights are the A
+//     operand (read from LDS, pre-permuted on the host side of the handle into fragment order,
+//     one conflict-free ds_read_b128 per lane), the activations are the B operand.  The 32x32
+//     accumulator of one layer (feature on the register index, sample on the lane) is, after
+//     ReLU + cvt to fp16, directly the B fragment of the next layer (k order
+//     32*nt + 16*s + 8*(j>>2) + 4*h + (j&3), matched by the weight permutation), so the whole
+//     MLP chain stays in registers;
+//   * the 16 base outputs sit in accumulator registers 0..7 of both lane halves: register 0 of
+//     half 0 is the density logit, the other 15 are the geo features; replacing the logit by the
+//     constant 1.0 (tcnn's input padding value) makes that fragment the input k-step of both heads.
+//
+// Precision: fp16 parameters, fp16 features/activations at every matrix-product input, fp32
+// accumulation, fp32 outputs (oracle/field.py states the same model).
+#include "field.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace mnf {
+
+typedef _Float16 half_t;
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CT = 2;                            // 32-sample column tiles per wave (lane = sample, 64 samples per wave)
+constexpr int kWavesPerBlock = 8;                // 512 samples per workgroup pass, two waves per SIMD
+constexpr int kThreads = kWavesPerBlock * 64;
+constexpr int kWaveSamples = 32 * CT;
+
+// ------------------------------------------------------------------ fragment block bookkeeping
+template <int W, int NH>
+struct Layout {
+    static constexpr int Wh = W / 2;
+    static constexpr int RT = W / 32;     // row tiles of a base hidden layer
+    static constexpr int RTh = Wh / 32;   // row tiles of a head hidden layer
+    static constexpr int KSW = W / 16;    // k-steps over a W-wide activation
+    static constexpr int KSh = Wh / 16;
+    static constexpr int o_b_in = 0;
+    static constexpr int o_b_hid = o_b_in + RT * 4;
+    static constexpr int o_b_out = o_b_hid + (NH - 1) * RT * KSW;
+    static constexpr int o_h_in = o_b_out + KSW;
+    static constexpr int o_h_hid = o_h_in + RTh * 2;
+    static constexpr int o_h_out = o_h_hid + RTh * KSh;
+    static constexpr int o_s_in = o_h_out + KSh;
+    static constexpr int o_s_hid = o_s_in + RTh * 1;
+    static constexpr int o_s_out = o_s_hid + RTh * KSh;
+    static constexpr int blocks = o_s_out + KSh;
+};
+
+struct KernelArgs {
+    const half4 *table;
+    const half8 *frags;
+    float aabb[6];
+    int C;
+    LevelMeta levels[16];   // wave-uniform: read with scalar loads
+    FieldIO io;
+};
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// One hidden layer, fused with ReLU + fp16 packing, one 32-row output tile at a time so that only
+// CT accumulator tiles are live: o[ct][2*rt + s] <- relu(W(rt,:) * b[ct])
+template <int RT_OUT, int KS>
+__device__ __forceinline__ void dense_relu(const half8 *__restrict__ w_lds, int lane, const half8 (&b)[CT][KS],
+                                           half8 (&o)[CT][RT_OUT * 2]) {
+#pragma unroll
+    for (int rt = 0; rt < RT_OUT; ++rt) {
+        f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 a = w_lds[(rt * KS + ks) * 64 + lane];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma(a, b[ct][ks], acc[ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[ct][rt * 2 + s][j] = (half_t)fmaxf(acc[ct][8 * s + j], 0.0f);
+    }
+}
+
+// Output layer (one 32-row tile, no activation)
+template <int KS>
+__device__ __forceinline__ void dense_out(const half8 *__restrict__ w_lds, int lane, const half8 (&b)[CT][KS], f32x16 (&o)[CT]) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[ct][i] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const half8 a = w_lds[ks * 64 + lane];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) o[ct] = mfma(a, b[ct][ks], o[ct]);
+    }
+}
+
+// Lane l (sample A = column l of tile 0) and lane l+32 (sample B = column l of tile 1) each hold all 16
+// features of a k-step of THEIR sample as lo = features 0..7, hi = features 8..15.  The MFMA B operand wants,
+// for tile t, lane half h to hold features 8h..8h+7 of the tile-t sample.  One v_permlane32_swap per dword
+// (lo's upper 32 lanes <-> hi's lower 32 lanes) produces exactly that: lo -> tile-0 fragment, hi -> tile-1 fragment.
+__device__ __forceinline__ void exchange_halves(half8 &lo, half8 &hi) {
+    u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(a[i], b[i], false, false);
+        a[i] = r[0]; b[i] = r[1];
+    }
+    lo = __builtin_bit_cast(half8, a); hi = __builtin_bit_cast(half8, b);
+}
+
+// One hash level (wave-uniform metadata) for the lane's sample: 8 gathers of 8 bytes, trilinear blend in fp32
+__device__ __forceinline__ void hash_level(const half4 *__restrict__ table, const LevelMeta m, const float xn[3], float (&f)[4]) {
+    float frac[3];
+    uint32_t cell[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float pos = __builtin_fmaf(m.scale, xn[d], 0.5f);
+        const float fl = floorf(pos);
+        frac[d] = pos - fl;
+        cell[d] = (uint32_t)(int32_t)fl;
+    }
+    uint32_t byte_off[8];
+    float w[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        float ww = 1.0f;
+        uint32_t p[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int bit = (corner >> d) & 1;
+            ww *= bit ? frac[d] : (1.0f - frac[d]);
+            p[d] = cell[d] + (uint32_t)bit;
+        }
+        uint32_t idx;
+        if (m.hashed) {   // uniform branch
+            idx = (p[0] ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u)) & (m.size - 1u);   // size is 2^k when hashed
+        } else {
+            idx = p[0] + p[1] * m.res + p[2] * m.res * m.res;
+            if (idx >= m.size) idx %= m.size;   // only out-of-box positions / the far corner
+        }
+        w[corner] = ww;
+        // 32-bit byte offset from the uniform table base -> global_load with an SGPR base, no 64-bit VGPR address
+        byte_off[corner] = (m.offset + idx) * 8u;
+    }
+    half4 v[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner)
+        v[corner] = *reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + byte_off[corner]);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        a0 += w[corner] * (float)v[corner][0]; a1 += w[corner] * (float)v[corner][1];
+        a2 += w[corner] * (float)v[corner][2]; a3 += w[corner] * (float)v[corner][3];
+    }
+    f[0] = a0; f[1] = a1; f[2] = a2; f[3] = a3;
+}
+
+// tcnn SphericalHarmonics degree 4 on 2u-1, u = (d+1)/2 (ngp.py:205): all 16 values of the lane's sample
+__device__ __forceinline__ void sh4(const float d[3], half8 &lo, half8 &hi) {
+    const float x = ((d[0] + 1.0f) / 2.0f) * 2.0f - 1.0f;
+    const float y = ((d[1] + 1.0f) / 2.0f) * 2.0f - 1.0f;
+    const float z = ((d[2] + 1.0f) / 2.0f) * 2.0f - 1.0f;
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    lo[0] = (half_t)0.28209479177387814f;
+    lo[1] = (half_t)(-0.48860251190291987f * y);
+    lo[2] = (half_t)(0.48860251190291987f * z);
+    lo[3] = (half_t)(-0.48860251190291987f * x);
+    lo[4] = (half_t)(1.0925484305920792f * xy);
+    lo[5] = (half_t)(-1.0925484305920792f * yz);
+    lo[6] = (half_t)(0.94617469575755997f * z2 - 0.31539156525251999f);
+    lo[7] = (half_t)(-1.0925484305920792f * xz);
+    hi[0] = (half_t)(0.54627421529603959f * x2 - 0.54627421529603959f * y2);
+    hi[1] = (half_t)(0.59004358992664352f * y * (-3.0f * x2 + y2));
+    hi[2] = (half_t)(2.8906114426405538f * xy * z);
+    hi[3] = (half_t)(0.45704579946446572f * y * (1.0f - 5.0f * z2));
+    hi[4] = (half_t)(0.3731763325901154f * z * (5.0f * z2 - 3.0f));
+    hi[5] = (half_t)(0.45704579946446572f * x * (1.0f - 5.0f * z2));
+    hi[6] = (half_t)(1.4453057213202769f * z * (x2 - y2));
+    hi[7] = (half_t)(0.59004358992664352f * x * (-x2 + 3.0f * y2));
+}
+
+// ------------------------------------------------------------------ the fused kernel
+template <int W, int NH, int MODE, bool DENSITY_ONLY>
+__global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs args) {
+    using L = Layout<W, NH>;
+    constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
+    __shared__ half8 s_w[kBlocks * 64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+
+    int64_t n = args.io.n;
+    if (MODE == 2) n = *args.io.n_dev;
+    const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
+    if ((int64_t)blockIdx.x * kWavesPerBlock >= n_tiles) return;  // uniform per block: nothing to do
+
+    for (int i = threadIdx.x; i < kBlocks * 64; i += kThreads) s_w[i] = args.frags[i];
+    __syncthreads();
+
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWavesPerBlock) {
+        // ---- this lane's sample ----
+        const int64_t col = tile * kWaveSamples + lane;
+        bool valid = col < n;
+        float pos[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 1.f};
+        if (MODE == 0) {
+            if (valid) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) pos[d] = args.io.positions[3 * col + d];
+                if (!DENSITY_ONLY)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) dir[d] = args.io.directions[3 * col + d];
+            }
+        } else {
+            int64_t ray = -1;
+            if (valid) ray = (MODE == 1) ? args.io.ray_idx64[col] : (int64_t)args.io.col_ray[col];
+            valid = ray >= 0;
+            if (valid) {
+                const float tsum = args.io.t_starts[col] + args.io.t_ends[col];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    dir[d] = args.io.rays_d[3 * ray + d];
+                    // utils.py:92 / :614: origins + dirs * (t_starts + t_ends) / 2.0
+                    pos[d] = args.io.rays_o[3 * ray + d] + (dir[d] * tsum) / 2.0f;
+                }
+            }
+        }
+        float xn[3];
+        bool selector = valid;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            xn[d] = (pos[d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);   // ngp.py:177-178
+            selector = selector && (xn[d] > 0.0f) && (xn[d] < 1.0f);               // ngp.py:179
+        }
+        if (!valid) { xn[0] = 0.5f; xn[1] = 0.5f; xn[2] = 0.5f; }
+
+        // ---- hash encode: all 16 levels of this lane's sample, then trade halves with lane^32 ----
+        half8 bfeat[CT][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float f[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t[4];
+                hash_level(args.table, args.levels[4 * ks + q], xn, t);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[4 * q + i] = t[i];
+                if (q == 1) __builtin_amdgcn_sched_barrier(0);   // at most two levels (16 gathers / lane) in flight
+            }
+            half8 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
+            exchange_halves(lo, hi);
+            bfeat[0][ks] = lo; bfeat[1][ks] = hi;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- base MLP ----
+        half8 hb[CT][L::KSW];
+        dense_relu<L::RT, 4>(s_w + L::o_b_in * 64, lane, bfeat, hb);
+#pragma unroll
+        for (int l = 0; l < NH - 1; ++l) {
+            half8 hn[CT][L::KSW];
+            dense_relu<L::RT, L::KSW>(s_w + (L::o_b_hid + l * L::RT * L::KSW) * 64, lane, hb, hn);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int k = 0; k < L::KSW; ++k) hb[ct][k] = hn[ct][k];
+        }
+        f32x16 bo[CT];
+        dense_out<L::KSW>(s_w + L::o_b_out * 64, lane, hb, bo);
+
+        // Results come back in MFMA layout: lane (c, h) holds rows {8g + 4h + i} of column c of tile ct.
+        // The density logit (row 0) of this lane's OWN sample sits in lane (lane&31) register 0 of tile h.
+        const float logit_t0 = __shfl(bo[0][0], lane & 31, 64);
+        const float logit_t1 = __shfl(bo[1][0], lane & 31, 64);
+        const float sigma = selector ? expf((h ? logit_t1 : logit_t0) - 1.0f) : 0.0f;   // ngp.py:79, :193-195
+
+        if (DENSITY_ONLY) {
+            if (col < n && args.io.density) args.io.density[col] = sigma;
+            continue;
+        }
+
+        // ---- heads ----
+        half8 bgeo[CT][1];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bgeo[ct][0][j] = (half_t)bo[ct][j];
+            if (h == 0) bgeo[ct][0][0] = (half_t)1.0f;   // tcnn pads MLP inputs with 1.0 (row 0 = density logit slot)
+        }
+        half8 hin[CT][2];
+        {
+            half8 lo, hi;
+            sh4(dir, lo, hi);
+            exchange_halves(lo, hi);
+            hin[0][0] = lo; hin[1][0] = hi;
+            hin[0][1] = bgeo[0][0]; hin[1][1] = bgeo[1][0];
+        }
+        half8 h1[CT][L::KSh], h2[CT][L::KSh];
+        f32x16 out_rgb[CT], out_sem[CT];
+        // rgb head (ngp.py:143-156, :202-213)
+        dense_relu<L::RTh, 2>(s_w + L::o_h_in * 64, lane, hin, h1);
+        dense_relu<L::RTh, L::KSh>(s_w + L::o_h_hid * 64, lane, h1, h2);
+        dense_out<L::KSh>(s_w + L::o_h_out * 64, lane, h2, out_rgb);
+        // semantic head (ngp.py:158-169, :215-220)
+        dense_relu<L::RTh, 1>(s_w + L::o_s_in * 64, lane, bgeo, h1);
+        dense_relu<L::RTh, L::KSh>(s_w + L::o_s_hid * 64, lane, h1, h2);
+        dense_out<L::KSh>(s_w + L::o_s_out * 64, lane, h2, out_sem);
+
+        // ---- write out ----
+        // rgb rows 0..2 of this lane's own sample: lane (lane&31), registers 0..2 of tile h
+        float rgb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t0 = __shfl(out_rgb[0][k], lane & 31, 64);
+            const float t1 = __shfl(out_rgb[1][k], lane & 31, 64);
+            rgb[k] = 1.0f / (1.0f + expf(-(h ? t1 : t0)));   // ngp.py:211-212
+        }
+        if (MODE == 2) {
+            if (valid) {
+                float4 v = {sigma, rgb[0], rgb[1], rgb[2]};
+                reinterpret_cast<float4 *>(args.io.col_srgb)[col] = v;
+            }
+        } else if (col < n) {
+            if (args.io.density) args.io.density[col] = sigma;
+            if (args.io.rgb) { args.io.rgb[3 * col] = rgb[0]; args.io.rgb[3 * col + 1] = rgb[1]; args.io.rgb[3 * col + 2] = rgb[2]; }
+        }
+        // semantic logits: lane (c, h) writes rows 8g + 4h + i of column c for both tiles
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int64_t scol = tile * kWaveSamples + ct * 32 + (lane & 31);
+            // validity of that column = validity of the lane that owns it
+            const bool svalid = __shfl((int)valid, ct * 32 + (lane & 31), 64) != 0;
+            if (MODE == 2) {
+                if (!svalid) continue;
+                float4 *dst = reinterpret_cast<float4 *>(args.io.col_sem + scol * 32);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v = {out_sem[ct][4 * g], out_sem[ct][4 * g + 1], out_sem[ct][4 * g + 2], out_sem[ct][4 * g + 3]};
+                    dst[2 * g + h] = v;
+                }
+            } else if (args.io.sem && scol < n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 8 * g + 4 * h + i;
+                        if (row < args.C) args.io.sem[scol * args.C + row] = out_sem[ct][4 * g + i];
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ parameter preparation kernels
+__global__ void __launch_bounds__(256) table_to_half_kernel(const float *__restrict__ src, half_t *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) dst[i] = (half_t)src[i];
+}
+
+__global__ void __launch_bounds__(256) gather_frags_kernel(const int32_t *__restrict__ src_idx, const float *__restrict__ p0,
+                                                           const float *__restrict__ p1, const float *__restrict__ p2,
+                                                           half_t *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t s = src_idx[i];
+    float v = 0.0f;
+    if (s >= 0) {
+        const int buf = s >> 28;
+        const int idx = s & 0x0FFFFFFF;
+        v = buf == 0 ? p0[idx] : (buf == 1 ? p1[idx] : p2[idx]);
+    }
+    dst[i] = (half_t)v;
+}
+
+// ------------------------------------------------------------------ host side
+static int grid_levels(const mnf_field_config &cfg, LevelMeta *levels, int64_t *total) {
+    const double pls = std::exp((std::log((double)cfg.max_resolution) - std::log((double)cfg.base_resolution)) / (cfg.n_levels - 1));
+    const double log2_pls = std::log2(pls);
+    int64_t offset = 0;
+    for (int l = 0; l < cfg.n_levels; ++l) {
+        const float scale = (float)(std::exp2(l * log2_pls) * cfg.base_resolution - 1.0);
+        const uint32_t res = (uint32_t)std::ceil((double)scale) + 1u;
+        const uint64_t dense = (uint64_t)res * res * res;
+        uint64_t n = ((dense + 7) / 8) * 8;
+        const uint64_t cap = 1ull << cfg.log2_hashmap_size;
+        if (n > cap) n = cap;
+        levels[l].scale = scale;
+        levels[l].res = res;
+        levels[l].size = (uint32_t)n;
+        levels[l].offset = (uint32_t)offset;
+        levels[l].hashed = dense > n ? 1u : 0u;
+        offset += (int64_t)n;
+    }
+    *total = offset;
+    return MNF_OK;
+}
+
+enum KMap { K_NATURAL, K_ACC, K_GEO };
+
+// Append the fragment blocks of one [n_out_real x n_in_real] matrix (row-major [out][in], at `off` in buffer `buf`).
+static void append_matrix(std::vector<int32_t> &t, int buf, int64_t off, int n_out_real, int n_in_real, int row_tiles,
+                          const std::vector<std::pair<KMap, int>> &ksteps, int geo_base, int pad_col) {
+    for (int rt = 0; rt < row_tiles; ++rt)
+        for (size_t ks = 0; ks < ksteps.size(); ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int r = lane & 31, h = lane >> 5;
+                    const int n = 32 * rt + r;
+                    int k = -1;
+                    const KMap km = ksteps[ks].first;
+                    const int kb = ksteps[ks].second;
+                    if (km == K_NATURAL) k = kb + 8 * h + j;
+                    else if (km == K_ACC) k = kb + 8 * (j >> 2) + 4 * h + (j & 3);
+                    else {
+                        const int row = 8 * (j >> 2) + 4 * h + (j & 3);
+                        k = row == 0 ? pad_col : geo_base + row - 1;
+                    }
+                    int32_t v = -1;
+                    if (n < n_out_real && k >= 0 && k < n_in_real) v = (int32_t)((buf << 28) | (int32_t)(off + (int64_t)n * n_in_real + k));
+                    t.push_back(v);
+                }
+}
+
+static std::vector<std::pair<KMap, int>> acc_ksteps(int width) {
+    std::vector<std::pair<KMap, int>> v;
+    for (int k = 0; k < width; k += 16) v.push_back({K_ACC, (k / 32) * 32 + ((k / 16) & 1) * 16});
+    return v;
+}
+
+static std::vector<int32_t> build_frag_table(const mnf_field_config &cfg) {
+    const int W = cfg.neurons, Wh = W / 2, NH = cfg.layers;
+    const int sem_pad = ((cfg.num_semantic_classes + 15) / 16) * 16;
+    std::vector<int32_t> t;
+    int64_t off = 0;
+    // mlp_base: [W][64], (NH-1) x [W][W], [16][W]
+    std::vector<std::pair<KMap, int>> nat64;
+    for (int k = 0; k < 64; k += 16) nat64.push_back({K_NATURAL, k});
+    append_matrix(t, 0, off, W, 64, W / 32, nat64, 0, 0); off += (int64_t)W * 64;
+    for (int l = 0; l < NH - 1; ++l) { append_matrix(t, 0, off, W, W, W / 32, acc_ksteps(W), 0, 0); off += (int64_t)W * W; }
+    append_matrix(t, 0, off, 16, W, 1, acc_ksteps(W), 0, 0); off += 16 * (int64_t)W;
+    // mlp_head: [Wh][32] (cols 0..15 SH, 16..30 geo, 31 pad), [Wh][Wh], [16][Wh]
+    off = 0;
+    append_matrix(t, 1, off, Wh, 32, Wh / 32, {{K_NATURAL, 0}, {K_GEO, 0}}, 16, 31); off += (int64_t)Wh * 32;
+    append_matrix(t, 1, off, Wh, Wh, Wh / 32, acc_ksteps(Wh), 0, 0); off += (int64_t)Wh * Wh;
+    append_matrix(t, 1, off, 16, Wh, 1, acc_ksteps(Wh), 0, 0);
+    // mlp_sem: [Wh][16] (cols 0..14 geo, 15 pad), [Wh][Wh], [sem_pad][Wh]
+    off = 0;
+    append_matrix(t, 2, off, Wh, 16, Wh / 32, {{K_GEO, 0}}, 0, 15); off += (int64_t)Wh * 16;
+    append_matrix(t, 2, off, Wh, Wh, Wh / 32, acc_ksteps(Wh), 0, 0); off += (int64_t)Wh * Wh;
+    append_matrix(t, 2, off, sem_pad, Wh, 1, acc_ksteps(Wh), 0, 0);
+    return t;
+}
+
+template <int W, int NH>
+static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, int grid, hipStream_t stream) {
+    KernelArgs a;
+    a.table = reinterpret_cast<const half4 *>(f->d_table);
+    a.frags = reinterpret_cast<const half8 *>(f->d_frags);
+    std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));
+    a.C = f->cfg.num_semantic_classes;
+    std::memcpy(a.levels, f->levels, sizeof(a.levels));
+    a.io = io;
+#define MNF_LAUNCH(MODE, DO) hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO>), dim3(grid), dim3(kThreads), 0, stream, a)
+    if (density_only) {
+        if (io.mode == 0) MNF_LAUNCH(0, true); else if (io.mode == 1) MNF_LAUNCH(1, true); else MNF_LAUNCH(2, true);
+    } else {
+        if (io.mode == 0) MNF_LAUNCH(0, false); else if (io.mode == 1) MNF_LAUNCH(1, false); else MNF_LAUNCH(2, false);
+    }
+#undef MNF_LAUNCH
+    return launch_status("field_kernel");
+}
+
+int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream) {
+    MNF_REQUIRE(f && f->params_loaded, "field: parameters not loaded (call mnf_field_set_params first)");
+    int grid = 256;  // one persistent workgroup per CU (LDS-limited), grid-stride over 64-sample tiles
+    if (io.mode != 2) {
+        const int64_t tiles = ceil_div(io.n, kWaveSamples);
+        if (tiles == 0) return MNF_OK;
+        const int64_t wgs = ceil_div(tiles, kWavesPerBlock);
+        if (wgs < grid) grid = (int)wgs;
+    }
+    const int W = f->cfg.neurons, NH = f->cfg.layers;
+#define MNF_CASE(w, nh) if (W == w && NH == nh) return launch_variant<w, nh>(f, io, density_only, grid, stream)
+#ifdef MNF_DEV_ONLY_128x2
+    MNF_CASE(128, 2);
+#else
+    MNF_CASE(128, 1); MNF_CASE(128, 2); MNF_CASE(128, 3); MNF_CASE(128, 4);
+    MNF_CASE(64, 1); MNF_CASE(64, 2); MNF_CASE(64, 3); MNF_CASE(64, 4);
+#endif
+#undef MNF_CASE
+    set_error("field: unsupported neurons=%d layers=%d (supported: 64|128 x 1..4)", W, NH);
+    return MNF_ERR_UNSUPPORTED;
+}
+
+}  // namespace mnf
+
+using namespace mnf;
+
+extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
+    MNF_REQUIRE(cfg && out, "field_create: null argument");
+    MNF_REQUIRE(cfg->neurons == 64 || cfg->neurons == 128, "field_create: neurons must be 64 or 128 (got %d)", cfg->neurons);
+    MNF_REQUIRE(cfg->layers >= 1 && cfg->layers <= 4, "field_create: layers must be 1..4 (got %d)", cfg->layers);
+    MNF_REQUIRE(cfg->num_semantic_classes >= 1 && cfg->num_semantic_classes <= 32,
+                "field_create: num_semantic_classes must be 1..32 (got %d)", cfg->num_semantic_classes);
+    MNF_REQUIRE(cfg->n_levels == 16 && cfg->n_features == 4, "field_create: only 16 levels x 4 features are supported");
+    MNF_REQUIRE(cfg->log2_hashmap_size >= 8 && cfg->log2_hashmap_size <= 24, "field_create: bad log2_hashmap_size");
+    mnf_field_s *f = new mnf_field_s();
+    f->cfg = *cfg;
+    grid_levels(*cfg, f->levels, &f->table_entries);
+    const int W = cfg->neurons, Wh = W / 2, NH = cfg->layers;
+    const int sem_pad = ((cfg->num_semantic_classes + 15) / 16) * 16;
+    f->n_base_mlp = (int64_t)W * 64 + (int64_t)(NH - 1) * W * W + 16 * (int64_t)W;
+    f->n_base = f->n_base_mlp + f->table_entries * 4;
+    f->n_head = (int64_t)Wh * 32 + (int64_t)Wh * Wh + 16 * (int64_t)Wh;
+    f->n_sem = (int64_t)Wh * 16 + (int64_t)Wh * Wh + (int64_t)sem_pad * Wh;
+    std::vector<int32_t> table = build_frag_table(*cfg);
+    f->shape = {W, NH, Wh, cfg->num_semantic_classes, (int)(table.size() / 512)};
+    f->d_table = nullptr; f->d_frags = nullptr; f->d_frag_src = nullptr; f->params_loaded = false;
+    hipError_t e = hipMalloc(&f->d_table, (size_t)f->table_entries * 4 * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc(&f->d_frags, table.size() * sizeof(uint16_t) + sizeof(LevelMeta) * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_frag_src, table.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(f->d_frag_src, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy((char *)f->d_frags + table.size() * sizeof(uint16_t), f->levels, sizeof(LevelMeta) * 16, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("field_create: %s", hipGetErrorString(e));
+        mnf_field_destroy(f);
+        return MNF_ERR_HIP;
+    }
+    *out = f;
+    return MNF_OK;
+}
+
+extern "C" int mnf_field_destroy(mnf_field_t f) {
+    if (!f) return MNF_OK;
+    if (f->d_table) (void)hipFree(f->d_table);
+    if (f->d_frags) (void)hipFree(f->d_frags);
+    if (f->d_frag_src) (void)hipFree(f->d_frag_src);
+    delete f;
+    return MNF_OK;
+}
+
+extern "C" int64_t mnf_field_param_count(mnf_field_t f, int32_t which) {
+    if (!f) return -1;
+    return which == 0 ? f->n_base : (which == 1 ? f->n_head : (which == 2 ? f->n_sem : -1));
+}
+
+extern "C" int mnf_field_grid_meta_host(mnf_field_t f, float *scale_host, int32_t *res_host, int32_t *size_host,
+                                        int64_t *offset_host, int32_t *hashed_host) {
+    MNF_REQUIRE(f, "grid_meta: null handle");
+    for (int l = 0; l < f->cfg.n_levels; ++l) {
+        if (scale_host) scale_host[l] = f->levels[l].scale;
+        if (res_host) res_host[l] = (int32_t)f->levels[l].res;
+        if (size_host) size_host[l] = (int32_t)f->levels[l].size;
+        if (offset_host) offset_host[l] = (int64_t)f->levels[l].offset;
+        if (hashed_host) hashed_host[l] = (int32_t)f->levels[l].hashed;
+    }
+    return MNF_OK;
+}
+
+extern "C" int mnf_field_set_params(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, mnf_stream_t stream) {
+    MNF_REQUIRE(f && mlp_base && mlp_head && mlp_sem, "field_set_params: null argument");
+    hipStream_t s = as_stream(stream);
+    const int64_t n_tab = f->table_entries * 4;
+    hipLaunchKernelGGL(table_to_half_kernel, dim3(2048), dim3(256), 0, s, mlp_base + f->n_base_mlp, (half_t *)f->d_table, n_tab);
+    int rc = launch_status("table_to_half_kernel");
+    if (rc) return rc;
+    const int64_t n_frag = (int64_t)f->shape.blocks_total * 512;
+    hipLaunchKernelGGL(gather_frags_kernel, dim3((unsigned)ceil_div(n_frag, 256)), dim3(256), 0, s, f->d_frag_src, mlp_base, mlp_head,
+                       mlp_sem, (half_t *)f->d_frags, n_frag);
+    rc = launch_status("gather_frags_kernel");
+    if (rc) return rc;
+    f->params_loaded = true;
+    return MNF_OK;
+}
+
+extern "C" int mnf_field_forward(mnf_field_t f, const float *positions, const float *directions, int64_t n,
+                                 float *rgb, float *density, float *sem, mnf_stream_t stream) {
+    MNF_REQUIRE(f, "field_forward: null handle");
+    MNF_REQUIRE(n >= 0, "field_forward: negative n");
+    if (n == 0) return MNF_OK;
+    MNF_REQUIRE(positions && directions, "field_forward: null positions/directions");
+    FieldIO io = {};
+    io.mode = 0; io.positions = positions; io.directions = directions; io.n = n;
+    io.rgb = rgb; io.density = density; io.sem = sem;
+    return launch_field(f, io, false, as_stream(stream));
+}
+
+extern "C" int mnf_field_density(mnf_field_t f, const float *positions, int64_t n, float *density, mnf_stream_t stream) {
+    MNF_REQUIRE(f, "field_density: null handle");
+    MNF_REQUIRE(n >= 0, "field_density: negative n");
+    if (n == 0) return MNF_OK;
+    MNF_REQUIRE(positions && density, "field_density: null pointer");
+    FieldIO io = {};
+    io.mode = 0; io.positions = positions; io.n = n; io.density = density;
+    return launch_field(f, io, true, as_stream(stream));
+}
+
+extern "C" int mnf_field_forward_samples(mnf_field_t f, const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                                         const float *t_starts, const float *t_ends, int64_t n,
+                                         float *rgb, float *density, float *sem, mnf_stream_t stream) {
+    MNF_REQUIRE(f, "field_forward_samples: null handle");
+    MNF_REQUIRE(n >= 0, "field_forward_samples: negative n");
+    if (n == 0) return MNF_OK;
+    MNF_REQUIRE(rays_o && rays_d && ray_indices && t_starts && t_ends, "field_forward_samples: null pointer");
+    FieldIO io = {};
+    io.mode = 1; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = ray_indices; io.t_starts = t_starts; io.t_ends = t_ends; io.n = n;
+    io.rgb = rgb; io.density = density; io.sem = sem;
+    const bool density_only = (rgb == nullptr && sem == nullptr);
+    return launch_field(f, io, density_only, as_stream(stream));
+}

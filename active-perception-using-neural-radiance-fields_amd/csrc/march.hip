@@ -1,0 +1,249 @@
+// nerfacc_cuda replacements: ray/AABB test, occupancy-grid traversal, packed scans, and the
+// pinhole ray generator.  Build with -ffp-contract=off (see march_dev.h).
+#include "common.h"
+#include "march_dev.h"
+
+namespace mnf {
+
+// ------------------------------------------------------------------ ray_aabb_intersect
+// grid.cu:284-313 — one (ray, aabb) pair per lane.
+__global__ void __launch_bounds__(256) ray_aabb_kernel(int64_t numel, int32_t n_aabbs,
+                                                       const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                       float near_plane, float far_plane,
+                                                       const float *__restrict__ aabbs, float miss,
+                                                       float *__restrict__ t_mins, float *__restrict__ t_maxs,
+                                                       uint8_t *__restrict__ hits) {
+    for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < numel; tid += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t r = tid / n_aabbs, a = tid % n_aabbs;
+        const F3 o = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+        const F3 inv = {1.0f / rays_d[3 * r], 1.0f / rays_d[3 * r + 1], 1.0f / rays_d[3 * r + 2]};
+        float t0, t1;
+        const bool hit = ray_aabb(o, inv, near_plane, far_plane, aabbs + 6 * a, t0, t1);
+        t_mins[tid] = hit ? t0 : miss;
+        t_maxs[tid] = hit ? t1 : miss;
+        hits[tid] = hit ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ traverse_grids
+struct SegOut {
+    float *vals; int64_t *ray_indices; uint8_t *is_left; uint8_t *is_right; uint8_t *is_valid;
+    const int64_t *chunk_starts; int64_t *chunk_cnts;
+};
+
+// Sink reproducing the interval / sample bookkeeping of grid.cu:219-257.
+struct PackedSink {
+    SegOut iv, sm;
+    bool first_pass;
+    int64_t iv_start, sm_start, tid;
+    int64_t n_intervals;
+    __device__ __forceinline__ void sample(float t_last, float t_next, bool continuous, int32_t n_samples) {
+        if (iv.chunk_cnts) {
+            if (!continuous) {
+                if (!first_pass) {
+                    const int64_t i0 = iv_start + n_intervals;
+                    iv.vals[i0] = t_last; iv.ray_indices[i0] = tid; iv.is_left[i0] = 1;
+                    iv.vals[i0 + 1] = t_next; iv.ray_indices[i0 + 1] = tid; iv.is_right[i0 + 1] = 1;
+                }
+                n_intervals += 2;
+            } else {
+                if (!first_pass) {
+                    const int64_t i0 = iv_start + n_intervals;
+                    iv.vals[i0] = t_next; iv.ray_indices[i0] = tid; iv.is_left[i0 - 1] = 1; iv.is_right[i0] = 1;
+                }
+                n_intervals += 1;
+            }
+        }
+        if (sm.chunk_cnts && !first_pass) {
+            const int64_t i0 = sm_start + n_samples;
+            sm.vals[i0] = (t_next + t_last) * 0.5f;
+            sm.ray_indices[i0] = tid;
+            if (sm.is_valid) sm.is_valid[i0] = 1;
+        }
+    }
+};
+
+__global__ void __launch_bounds__(256) traverse_kernel(int32_t n_rays, const float *__restrict__ rays_o,
+                                                       const float *__restrict__ rays_d, const uint8_t *__restrict__ rays_mask,
+                                                       int32_t n_grids, I3 res, const uint8_t *__restrict__ binaries,
+                                                       const float *__restrict__ aabbs, const uint8_t *__restrict__ hits,
+                                                       const float *__restrict__ t_sorted, const int64_t *__restrict__ t_indices,
+                                                       const float *__restrict__ near_planes, const float *__restrict__ far_planes,
+                                                       float step_size, float cone_angle, int32_t limit, bool first_pass,
+                                                       SegOut iv, SegOut sm, float *__restrict__ terminate_planes) {
+    const int64_t cells = (int64_t)res.x * res.y * res.z;
+    for (int32_t tid = blockIdx.x * blockDim.x + threadIdx.x; tid < n_rays; tid += blockDim.x * gridDim.x) {
+        if (rays_mask && !rays_mask[tid]) continue;
+        if (iv.chunk_cnts && !first_pass && iv.chunk_cnts[tid] == 0) continue;
+        if (sm.chunk_cnts && !first_pass && sm.chunk_cnts[tid] == 0) continue;
+        PackedSink sink;
+        sink.iv = iv; sink.sm = sm; sink.first_pass = first_pass; sink.tid = tid; sink.n_intervals = 0;
+        sink.iv_start = (!first_pass && iv.chunk_cnts) ? iv.chunk_starts[tid] : 0;
+        sink.sm_start = (!first_pass && sm.chunk_cnts) ? sm.chunk_starts[tid] : 0;
+        const float near_plane = near_planes[tid], far_plane = far_planes[tid];
+        const F3 org = {rays_o[3 * tid], rays_o[3 * tid + 1], rays_o[3 * tid + 2]};
+        const F3 dir = {rays_d[3 * tid], rays_d[3 * tid + 1], rays_d[3 * tid + 2]};
+        const F3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+        const int32_t base_hits = tid * n_grids, base_t = tid * n_grids * 2;
+        MarchState st = {near_plane, false, 0};
+        for (int32_t i = base_t; i < base_t + n_grids * 2 - 1; ++i) {   // grid.cu:125-151
+            const bool is_entering = t_indices[i] < n_grids;
+            int64_t level = t_indices[i] % n_grids;
+            if (!hits[base_hits + level]) continue;
+            if (!is_entering) {
+                if (t_indices[i + 1] < n_grids) continue;
+                level = t_indices[i + 1] % n_grids;
+                if (!hits[base_hits + level]) continue;
+            }
+            const float this_tmin = fmaxf(t_sorted[i], near_plane);
+            const float this_tmax = fminf(t_sorted[i + 1], far_plane);
+            if (this_tmin >= this_tmax) continue;
+            march_segment(org, dir, inv, this_tmin, this_tmax, aabbs + level * 6, res, binaries + level * cells,
+                          step_size, cone_angle, limit, st, sink);
+        }
+        if (terminate_planes) terminate_planes[tid] = st.t_last;
+        if (iv.chunk_cnts) iv.chunk_cnts[tid] = sink.n_intervals;
+        if (sm.chunk_cnts) sm.chunk_cnts[tid] = st.n_samples;
+    }
+}
+
+// ------------------------------------------------------------------ packed scans
+// One lane per ray: chunks are short (<= a few hundred samples) and consecutive lanes own
+// consecutive chunks, so the wave streams a contiguous window.  Sequential fp32 order == oracle.
+__global__ void __launch_bounds__(256) exclusive_sum_kernel(int32_t n_rays, const int64_t *__restrict__ starts,
+                                                            const int64_t *__restrict__ cnts, const float *__restrict__ in,
+                                                            float *__restrict__ out, bool backward) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const int64_t s = starts[r], c = cnts[r];
+    float acc = 0.0f;
+    if (!backward) for (int64_t k = 0; k < c; ++k) { out[s + k] = acc; acc += in[s + k]; }
+    else           for (int64_t k = c - 1; k >= 0; --k) { out[s + k] = acc; acc += in[s + k]; }
+}
+
+// volrend.py:258-267 + :361-365 fused: sigma*dt -> alpha, T = exp(-excl_sum) * prefix, w = T*alpha
+__global__ void __launch_bounds__(256) weight_from_density_kernel(int32_t n_rays, const int64_t *__restrict__ starts,
+                                                                  const int64_t *__restrict__ cnts,
+                                                                  const float *__restrict__ ts, const float *__restrict__ te,
+                                                                  const float *__restrict__ sig, const float *__restrict__ prefix,
+                                                                  float *__restrict__ w, float *__restrict__ tr, float *__restrict__ al) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const int64_t s = starts[r], c = cnts[r];
+    float acc = 0.0f;
+    for (int64_t k = s; k < s + c; ++k) {
+        const float sdt = sig[k] * (te[k] - ts[k]);
+        const float alpha = 1.0f - expf(-sdt);
+        float trans = expf(-acc);
+        if (prefix) trans *= prefix[k];
+        acc += sdt;
+        if (w) w[k] = trans * alpha;
+        if (tr) tr[k] = trans;
+        if (al) al[k] = alpha;
+    }
+}
+
+// ------------------------------------------------------------------ ray generation
+// habitat_to_data.py:274-301; arithmetic order pinned by tests/golden/raygen.npz (oracle/render.py).
+__global__ void __launch_bounds__(256) raygen_kernel(const float *__restrict__ c2w, int32_t n_views, int32_t width, int32_t height,
+                                                     float focal, const int64_t *__restrict__ pix_idx, int64_t n_pix,
+                                                     float *__restrict__ origins, float *__restrict__ viewdirs) {
+    const int64_t total = (int64_t)n_views * n_pix;
+    const float cx = (float)width * 0.5f, cy = (float)height * 0.5f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t v = i / n_pix, p = i % n_pix;
+        const int64_t pix = pix_idx ? pix_idx[p] : p;
+        const float x = (float)(pix % width), y = (float)(pix / width);
+        const float *m = c2w + v * 12;
+        const float cam0 = (x - cx + 0.5f) / focal;
+        const float cam1 = (y - cy + 0.5f) / focal * -1.0f;
+        const float cam2 = -1.0f;
+        const float dx = (cam0 * m[0] + cam1 * m[1]) + cam2 * m[2];
+        const float dy = (cam0 * m[4] + cam1 * m[5]) + cam2 * m[6];
+        const float dz = (cam0 * m[8] + cam1 * m[9]) + cam2 * m[10];
+        const float n = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+        origins[3 * i] = m[3]; origins[3 * i + 1] = m[7]; origins[3 * i + 2] = m[11];
+        viewdirs[3 * i] = dx / n; viewdirs[3 * i + 1] = dy / n; viewdirs[3 * i + 2] = dz / n;
+    }
+}
+
+static inline int grid_for(int64_t n, int threads) {
+    int64_t b = ceil_div(n, threads);
+    return (int)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
+}
+
+}  // namespace mnf
+
+using namespace mnf;
+
+extern "C" int mnf_ray_aabb_intersect(const float *rays_o, const float *rays_d, int32_t n_rays, const float *aabbs,
+                                      int32_t n_aabbs, float near_plane, float far_plane, float miss_value,
+                                      float *t_mins, float *t_maxs, uint8_t *hits, mnf_stream_t stream) {
+    MNF_REQUIRE(n_rays >= 0 && n_aabbs > 0, "ray_aabb_intersect: bad sizes (%d rays, %d aabbs)", n_rays, n_aabbs);
+    const int64_t numel = (int64_t)n_rays * n_aabbs;
+    if (numel == 0) return MNF_OK;
+    MNF_REQUIRE(rays_o && rays_d && aabbs && t_mins && t_maxs && hits, "ray_aabb_intersect: null pointer");
+    hipLaunchKernelGGL(ray_aabb_kernel, dim3(grid_for(numel, 256)), dim3(256), 0, as_stream(stream), numel, n_aabbs,
+                       rays_o, rays_d, near_plane, far_plane, aabbs, miss_value, t_mins, t_maxs, hits);
+    return launch_status("ray_aabb_kernel");
+}
+
+extern "C" int mnf_traverse_grids(const float *rays_o, const float *rays_d, const uint8_t *rays_mask, int32_t n_rays,
+                                  const uint8_t *binaries, const float *aabbs, int32_t n_grids,
+                                  int32_t res_x, int32_t res_y, int32_t res_z,
+                                  const uint8_t *hits, const float *t_sorted, const int64_t *t_indices,
+                                  const float *near_planes, const float *far_planes,
+                                  float step_size, float cone_angle, int32_t traverse_steps_limit, int32_t first_pass,
+                                  float *iv_vals, int64_t *iv_ray_indices, uint8_t *iv_is_left, uint8_t *iv_is_right,
+                                  const int64_t *iv_chunk_starts, int64_t *iv_chunk_cnts,
+                                  float *sm_vals, int64_t *sm_ray_indices, uint8_t *sm_is_valid,
+                                  const int64_t *sm_chunk_starts, int64_t *sm_chunk_cnts,
+                                  float *terminate_planes, mnf_stream_t stream) {
+    MNF_REQUIRE(n_rays >= 0 && n_grids > 0 && n_grids <= 8, "traverse_grids: bad sizes");
+    if (n_rays == 0) return MNF_OK;
+    MNF_REQUIRE(rays_o && rays_d && binaries && aabbs && hits && t_sorted && t_indices && near_planes && far_planes,
+                "traverse_grids: null input pointer");
+    if (!first_pass) {
+        MNF_REQUIRE(!iv_chunk_cnts || (iv_chunk_starts && iv_vals && iv_ray_indices && iv_is_left && iv_is_right),
+                    "traverse_grids: fill pass needs interval buffers");
+        MNF_REQUIRE(!sm_chunk_cnts || (sm_chunk_starts && sm_vals && sm_ray_indices), "traverse_grids: fill pass needs sample buffers");
+    }
+    SegOut iv = {iv_vals, iv_ray_indices, iv_is_left, iv_is_right, nullptr, iv_chunk_starts, iv_chunk_cnts};
+    SegOut sm = {sm_vals, sm_ray_indices, nullptr, nullptr, sm_is_valid, sm_chunk_starts, sm_chunk_cnts};
+    const I3 res = {res_x, res_y, res_z};
+    hipLaunchKernelGGL(traverse_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, as_stream(stream), n_rays, rays_o, rays_d,
+                       rays_mask, n_grids, res, binaries, aabbs, hits, t_sorted, t_indices, near_planes, far_planes,
+                       step_size, cone_angle, traverse_steps_limit, first_pass != 0, iv, sm, terminate_planes);
+    return launch_status("traverse_kernel");
+}
+
+extern "C" int mnf_exclusive_sum(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                 const float *inputs, float *outputs, int64_t n_edges, int32_t backward, mnf_stream_t stream) {
+    if (n_rays == 0 || n_edges == 0) return MNF_OK;
+    MNF_REQUIRE(chunk_starts && chunk_cnts && inputs && outputs, "exclusive_sum: null pointer");
+    hipLaunchKernelGGL(exclusive_sum_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, as_stream(stream), n_rays,
+                       chunk_starts, chunk_cnts, inputs, outputs, backward != 0);
+    return launch_status("exclusive_sum_kernel");
+}
+
+extern "C" int mnf_render_weight_from_density(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                              const float *t_starts, const float *t_ends, const float *sigmas,
+                                              const float *prefix_trans, int64_t n_samples,
+                                              float *weights, float *trans, float *alphas, mnf_stream_t stream) {
+    if (n_rays == 0 || n_samples == 0) return MNF_OK;
+    MNF_REQUIRE(chunk_starts && chunk_cnts && t_starts && t_ends && sigmas, "render_weight_from_density: null pointer");
+    hipLaunchKernelGGL(weight_from_density_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, as_stream(stream), n_rays,
+                       chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, prefix_trans, weights, trans, alphas);
+    return launch_status("weight_from_density_kernel");
+}
+
+extern "C" int mnf_generate_rays(const float *c2w, int32_t n_views, int32_t width, int32_t height, float focal,
+                                 const int64_t *pix_idx, int64_t n_pix, float *origins, float *viewdirs, mnf_stream_t stream) {
+    MNF_REQUIRE(n_views >= 0 && width > 0 && height > 0 && focal > 0, "generate_rays: bad arguments");
+    if (!pix_idx) n_pix = (int64_t)width * height;
+    if (n_views == 0 || n_pix == 0) return MNF_OK;
+    MNF_REQUIRE(c2w && origins && viewdirs, "generate_rays: null pointer");
+    hipLaunchKernelGGL(raygen_kernel, dim3(grid_for((int64_t)n_views * n_pix, 256)), dim3(256), 0, as_stream(stream), c2w,
+                       n_views, width, height, focal, pix_idx, n_pix, origins, viewdirs);
+    return launch_status("raygen_kernel");
+}

@@ -1,0 +1,155 @@
+// Device-side occupancy-grid ray marcher (one lane = one ray).
+//
+// Semantics follow the reference kernel perception/nerfacc/nerfacc/cuda/csrc/grid.cu:68-282 with
+// its helpers include/utils_grid.cuh:10-142; results are bit-identical to oracle/nerfacc_grid.c
+// (both must be built with -ffp-contract=off: every t value is a chain of separately rounded
+// fp32 operations).  The traversal is written once, parameterised by a `Sink` that receives each
+// emitted sample (t_last, t_next, continuous), so the same code serves the count pass, the fill
+// pass and the fused per-round marcher of the test-mode renderer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mnf {
+
+struct F3 { float x, y, z; };
+struct I3 { int x, y, z; };
+
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+__device__ __forceinline__ int clampi(int f, int a, int b) { return max(a, min(f, b)); }
+
+// utils_grid.cuh:10-55
+__device__ __forceinline__ bool ray_aabb(const F3 o, const F3 inv, float ray_tmin, float ray_tmax,
+                                         const float *__restrict__ aabb, float &tmin, float &tmax) {
+    float tmin_t, tmax_t;
+    if (inv.x >= 0) { tmin = (aabb[0] - o.x) * inv.x; tmax = (aabb[3] - o.x) * inv.x; }
+    else            { tmin = (aabb[3] - o.x) * inv.x; tmax = (aabb[0] - o.x) * inv.x; }
+    if (inv.y >= 0) { tmin_t = (aabb[1] - o.y) * inv.y; tmax_t = (aabb[4] - o.y) * inv.y; }
+    else            { tmin_t = (aabb[4] - o.y) * inv.y; tmax_t = (aabb[1] - o.y) * inv.y; }
+    if (tmin > tmax_t || tmin_t > tmax) return false;
+    if (tmin_t > tmin) tmin = tmin_t;
+    if (tmax_t < tmax) tmax = tmax_t;
+    if (inv.z >= 0) { tmin_t = (aabb[2] - o.z) * inv.z; tmax_t = (aabb[5] - o.z) * inv.z; }
+    else            { tmin_t = (aabb[5] - o.z) * inv.z; tmax_t = (aabb[2] - o.z) * inv.z; }
+    if (tmin > tmax_t || tmin_t > tmax) return false;
+    if (tmin_t > tmin) tmin = tmin_t;
+    if (tmax_t < tmax) tmax = tmax_t;
+    if (tmax <= 0) return false;
+    tmin = fmaxf(tmin, ray_tmin);
+    tmax = fminf(tmax, ray_tmax);
+    return true;
+}
+
+__device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min, float dt_max) {
+    return clampf(t * cone_angle, dt_min, dt_max);  // grid.cu:23-28
+}
+
+// grid.cu:158-161 / :199-203: advance t_last in dt steps until the step's midpoint passes `target`.
+// The extra `!(nt > t_last)` exit only triggers where the reference would spin forever
+// (dt below half an ulp of t_last, or NaN) — it protects the GPU from a hang.
+__device__ __forceinline__ void skip_to(float &t_last, float dt, float target) {
+    for (;;) {
+        if (t_last + dt * 0.5f >= target) break;
+        const float nt = t_last + dt;
+        if (!(nt > t_last)) break;
+        t_last = nt;
+    }
+}
+
+struct MarchState {
+    float t_last;
+    bool continuous;
+    int32_t n_samples;
+};
+
+// March one [this_tmin, this_tmax] segment of one grid level.  `binaries` points at that level's
+// [X,Y,Z] byte grid.  Returns through `st`; `sink.sample(t_last, t_next, continuous)` per sample.
+template <class Sink>
+__device__ __forceinline__ void march_segment(const F3 org, const F3 dir, const F3 inv,
+                                              float this_tmin, float this_tmax,
+                                              const float *__restrict__ ab, const I3 res,
+                                              const uint8_t *__restrict__ binaries,
+                                              float step_size, float cone_angle, int32_t limit,
+                                              MarchState &st, Sink &sink) {
+    const float eps = 1e-6f;
+    if (!st.continuous) {
+        if (step_size <= 0.0f) {
+            st.t_last = this_tmin;
+        } else {
+            float dt = calc_dt(st.t_last, cone_angle, step_size, 1e10f);
+            skip_to(st.t_last, dt, this_tmin);
+        }
+    }
+    // setup_traversal, utils_grid.cuh:58-114
+    const F3 amin = {ab[0], ab[1], ab[2]}, amax = {ab[3], ab[4], ab[5]};
+    const F3 resf = {(float)res.x, (float)res.y, (float)res.z};
+    const F3 vox = {(amax.x - amin.x) / resf.x, (amax.y - amin.y) / resf.y, (amax.z - amin.z) / resf.z};
+    const float ts = this_tmin + eps, te = this_tmax - eps;
+    const F3 rs = {org.x + dir.x * ts, org.y + dir.y * ts, org.z + dir.z * ts};
+    const F3 re = {org.x + dir.x * te, org.y + dir.y * te, org.z + dir.z * te};
+    I3 cur = {(int)(((rs.x - amin.x) / (amax.x - amin.x)) * resf.x),
+              (int)(((rs.y - amin.y) / (amax.y - amin.y)) * resf.y),
+              (int)(((rs.z - amin.z) / (amax.z - amin.z)) * resf.z)};
+    cur.x = clampi(cur.x, 0, res.x - 1); cur.y = clampi(cur.y, 0, res.y - 1); cur.z = clampi(cur.z, 0, res.z - 1);
+    I3 fin = {(int)(((re.x - amin.x) / (amax.x - amin.x)) * resf.x),
+              (int)(((re.y - amin.y) / (amax.y - amin.y)) * resf.y),
+              (int)(((re.z - amin.z) / (amax.z - amin.z)) * resf.z)};
+    fin.x = clampi(fin.x, 0, res.x - 1); fin.y = clampi(fin.y, 0, res.y - 1); fin.z = clampi(fin.z, 0, res.z - 1);
+    const I3 start = {cur.x + (dir.x > 0 ? 1 : 0), cur.y + (dir.y > 0 ? 1 : 0), cur.z + (dir.z > 0 ? 1 : 0)};
+    const F3 tmx = {((amin.x + (((float)start.x * vox.x) - rs.x)) * inv.x) + this_tmin,
+                    ((amin.y + (((float)start.y * vox.y) - rs.y)) * inv.y) + this_tmin,
+                    ((amin.z + (((float)start.z * vox.z) - rs.z)) * inv.z) + this_tmin};
+    F3 tdist = {dir.x == 0.0f ? this_tmax : tmx.x, dir.y == 0.0f ? this_tmax : tmx.y, dir.z == 0.0f ? this_tmax : tmx.z};
+    const F3 stepf = {dir.x == 0.0f ? 0.0f : (dir.x > 0.0f ? 1.0f : -1.0f),
+                      dir.y == 0.0f ? 0.0f : (dir.y > 0.0f ? 1.0f : -1.0f),
+                      dir.z == 0.0f ? 0.0f : (dir.z > 0.0f ? 1.0f : -1.0f)};
+    const I3 step = {(int)stepf.x, (int)stepf.y, (int)stepf.z};
+    const F3 dtmp = {vox.x * inv.x * stepf.x, vox.y * inv.y * stepf.y, vox.z * inv.z * stepf.z};
+    const F3 delta = {dir.x == 0.0f ? this_tmax : dtmp.x, dir.y == 0.0f ? this_tmax : dtmp.y, dir.z == 0.0f ? this_tmax : dtmp.z};
+    const I3 overflow = {fin.x + step.x, fin.y + step.y, fin.z + step.z};
+
+    while (limit <= 0 || st.n_samples < limit) {
+        float t_traverse = fminf(tdist.x, fminf(tdist.y, tdist.z));
+        t_traverse = fminf(t_traverse, this_tmax);
+        const int64_t cell = (int64_t)cur.x * res.y * res.z + (int64_t)cur.y * res.z + cur.z;
+        if (!binaries[cell]) {
+            if (step_size <= 0.0f) {
+                st.t_last = t_traverse;
+            } else {
+                float dt = calc_dt(st.t_last, cone_angle, step_size, 1e10f);
+                skip_to(st.t_last, dt, t_traverse);
+            }
+            st.continuous = false;
+        } else {
+            while (limit <= 0 || st.n_samples < limit) {
+                float t_next;
+                if (step_size <= 0.0f) {
+                    t_next = t_traverse;
+                } else {
+                    float dt = calc_dt(st.t_last, cone_angle, step_size, 1e10f);
+                    if (st.t_last + dt * 0.5f >= t_traverse) break;
+                    t_next = st.t_last + dt;
+                    if (!(t_next > st.t_last)) return;  // hang guard, see skip_to()
+                }
+                sink.sample(st.t_last, t_next, st.continuous, st.n_samples);
+                st.n_samples++;
+                st.continuous = true;
+                st.t_last = t_next;
+                if (t_next >= t_traverse) break;
+            }
+        }
+        // single_traversal, utils_grid.cuh:116-142
+        if (tdist.x < tdist.y && tdist.x < tdist.z) {
+            cur.x += step.x; tdist.x += delta.x;
+            if (cur.x == overflow.x) break;
+        } else if (tdist.y < tdist.z) {
+            cur.y += step.y; tdist.y += delta.y;
+            if (cur.y == overflow.y) break;
+        } else {
+            cur.z += step.z; tdist.z += delta.z;
+            if (cur.z == overflow.z) break;
+        }
+    }
+}
+
+}  // namespace mnf

@@ -1,0 +1,457 @@
+// Fused test-mode renderers and the predictive-information scorer.
+//
+//   mnf_render_test  <- perception/models/utils.py:555-779 (render_image_with_occgrid_test) and
+//                       utils.py:782-1032 (render_probablistic_image_with_occgrid_test)
+//   mnf_score_views  <- scripts/pipeline.py:727-781
+//
+// The reference runs <=256 host-synchronised rounds per call (utils.py:666-757): count alive rays
+// (`.item()`), march <= n_samples new samples per alive ray, query the field, composite with the
+// carried transmittance, retire rays.  Here a round is four dependent launches with every
+// data-dependent quantity (alive counts, per-view n_samples, number of sample columns) kept on the
+// device, and many independent reference calls ("views" of rays_per_view rays) advance through the
+// same launches, each with its own round schedule.
+//
+// Build with -ffp-contract=off (march_dev.h).
+#include "field.h"
+#include "march_dev.h"
+
+namespace mnf {
+
+constexpr int kRayThreads = 256;
+
+struct RenderWs {
+    // per ray
+    float *near_plane, *t_min, *t_max;
+    int32_t *col0, *cnt;
+    uint8_t *alive, *hit, *marched;
+    // per view
+    int32_t *alive_count, *n_samples, *iter_samples, *active;
+    // global
+    int32_t *n_cols, *any_active;
+    // per column
+    int32_t *col_ray;
+    float *col_ts, *col_te, *col_srgb, *col_sem;
+    int64_t col_cap;
+};
+
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_view) {
+    const int64_t n_views = n_rays / rays_per_view;
+    const int64_t col_cap = 4 * n_rays;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    char *p;
+    p = take(n_rays * 4); if (ws) ws->near_plane = (float *)p;
+    p = take(n_rays * 4); if (ws) ws->t_min = (float *)p;
+    p = take(n_rays * 4); if (ws) ws->t_max = (float *)p;
+    p = take(n_rays * 4); if (ws) ws->col0 = (int32_t *)p;
+    p = take(n_rays * 4); if (ws) ws->cnt = (int32_t *)p;
+    p = take(n_rays); if (ws) ws->alive = (uint8_t *)p;
+    p = take(n_rays); if (ws) ws->hit = (uint8_t *)p;
+    p = take(n_rays); if (ws) ws->marched = (uint8_t *)p;
+    p = take(n_views * 4); if (ws) ws->alive_count = (int32_t *)p;
+    p = take(n_views * 4); if (ws) ws->n_samples = (int32_t *)p;
+    p = take(n_views * 4); if (ws) ws->iter_samples = (int32_t *)p;
+    p = take(n_views * 4); if (ws) ws->active = (int32_t *)p;
+    p = take(256); if (ws) { ws->n_cols = (int32_t *)p; ws->any_active = (int32_t *)p + 1; }
+    p = take(col_cap * 4); if (ws) ws->col_ray = (int32_t *)p;
+    p = take(col_cap * 4); if (ws) ws->col_ts = (float *)p;
+    p = take(col_cap * 4); if (ws) ws->col_te = (float *)p;
+    p = take(col_cap * 16); if (ws) ws->col_srgb = (float *)p;
+    p = take(col_cap * 128); if (ws) ws->col_sem = (float *)p;
+    if (ws) ws->col_cap = col_cap;
+    return (int64_t)off;
+}
+
+struct RenderOut {
+    float *rgb, *acc, *depth, *sem, *rgb_var, *depth_var;
+    int64_t *total_samples;
+};
+
+// ------------------------------------------------------------------ kernels
+// utils.py:640-664: zero the accumulators, all rays alive, one ray/AABB test per call
+__global__ void __launch_bounds__(kRayThreads) init_kernel(int64_t n_rays, int32_t rays_per_view, int32_t C,
+                                                           const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                           float a0, float a1, float a2, float a3, float a4, float a5,
+                                                           float near_plane, RenderWs ws, RenderOut out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) { *out.total_samples = 0; }
+    if (r < n_rays / rays_per_view) { ws.alive_count[r] = rays_per_view; ws.iter_samples[r] = 0; }
+    if (r >= n_rays) return;
+    const float ab[6] = {a0, a1, a2, a3, a4, a5};
+    const F3 o = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    const F3 inv = {1.0f / rays_d[3 * r], 1.0f / rays_d[3 * r + 1], 1.0f / rays_d[3 * r + 2]};
+    float t0, t1;
+    const bool hit = ray_aabb(o, inv, -INFINITY, INFINITY, ab, t0, t1);   // utils.py:658 (default near/far)
+    ws.t_min[r] = hit ? t0 : INFINITY;
+    ws.t_max[r] = hit ? t1 : INFINITY;
+    ws.hit[r] = hit;
+    ws.alive[r] = 1;
+    ws.near_plane[r] = near_plane;
+    out.rgb[3 * r] = 0.f; out.rgb[3 * r + 1] = 0.f; out.rgb[3 * r + 2] = 0.f;
+    out.acc[r] = 0.f; out.depth[r] = 0.f;
+    for (int k = 0; k < C; ++k) out.sem[r * C + k] = 0.f;
+    if (out.rgb_var) { out.rgb_var[3 * r] = 0.f; out.rgb_var[3 * r + 1] = 0.f; out.rgb_var[3 * r + 2] = 0.f; }
+    if (out.depth_var) out.depth_var[r] = 0.f;
+}
+
+// utils.py:666-672 per view: n_alive -> n_samples, iter_samples; also resets the round's counters
+__global__ void __launch_bounds__(256) round_prep_kernel(int32_t n_views, int32_t rays_per_view, int32_t max_samples,
+                                                         int32_t min_samples, RenderWs ws) {
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    int any = 0;
+    for (int v = threadIdx.x; v < n_views; v += blockDim.x) {
+        const int n_alive = ws.alive_count[v];
+        int act = 0;
+        if (ws.iter_samples[v] < max_samples && n_alive > 0) {
+            const int ns = max(min(rays_per_view / n_alive, 64), min_samples);
+            ws.n_samples[v] = ns;
+            ws.iter_samples[v] += ns;
+            act = 1;
+        }
+        ws.active[v] = act;
+        ws.alive_count[v] = 0;   // re-counted by composite_kernel; rays of inactive views are never marched again
+        any |= act;
+    }
+    if (any) atomicOr(&s_any, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { *ws.any_active = s_any; *ws.n_cols = 0; }
+}
+
+struct RoundSink {
+    int32_t *col_ray; float *col_ts, *col_te;
+    int32_t col0, ray;
+    __device__ __forceinline__ void sample(float t_last, float t_next, bool, int32_t k) {
+        col_ray[col0 + k] = ray; col_ts[col0 + k] = t_last; col_te[col0 + k] = t_next;
+    }
+};
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// utils.py:674-696: one traversal of <= n_samples steps per alive ray (over-allocated mode of grid.cu:364-404)
+__global__ void __launch_bounds__(kRayThreads) round_march_kernel(int64_t n_rays, int32_t rays_per_view,
+                                                                  const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                                  const uint8_t *__restrict__ binaries, I3 res,
+                                                                  float a0, float a1, float a2, float a3, float a4, float a5,
+                                                                  float far_plane, float step_size, float cone_angle, RenderWs ws) {
+    __shared__ int s_wave_tot[kRayThreads / 64];
+    __shared__ int s_base;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool go = false;
+    int ns = 0;
+    if (r < n_rays) {
+        const int v = (int)(r / rays_per_view);
+        go = ws.alive[r] && ws.active[v];
+        ns = go ? ws.n_samples[v] : 0;
+        ws.marched[r] = go;
+    }
+    const int incl = wave_inclusive_scan(ns, lane);
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < kRayThreads / 64; ++w) tot += s_wave_tot[w];
+        s_base = tot ? atomicAdd(ws.n_cols, tot) : 0;
+    }
+    __syncthreads();
+    if (!go) return;
+    int col0 = s_base + incl - ns;
+    for (int w = 0; w < wave; ++w) col0 += s_wave_tot[w];
+
+    const float ab[6] = {a0, a1, a2, a3, a4, a5};
+    const F3 org = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    const F3 dir = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const F3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+    const float near_plane = ws.near_plane[r];
+    MarchState st = {near_plane, false, 0};
+    RoundSink sink = {ws.col_ray, ws.col_ts, ws.col_te, col0, (int32_t)r};
+    if (ws.hit[r]) {   // single grid level: the only interval is [t_min, t_max] (grid.cu:125-151 with n_grids == 1)
+        const float this_tmin = fmaxf(ws.t_min[r], near_plane);
+        const float this_tmax = fminf(ws.t_max[r], far_plane);
+        if (this_tmin < this_tmax)
+            march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, binaries, step_size, cone_angle, ns, st, sink);
+    }
+    for (int k = st.n_samples; k < ns; ++k) ws.col_ray[col0 + k] = -1;   // unused columns of this ray's allocation
+    ws.col0[r] = col0;
+    ws.cnt[r] = st.n_samples;
+    ws.near_plane[r] = st.t_last;   // utils.py:749 near_planes = termination_planes
+}
+
+// utils.py:704-757 (+ :984-999 for the probabilistic variant): composite this round's samples of one ray
+__global__ void __launch_bounds__(kRayThreads) composite_kernel(int64_t n_rays, int32_t rays_per_view, int32_t C,
+                                                                float alpha_thre, float opc_thre, int probabilistic,
+                                                                RenderWs ws, RenderOut out) {
+    __shared__ int s_alive;
+    __shared__ int s_kept;
+    if (threadIdx.x == 0) { s_alive = 0; s_kept = 0; }
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r_first = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t r_last = min(r_first + (int64_t)blockDim.x, n_rays) - 1;
+    const bool one_view = (r_first / rays_per_view) == (r_last / rays_per_view);
+    int kept = 0;
+    bool still_alive = false;
+    if (r < n_rays && ws.marched[r]) {
+        const int v = (int)(r / rays_per_view);
+        const int cnt = ws.cnt[r], col0 = ws.col0[r];
+        float opacity = out.acc[r];
+        const float prefix = 1.0f - opacity;                         // utils.py:712
+        float c0 = out.rgb[3 * r], c1 = out.rgb[3 * r + 1], c2 = out.rgb[3 * r + 2];
+        float depth = out.depth[r];
+        float sem[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sem[k] = (k < C) ? out.sem[r * C + k] : 0.f;
+        float acc_sdt = 0.f;
+        for (int j = 0; j < cnt; ++j) {
+            const int col = col0 + j;
+            const float ts = ws.col_ts[col], te = ws.col_te[col];
+            const float4 s = reinterpret_cast<const float4 *>(ws.col_srgb)[col];
+            const float sdt = s.x * (te - ts);
+            const float alpha = 1.0f - expf(-sdt);
+            const float w = expf(-acc_sdt) * prefix * alpha;          // volrend.py:258-267, :361-365
+            acc_sdt += sdt;
+            if (alpha_thre > 0.f && !(alpha >= alpha_thre)) continue; // utils.py:714-725
+            ++kept;
+            c0 += w * s.y; c1 += w * s.z; c2 += w * s.w;
+            opacity += w;
+            depth += w * ((ts + te) / 2.0f);
+            const float4 *sp = reinterpret_cast<const float4 *>(ws.col_sem + (int64_t)col * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 t = sp[q];
+                sem[4 * q] += w * t.x; sem[4 * q + 1] += w * t.y; sem[4 * q + 2] += w * t.z; sem[4 * q + 3] += w * t.w;
+            }
+        }
+        if (probabilistic) {
+            // variance terms use the accumulators AFTER this round (running, un-normalised means)
+            float v0 = out.rgb_var[3 * r], v1 = out.rgb_var[3 * r + 1], v2 = out.rgb_var[3 * r + 2], dv = out.depth_var[r];
+            acc_sdt = 0.f;
+            for (int j = 0; j < cnt; ++j) {
+                const int col = col0 + j;
+                const float ts = ws.col_ts[col], te = ws.col_te[col];
+                const float4 s = reinterpret_cast<const float4 *>(ws.col_srgb)[col];
+                const float sdt = s.x * (te - ts);
+                const float alpha = 1.0f - expf(-sdt);
+                const float w = expf(-acc_sdt) * prefix * alpha;
+                acc_sdt += sdt;
+                if (alpha_thre > 0.f && !(alpha >= alpha_thre)) continue;
+                const float d0 = s.y - c0, d1 = s.z - c1, d2 = s.w - c2;
+                v0 += w * (d0 * d0); v1 += w * (d1 * d1); v2 += w * (d2 * d2);
+                const float dd = (ts + te) / 2.0f - depth;
+                dv += w * (dd * dd);
+            }
+            out.rgb_var[3 * r] = v0; out.rgb_var[3 * r + 1] = v1; out.rgb_var[3 * r + 2] = v2; out.depth_var[r] = dv;
+        }
+        out.rgb[3 * r] = c0; out.rgb[3 * r + 1] = c1; out.rgb[3 * r + 2] = c2;
+        out.acc[r] = opacity; out.depth[r] = depth;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) if (k < C) out.sem[r * C + k] = sem[k];
+        still_alive = (opacity <= opc_thre) && (cnt == ws.n_samples[v]);   // utils.py:751-756
+        ws.alive[r] = still_alive;
+        if (!one_view && still_alive) atomicAdd(&ws.alive_count[v], 1);
+    }
+    // block-aggregated counters
+    const unsigned long long m_alive = __ballot(still_alive);
+    int wave_kept = kept;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wave_kept += __shfl_xor(wave_kept, d, 64);
+    if ((threadIdx.x & 63) == 0) {
+        if (one_view && m_alive) atomicAdd(&s_alive, __popcll(m_alive));
+        if (wave_kept) atomicAdd(&s_kept, wave_kept);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (one_view && s_alive) atomicAdd(&ws.alive_count[r_first / rays_per_view], s_alive);
+        if (s_kept) atomicAdd((unsigned long long *)out.total_samples, (unsigned long long)s_kept);
+    }
+}
+
+// utils.py:759-760
+__global__ void __launch_bounds__(kRayThreads) finalize_kernel(int64_t n_rays, float b0, float b1, float b2, RenderOut out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float op = out.acc[r];
+    out.rgb[3 * r] = out.rgb[3 * r] + b0 * (1.0f - op);
+    out.rgb[3 * r + 1] = out.rgb[3 * r + 1] + b1 * (1.0f - op);
+    out.rgb[3 * r + 2] = out.rgb[3 * r + 2] + b2 * (1.0f - op);
+    out.depth[r] = out.depth[r] / fmaxf(op, 1.1920928955078125e-07f);   // torch.finfo(float32).eps
+}
+
+// ------------------------------------------------------------------ scorer (pipeline.py:727-781), one block per view
+__device__ __forceinline__ double block_sum(double v, double *s_buf) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_buf[w];
+    return t;
+}
+
+__global__ void __launch_bounds__(256) score_kernel(const float *__restrict__ rgb_var, const float *__restrict__ depth_var,
+                                                    const float *__restrict__ acc, const float *__restrict__ sem,
+                                                    int M, int V, int P, int C, double *__restrict__ terms) {
+    __shared__ double s_buf[4];
+    const int v = blockIdx.x;
+    const double k2pie = 2.0 * 3.14159265358979323846 * 2.71828182845904523536;
+    double s_rgb = 0.0, s_dep = 0.0, s_sem = 0.0, s_occ = 0.0;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        // rgb / depth: entropy of the summed variance minus mean member entropy (pipeline.py:727-746)
+        for (int ch = 0; ch < 3; ++ch) {
+            double sum_var = 0.0, mean_ce = 0.0;
+            for (int m = 0; m < M; ++m) {
+                const double x = rgb_var[(((int64_t)m * V + v) * P + p) * 3 + ch];
+                sum_var += x;
+                mean_ce += log(k2pie * x + 1e-4) / 2.0;
+            }
+            s_rgb += log(k2pie * (sum_var / 2.0) + 1e-4) / 2.0 - mean_ce / M;
+        }
+        {
+            double sum_var = 0.0, mean_ce = 0.0;
+            for (int m = 0; m < M; ++m) {
+                const double x = depth_var[((int64_t)m * V + v) * P + p];
+                sum_var += x;
+                mean_ce += log(k2pie * x + 1e-4) / 2.0;
+            }
+            s_dep += log(k2pie * (sum_var / 2.0) + 1e-4) / 2.0 - mean_ce / M;
+        }
+        // semantics (pipeline.py:748-760)
+        {
+            double p_ens[32];
+            for (int k = 0; k < C; ++k) p_ens[k] = 0.0;
+            double mean_ce = 0.0;
+            for (int m = 0; m < M; ++m) {
+                const float *lg = sem + (((int64_t)m * V + v) * P + p) * C;
+                double mx = -1e300;
+                for (int k = 0; k < C; ++k) mx = fmax(mx, (double)lg[k]);
+                double den = 0.0;
+                for (int k = 0; k < C; ++k) den += exp((double)lg[k] - mx);
+                double ce = 0.0;
+                for (int k = 0; k < C; ++k) {
+                    const double pk = exp((double)lg[k] - mx) / den;
+                    p_ens[k] += pk;
+                    ce -= (pk + 1e-4) * log(pk + 1e-4);
+                }
+                mean_ce += ce;
+            }
+            double ent = 0.0;
+            for (int k = 0; k < C; ++k) { const double pk = p_ens[k] / M; ent -= (pk + 1e-4) * log(pk + 1e-4); }
+            s_sem += ent - mean_ce / M;
+        }
+        // occupancy (pipeline.py:762-773)
+        {
+            double a_ens = 0.0, mean_ce = 0.0;
+            for (int m = 0; m < M; ++m) {
+                const double a = acc[((int64_t)m * V + v) * P + p];
+                a_ens += a;
+                mean_ce += -(a + 1e-4) * log(a + 1e-4) - (1.0 - a + 1e-4) * log(1.0 - a + 1e-4);
+            }
+            a_ens /= M;
+            s_occ += -(a_ens + 1e-4) * log(a_ens + 1e-4) - (1.0 - a_ens + 1e-4) * log(1.0 - a_ens + 1e-4) - mean_ce / M;
+        }
+    }
+    const double t0 = block_sum(s_rgb, s_buf), t1 = block_sum(s_dep, s_buf), t2 = block_sum(s_sem, s_buf), t3 = block_sum(s_occ, s_buf);
+    if (threadIdx.x == 0) {
+        terms[4 * v + 0] = t0 / (3.0 * P);
+        terms[4 * v + 1] = t1 / P;
+        terms[4 * v + 2] = t2 / P;
+        terms[4 * v + 3] = t3 / P;
+    }
+}
+
+}  // namespace mnf
+
+using namespace mnf;
+
+extern "C" int64_t mnf_render_workspace_bytes(int64_t n_rays, int32_t rays_per_view) {
+    if (n_rays <= 0 || rays_per_view <= 0 || n_rays % rays_per_view) return -1;
+    return carve(nullptr, nullptr, n_rays, rays_per_view);
+}
+
+extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32_t res_y, int32_t res_z,
+                               const float *aabb_host, const float *rays_o, const float *rays_d, int64_t n_rays,
+                               const mnf_render_opts *opts,
+                               float *rgb, float *acc, float *depth, float *sem, float *rgb_var, float *depth_var,
+                               int64_t *total_samples, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
+    MNF_REQUIRE(f && opts && aabb_host, "render_test: null argument");
+    MNF_REQUIRE(f->params_loaded, "render_test: field parameters not loaded");
+    MNF_REQUIRE(n_rays >= 0, "render_test: negative n_rays");
+    if (n_rays == 0) return MNF_OK;
+    MNF_REQUIRE(opts->rays_per_view > 0 && n_rays % opts->rays_per_view == 0,
+                "render_test: n_rays (%lld) must be a multiple of rays_per_view (%d)", (long long)n_rays, opts->rays_per_view);
+    MNF_REQUIRE(n_rays <= (int64_t)500 * 1000 * 1000, "render_test: too many rays for 32-bit column indices");
+    MNF_REQUIRE(binaries && rays_o && rays_d && rgb && acc && depth && sem && total_samples, "render_test: null buffer");
+    MNF_REQUIRE(!opts->probabilistic || (rgb_var && depth_var), "render_test: probabilistic needs rgb_var and depth_var");
+    MNF_REQUIRE(opts->max_samples > 0 && opts->render_step_size > 0.f, "render_test: max_samples and render_step_size must be > 0");
+    const int64_t need = carve(nullptr, nullptr, n_rays, opts->rays_per_view);
+    if (!workspace || workspace_bytes < need) {
+        set_error("render_test: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)need);
+        return MNF_ERR_WORKSPACE;
+    }
+    RenderWs ws;
+    carve(&ws, (char *)workspace, n_rays, opts->rays_per_view);
+    RenderOut out = {rgb, acc, depth, sem, opts->probabilistic ? rgb_var : nullptr, opts->probabilistic ? depth_var : nullptr, total_samples};
+    hipStream_t s = as_stream(stream);
+    const int32_t n_views = (int32_t)(n_rays / opts->rays_per_view);
+    const int32_t C = f->cfg.num_semantic_classes;
+    const int ray_blocks = (int)ceil_div(n_rays > n_views ? n_rays : n_views, kRayThreads);
+    const float *ab = aabb_host;
+    const I3 res = {res_x, res_y, res_z};
+    const int32_t min_samples = opts->cone_angle == 0.f ? 1 : 4;                      // utils.py:645
+    const float opc_thre = 1.0f - opts->early_stop_eps;                                // utils.py:664
+
+    hipLaunchKernelGGL(init_kernel, dim3(ray_blocks), dim3(kRayThreads), 0, s, n_rays, opts->rays_per_view, C, rays_o, rays_d,
+                       ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], opts->near_plane, ws, out);
+    int rc = launch_status("init_kernel");
+    if (rc) return rc;
+
+    FieldIO io = {};
+    io.mode = 2; io.rays_o = rays_o; io.rays_d = rays_d; io.col_ray = ws.col_ray; io.t_starts = ws.col_ts; io.t_ends = ws.col_te;
+    io.n_dev = ws.n_cols; io.col_srgb = ws.col_srgb; io.col_sem = ws.col_sem;
+
+    const int max_rounds = (int)ceil_div(opts->max_samples, min_samples);
+    for (int round = 0; round < max_rounds; ++round) {
+        hipLaunchKernelGGL(round_prep_kernel, dim3(1), dim3(256), 0, s, n_views, opts->rays_per_view, opts->max_samples, min_samples, ws);
+        if (opts->sync_every > 0 && round > 0 && round % opts->sync_every == 0) {
+            // the prep just enqueued decided whether any view still has a round to run
+            int32_t any = 1;
+            MNF_HIP(hipMemcpyAsync(&any, ws.any_active, sizeof(any), hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipStreamSynchronize(s));
+            if (!any) break;
+        }
+        hipLaunchKernelGGL(round_march_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,
+                           opts->rays_per_view, rays_o, rays_d, binaries, res, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
+                           opts->far_plane, opts->render_step_size, opts->cone_angle, ws);
+        rc = launch_field(f, io, false, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(composite_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,
+                           opts->rays_per_view, C, opts->alpha_thre, opc_thre, opts->probabilistic, ws, out);
+        rc = launch_status("render round");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,
+                       opts->render_bkgd[0], opts->render_bkgd[1], opts->render_bkgd[2], out);
+    return launch_status("finalize_kernel");
+}
+
+extern "C" int mnf_score_views(const float *rgb_var, const float *depth_var, const float *acc, const float *sem,
+                               int32_t n_members, int32_t n_views, int32_t n_pix, int32_t n_classes, double *terms, mnf_stream_t stream) {
+    MNF_REQUIRE(n_members >= 1 && n_views >= 0 && n_pix > 0 && n_classes >= 1 && n_classes <= 32, "score_views: bad sizes");
+    if (n_views == 0) return MNF_OK;
+    MNF_REQUIRE(rgb_var && depth_var && acc && sem && terms, "score_views: null pointer");
+    hipLaunchKernelGGL(score_kernel, dim3(n_views), dim3(256), 0, as_stream(stream), rgb_var, depth_var, acc, sem, n_members, n_views,
+                       n_pix, n_classes, terms);
+    return launch_status("score_kernel");
+}

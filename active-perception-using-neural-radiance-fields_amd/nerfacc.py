@@ -1,0 +1,407 @@
+"""Drop-in for the subset of the reference's nerfacc fork that scripts/pipeline.py reaches
+(SURVEY.md §2.2), backed by libmi355nerf.so.  Names, argument order and error behaviour follow
+the reference; file:line citations are relative to /root/reference.
+
+  ray_aabb_intersect              perception/nerfacc/nerfacc/grid.py:13-51
+  traverse_grids                  grid.py:93-192 (+ host protocol cuda/csrc/grid.cu:320-474)
+  RayIntervals / RaySamples       data_specs.py:12-180
+  pack_info                       pack.py:10-49
+  exclusive_sum                   scan.py:57-97
+  render_*_from_density           volrend.py:212-267, :315-365, :424-483
+  accumulate_along_rays[_]        volrend.py:486-576
+  OccGridEstimator                estimators/occ_grid.py:13-437
+"""
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+# ------------------------------------------------------------------ data specs
+@dataclass
+class RaySamples:
+    vals: Tensor
+    packed_info: Optional[Tensor] = None
+    ray_indices: Optional[Tensor] = None
+    is_valid: Optional[Tensor] = None
+
+    @property
+    def device(self):
+        return self.vals.device
+
+
+@dataclass
+class RayIntervals:
+    vals: Tensor
+    packed_info: Optional[Tensor] = None
+    ray_indices: Optional[Tensor] = None
+    is_left: Optional[Tensor] = None
+    is_right: Optional[Tensor] = None
+
+    @property
+    def device(self):
+        return self.vals.device
+
+
+# ------------------------------------------------------------------ grid.py
+@torch.no_grad()
+def ray_aabb_intersect(rays_o: Tensor, rays_d: Tensor, aabbs: Tensor, near_plane: float = -float("inf"),
+                       far_plane: float = float("inf"), miss_value: float = float("inf")):
+    assert rays_o.ndim == 2 and rays_o.shape[-1] == 3
+    assert rays_d.ndim == 2 and rays_d.shape[-1] == 3
+    assert aabbs.ndim == 2 and aabbs.shape[-1] == 6
+    L.require_gpu(rays_o, rays_d, aabbs)
+    rays_o, rays_d, aabbs = L.contig(rays_o, torch.float32), L.contig(rays_d, torch.float32), L.contig(aabbs, torch.float32)
+    n, m = rays_o.shape[0], aabbs.shape[0]
+    t_mins = torch.empty((n, m), device=rays_o.device, dtype=torch.float32)
+    t_maxs = torch.empty_like(t_mins)
+    hits = torch.empty((n, m), device=rays_o.device, dtype=torch.bool)
+    L.check(L.load_library().mnf_ray_aabb_intersect(L.ptr(rays_o), L.ptr(rays_d), n, L.ptr(aabbs), m, near_plane, far_plane,
+                                                    miss_value, L.ptr(t_mins), L.ptr(t_maxs), L.ptr(hits), L.stream()))
+    return t_mins, t_maxs, hits
+
+
+def _alloc_segments(cnts: Tensor, masks: bool, valid: bool):
+    """RaySegmentsSpec::memalloc_data_from_chunk (include/data_spec.hpp:86-96): cumsum + one host sync."""
+    cumsum = torch.cumsum(cnts, 0, dtype=torch.int64)
+    n_edges = int(cumsum[-1].item()) if cnts.numel() else 0
+    starts = cumsum - cnts
+    dev = cnts.device
+    vals = torch.zeros(n_edges, device=dev, dtype=torch.float32)
+    ridx = torch.zeros(n_edges, device=dev, dtype=torch.int64)
+    left = torch.zeros(n_edges, device=dev, dtype=torch.bool) if masks else None
+    right = torch.zeros(n_edges, device=dev, dtype=torch.bool) if masks else None
+    isvalid = torch.zeros(n_edges, device=dev, dtype=torch.bool) if valid else None
+    return starts, vals, ridx, left, right, isvalid
+
+
+@torch.no_grad()
+def traverse_grids(rays_o: Tensor, rays_d: Tensor, binaries: Tensor, aabbs: Tensor,
+                   near_planes: Optional[Tensor] = None, far_planes: Optional[Tensor] = None,
+                   step_size: Optional[float] = 1e-3, cone_angle: Optional[float] = 0.0,
+                   traverse_steps_limit: Optional[int] = None, over_allocate: Optional[bool] = False,
+                   rays_mask: Optional[Tensor] = None, t_sorted: Optional[Tensor] = None,
+                   t_indices: Optional[Tensor] = None, hits: Optional[Tensor] = None
+                   ) -> Tuple[RayIntervals, RaySamples, Tensor]:
+    L.require_gpu(rays_o, rays_d, binaries, aabbs)
+    dev = rays_o.device
+    if near_planes is None:
+        near_planes = torch.zeros_like(rays_o[:, 0])
+    if far_planes is None:
+        far_planes = torch.full_like(rays_o[:, 0], float("inf"))
+    if rays_mask is None:
+        rays_mask = torch.ones_like(rays_o[:, 0], dtype=torch.bool)
+    if traverse_steps_limit is None:
+        traverse_steps_limit = -1
+    if over_allocate:
+        assert traverse_steps_limit > 0, "traverse_steps_limit must be set if over_allocate is True."
+    if t_sorted is None or t_indices is None or hits is None:
+        t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
+        t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], dim=-1), dim=-1)
+    rays_o, rays_d = L.contig(rays_o, torch.float32), L.contig(rays_d, torch.float32)
+    binaries_u8 = L.contig(binaries).view(torch.uint8) if binaries.dtype == torch.bool else L.contig(binaries, torch.uint8)
+    aabbs = L.contig(aabbs, torch.float32)
+    t_sorted, t_indices = L.contig(t_sorted, torch.float32), L.contig(t_indices, torch.int64)
+    hits_c, mask_c = L.contig(hits), L.contig(rays_mask)
+    near_planes, far_planes = L.contig(near_planes, torch.float32), L.contig(far_planes, torch.float32)
+    n = rays_o.shape[0]
+    n_grids, rx, ry, rz = binaries.shape
+    term = torch.empty(n, device=dev, dtype=torch.float32)
+    lib = L.load_library()
+
+    def call(first_pass, iv, sm, mask, term_t):
+        iv_vals, iv_r, iv_l, iv_rt, iv_st, iv_cnt = iv
+        sm_vals, sm_r, sm_valid, sm_st, sm_cnt = sm
+        L.check(lib.mnf_traverse_grids(
+            L.ptr(rays_o), L.ptr(rays_d), L.ptr(mask), n, L.ptr(binaries_u8), L.ptr(aabbs), n_grids, rx, ry, rz,
+            L.ptr(hits_c), L.ptr(t_sorted), L.ptr(t_indices), L.ptr(near_planes), L.ptr(far_planes),
+            float(step_size), float(cone_angle), int(traverse_steps_limit), 1 if first_pass else 0,
+            L.ptr(iv_vals), L.ptr(iv_r), L.ptr(iv_l), L.ptr(iv_rt), L.ptr(iv_st), L.ptr(iv_cnt),
+            L.ptr(sm_vals), L.ptr(sm_r), L.ptr(sm_valid), L.ptr(sm_st), L.ptr(sm_cnt), L.ptr(term_t), L.stream()))
+
+    if over_allocate:
+        # grid.cu:364-404
+        iv_cnt = torch.full((n,), traverse_steps_limit * 2, device=dev, dtype=torch.int64) * rays_mask
+        sm_cnt = torch.full((n,), traverse_steps_limit, device=dev, dtype=torch.int64) * rays_mask
+        iv_st, iv_vals, iv_r, iv_l, iv_rt, _ = _alloc_segments(iv_cnt, True, False)
+        sm_st, sm_vals, sm_r, _, _, sm_valid = _alloc_segments(sm_cnt, False, True)
+        call(False, (iv_vals, iv_r, iv_l, iv_rt, iv_st, iv_cnt), (sm_vals, sm_r, sm_valid, sm_st, sm_cnt), mask_c, term)
+        iv_st = torch.cumsum(iv_cnt, 0) - iv_cnt
+        sm_st = torch.cumsum(sm_cnt, 0) - sm_cnt
+    else:
+        # grid.cu:405-470: count pass, allocate, fill pass
+        iv_cnt = torch.empty(n, device=dev, dtype=torch.int64)
+        sm_cnt = torch.empty(n, device=dev, dtype=torch.int64)
+        call(True, (None, None, None, None, None, iv_cnt), (None, None, None, None, sm_cnt), None, None)
+        iv_st, iv_vals, iv_r, iv_l, iv_rt, _ = _alloc_segments(iv_cnt, True, False)
+        sm_st, sm_vals, sm_r, _, _, sm_valid = _alloc_segments(sm_cnt, False, False)
+        call(False, (iv_vals, iv_r, iv_l, iv_rt, iv_st, iv_cnt), (sm_vals, sm_r, None, sm_st, sm_cnt), None, term)
+    intervals = RayIntervals(iv_vals, torch.stack([iv_st, iv_cnt], -1), iv_r, iv_l, iv_rt)
+    samples = RaySamples(sm_vals, torch.stack([sm_st, sm_cnt], -1), sm_r, sm_valid)
+    return intervals, samples, term
+
+
+def _enlarge_aabb(aabb, factor: float) -> Tensor:
+    center = (aabb[:3] + aabb[3:]) / 2
+    extent = (aabb[3:] - aabb[:3]) / 2
+    return torch.cat([center - extent * factor, center + extent * factor])
+
+
+# ------------------------------------------------------------------ pack.py / scan.py / volrend.py
+@torch.no_grad()
+def pack_info(ray_indices: Tensor, n_rays: Optional[int] = None) -> Tensor:
+    assert ray_indices.dim() == 1, "ray_indices must be a 1D tensor with shape (n_samples)."
+    if not ray_indices.is_cuda:
+        raise NotImplementedError("Only support cuda inputs.")
+    if n_rays is None:
+        n_rays = ray_indices.max().item() + 1
+    cnts = torch.zeros((n_rays,), device=ray_indices.device, dtype=ray_indices.dtype)
+    cnts.index_add_(0, ray_indices, torch.ones_like(ray_indices))
+    starts = cnts.cumsum(dim=0, dtype=ray_indices.dtype) - cnts
+    return torch.stack([starts, cnts], dim=-1)
+
+
+class _ExclusiveSum(torch.autograd.Function):
+    """scan.py:206-229: forward packed exclusive sum; backward = reverse-direction scan of the grad."""
+
+    @staticmethod
+    def forward(ctx, chunk_starts, chunk_cnts, inputs):
+        chunk_starts, chunk_cnts = chunk_starts.contiguous(), chunk_cnts.contiguous()
+        inputs = inputs.contiguous()
+        out = torch.empty_like(inputs)
+        L.check(L.load_library().mnf_exclusive_sum(L.ptr(chunk_starts), L.ptr(chunk_cnts), chunk_cnts.shape[0], L.ptr(inputs),
+                                                   L.ptr(out), inputs.shape[0], 0, L.stream()))
+        ctx.save_for_backward(chunk_starts, chunk_cnts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        chunk_starts, chunk_cnts = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        L.check(L.load_library().mnf_exclusive_sum(L.ptr(chunk_starts), L.ptr(chunk_cnts), chunk_cnts.shape[0], L.ptr(g),
+                                                   L.ptr(out), g.shape[0], 1, L.stream()))
+        return None, None, out
+
+
+def exclusive_sum(inputs: Tensor, packed_info: Optional[Tensor] = None) -> Tensor:
+    if packed_info is None:
+        return torch.cumsum(torch.cat([torch.zeros_like(inputs[..., :1]), inputs[..., :-1]], dim=-1), dim=-1)
+    assert inputs.dim() == 1, "inputs must be flattened."
+    assert packed_info.dim() == 2 and packed_info.shape[-1] == 2, "packed_info must be 2-D with shape (B, 2)."
+    L.require_gpu(inputs, packed_info)
+    chunk_starts, chunk_cnts = packed_info.to(torch.int64).unbind(dim=-1)
+    return _ExclusiveSum.apply(chunk_starts, chunk_cnts, inputs)
+
+
+def render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None,
+                                      prefix_trans=None):
+    if ray_indices is not None and packed_info is None:
+        packed_info = pack_info(ray_indices, n_rays)
+    sigmas_dt = sigmas * (t_ends - t_starts)
+    alphas = 1.0 - torch.exp(-sigmas_dt)
+    trans = torch.exp(-exclusive_sum(sigmas_dt, packed_info))
+    if prefix_trans is not None:
+        trans = trans * prefix_trans
+    return trans, alphas
+
+
+def render_weight_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None,
+                               prefix_trans=None):
+    trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info, ray_indices, n_rays, prefix_trans)
+    return trans * alphas, trans, alphas
+
+
+@torch.no_grad()
+def render_visibility_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None,
+                                   early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, prefix_trans=None):
+    """volrend.py:424-483; the packed path is one fused kernel (sigma*dt -> alpha, T, threshold)."""
+    if ray_indices is not None and packed_info is None:
+        packed_info = pack_info(ray_indices, n_rays)
+    if packed_info is None:
+        trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, prefix_trans=prefix_trans)
+    else:
+        L.require_gpu(t_starts, t_ends, sigmas, packed_info)
+        starts, cnts = (x.contiguous() for x in packed_info.to(torch.int64).unbind(-1))
+        ts, te, sg = L.contig(t_starts, torch.float32), L.contig(t_ends, torch.float32), L.contig(sigmas, torch.float32)
+        pf = L.contig(prefix_trans, torch.float32)
+        trans, alphas = torch.empty_like(sg), torch.empty_like(sg)
+        L.check(L.load_library().mnf_render_weight_from_density(L.ptr(starts), L.ptr(cnts), cnts.shape[0], L.ptr(ts), L.ptr(te),
+                                                                L.ptr(sg), L.ptr(pf), sg.shape[0], None, L.ptr(trans),
+                                                                L.ptr(alphas), L.stream()))
+    vis = trans >= early_stop_eps
+    if alpha_thre > 0:
+        vis = vis & (alphas >= alpha_thre)
+    return vis
+
+
+def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                          n_rays: Optional[int] = None) -> Tensor:
+    if values is None:
+        src = weights[..., None]
+    else:
+        assert values.dim() == weights.dim() + 1
+        assert weights.shape == values.shape[:-1]
+        src = weights[..., None] * values
+    if ray_indices is not None:
+        assert n_rays is not None, "n_rays must be provided"
+        assert weights.dim() == 1, "weights must be flattened"
+        outputs = torch.zeros((n_rays, src.shape[-1]), device=src.device, dtype=src.dtype)
+        outputs.index_add_(0, ray_indices, src)
+    else:
+        outputs = torch.sum(src, dim=-2)
+    return outputs
+
+
+def accumulate_along_rays_(weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                           outputs: Optional[Tensor] = None) -> None:
+    if values is None:
+        src = weights[..., None]
+    else:
+        assert values.dim() == weights.dim() + 1
+        assert weights.shape == values.shape[:-1]
+        src = weights[..., None] * values
+    if ray_indices is not None:
+        assert weights.dim() == 1, "weights must be flattened"
+        assert outputs.dim() == 2 and outputs.shape[-1] == src.shape[-1], "outputs must be of shape (n_rays, D)"
+        outputs.index_add_(0, ray_indices, src)
+    else:
+        outputs.add_(src.sum(dim=-2))
+
+
+# ------------------------------------------------------------------ estimators/occ_grid.py
+def _meshgrid3d(res: Tensor, device: Union[torch.device, str] = "cpu") -> Tensor:
+    res = res.tolist()
+    return torch.stack(torch.meshgrid([torch.arange(res[0], dtype=torch.long), torch.arange(res[1], dtype=torch.long),
+                                       torch.arange(res[2], dtype=torch.long)], indexing="ij"), dim=-1).to(device)
+
+
+class OccGridEstimator(torch.nn.Module):
+    """Occupancy-grid estimator, same buffers and methods as estimators/occ_grid.py:13-437."""
+
+    DIM: int = 3
+
+    def __init__(self, roi_aabb: Union[List[int], Tensor], resolution: Union[int, List[int], Tensor] = 128,
+                 levels: int = 1, **kwargs) -> None:
+        super().__init__()
+        if "contraction_type" in kwargs:
+            raise ValueError("`contraction_type` is not supported anymore for nerfacc >= 0.4.0.")
+        if isinstance(resolution, int):
+            resolution = [resolution] * self.DIM
+        if isinstance(resolution, (list, tuple)):
+            resolution = torch.tensor(resolution, dtype=torch.int32)
+        assert isinstance(resolution, Tensor), f"Invalid type: {resolution}!"
+        assert resolution.shape[0] == self.DIM, f"Invalid shape: {resolution}!"
+        if isinstance(roi_aabb, (list, tuple)):
+            roi_aabb = torch.tensor(roi_aabb, dtype=torch.float32)
+        assert isinstance(roi_aabb, Tensor), f"Invalid type: {roi_aabb}!"
+        assert roi_aabb.shape[0] == self.DIM * 2, f"Invalid shape: {roi_aabb}!"
+        roi_aabb = roi_aabb.detach().cpu().float()
+        aabbs = torch.stack([_enlarge_aabb(roi_aabb, 2 ** i) for i in range(levels)], dim=0)
+        self.cells_per_lvl = int(resolution.prod().item())
+        self.levels = levels
+        self.register_buffer("resolution", resolution)
+        self.register_buffer("aabbs", aabbs)
+        self.register_buffer("occs", torch.zeros(self.levels * self.cells_per_lvl))
+        self.register_buffer("binaries", torch.zeros([levels] + resolution.tolist(), dtype=torch.bool))
+        grid_coords = _meshgrid3d(resolution).reshape(self.cells_per_lvl, self.DIM)
+        self.register_buffer("grid_coords", grid_coords, persistent=False)
+        self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
+
+    @property
+    def device(self):
+        return self.occs.device
+
+    @torch.no_grad()
+    def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
+                 alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
+                 t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
+                 early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
+                 cone_angle: float = 0.0, depth: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+        """occ_grid.py:80-238 (`depth` is accepted and ignored, as in the reference fork)."""
+        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
+        if t_min is not None:
+            near_planes = torch.clamp(near_planes, min=t_min)
+        if t_max is not None:
+            far_planes = torch.clamp(far_planes, max=t_max)
+        if stratified:
+            near_planes += torch.rand_like(near_planes) * render_step_size
+        intervals, samples, _ = traverse_grids(rays_o, rays_d, self.binaries, self.aabbs, near_planes=near_planes,
+                                               far_planes=far_planes, step_size=render_step_size, cone_angle=cone_angle)
+        t_starts = intervals.vals[intervals.is_left]
+        t_ends = intervals.vals[intervals.is_right]
+        ray_indices = samples.ray_indices
+        packed_info = samples.packed_info
+        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
+            alpha_thre = min(alpha_thre, self.occs.mean().item())
+            if sigma_fn is not None:
+                sigmas = sigma_fn(t_starts, t_ends, ray_indices) if t_starts.shape[0] != 0 else torch.empty((0,), device=t_starts.device)
+                assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+                masks = render_visibility_from_density(t_starts=t_starts, t_ends=t_ends, sigmas=sigmas, packed_info=packed_info,
+                                                       early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+            else:
+                alphas = alpha_fn(t_starts, t_ends, ray_indices) if t_starts.shape[0] != 0 else torch.empty((0,), device=t_starts.device)
+                assert alphas.shape == t_starts.shape, "alphas must have shape of (N,)! Got {}".format(alphas.shape)
+                trans = torch.exp(exclusive_sum(torch.log1p(-alphas), packed_info))
+                masks = trans >= early_stop_eps
+                if alpha_thre > 0:
+                    masks = masks & (alphas >= alpha_thre)
+            ray_indices, t_starts, t_ends = ray_indices[masks], t_starts[masks], t_ends[masks]
+        return ray_indices, t_starts, t_ends
+
+    @torch.no_grad()
+    def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
+                             warmup_steps: int = 256, n: int = 16) -> None:
+        if not self.training:
+            raise RuntimeError("You should only call this function only during training. "
+                               "Please call _update() directly if you want to update the field during inference.")
+        if step % n == 0 and self.training:
+            self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay, warmup_steps=warmup_steps)
+
+    @torch.no_grad()
+    def _get_all_cells(self) -> List[Tensor]:
+        out = []
+        for lvl in range(self.levels):
+            cell_ids = lvl * self.cells_per_lvl + self.grid_indices
+            out.append(self.grid_indices[self.occs[cell_ids] >= 0.0])
+        return out
+
+    @torch.no_grad()
+    def _sample_uniform_and_occupied_cells(self, n: int) -> List[Tensor]:
+        out = []
+        for lvl in range(self.levels):
+            uniform_indices = torch.randint(self.cells_per_lvl, (n,), device=self.device)
+            cell_ids = lvl * self.cells_per_lvl + uniform_indices
+            uniform_indices = uniform_indices[self.occs[cell_ids] >= 0.0]
+            occupied_indices = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
+            if n < len(occupied_indices):
+                selector = torch.randint(len(occupied_indices), (n,), device=self.device)
+                occupied_indices = occupied_indices[selector]
+            out.append(torch.cat([uniform_indices, occupied_indices], dim=0))
+        return out
+
+    @torch.no_grad()
+    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
+                warmup_steps: int = 256) -> None:
+        """occ_grid.py:377-437 (EMA-max update with the fork's NaN roll-back)."""
+        if step < warmup_steps:
+            lvl_indices = self._get_all_cells()
+        else:
+            lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
+        for lvl, indices in enumerate(lvl_indices):
+            grid_coords = self.grid_coords[indices]
+            x = (grid_coords + torch.rand_like(grid_coords, dtype=torch.float32)) / self.resolution
+            x = self.aabbs[lvl, :3] + x * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])
+            occs_backup = torch.clone(self.occs)
+            occ = occ_eval_fn(x).squeeze(-1)
+            cell_ids = lvl * self.cells_per_lvl + indices
+            self.occs[cell_ids] = torch.maximum(self.occs[cell_ids] * ema_decay, occ)
+            nan = torch.isnan(self.occs)
+            if nan.any():
+                self.occs[nan] = occs_backup[nan]
+        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+        self.binaries = (self.occs > thre).view(self.binaries.shape)

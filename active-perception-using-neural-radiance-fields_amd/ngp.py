@@ -1,0 +1,195 @@
+"""`NGPRadianceField` with the reference's constructor and call surface
+(perception/models/radiance_fields/ngp.py:69-238), evaluated by the fused HIP kernel of
+csrc/field.hip instead of tiny-cuda-nn.
+
+Parameters live in three flat fp32 tensors named like the reference's state_dict
+(`mlp_base.params` = base-MLP weights followed by the hash table, `mlp_head.params`,
+`mlp_sem.params`), so optimizers and checkpoints see the same objects.  The layout inside each
+vector restates tiny-cuda-nn's (un-pinned, see oracle/field.py); the C library converts them to
+fp16 hash entries and MFMA-fragment-ordered fp16 weights whenever they change.
+"""
+import ctypes
+import math
+from typing import List, Union
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class _Params(torch.nn.Module):
+    """Stands in for a tcnn module: one flat `params` Parameter."""
+
+    def __init__(self, n: int):
+        super().__init__()
+        self.params = torch.nn.Parameter(torch.zeros(n, dtype=torch.float32))
+
+
+def _xavier_uniform_(flat: torch.Tensor, shapes, gen: torch.Generator):
+    k = 0
+    for o, i in shapes:
+        lim = math.sqrt(6.0 / (o + i))
+        flat[k:k + o * i] = (torch.rand(o * i, generator=gen) * 2 - 1) * lim
+        k += o * i
+    return k
+
+
+class NGPRadianceField(torch.nn.Module):
+    """Instant-NGP radiance field with a semantic head (ngp.py:69-169)."""
+
+    def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
+                 neurons: int = 128, layers: int = 4, density_activation=None, unbounded: bool = False,
+                 base_resolution: int = 16, max_resolution: int = 4096, geo_feat_dim: int = 15, n_levels: int = 16,
+                 log2_hashmap_size: int = 19, num_semantic_classes: int = 0, seed: int = 0) -> None:
+        super().__init__()
+        if not isinstance(aabb, torch.Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        if num_dim != 3 or not use_viewdirs or unbounded or geo_feat_dim != 15 or density_activation is not None:
+            raise NotImplementedError("mi355nerf supports the configuration scripts/pipeline.py uses: num_dim=3, "
+                                      "use_viewdirs=True, unbounded=False, geo_feat_dim=15, trunc_exp(x-1) density")
+        if num_semantic_classes <= 0:
+            raise NotImplementedError("mi355nerf requires num_semantic_classes > 0 (pipeline.py always passes --sem-num)")
+        self.register_buffer("aabb", aabb.detach().clone().float())
+        self.num_dim, self.use_viewdirs, self.unbounded = num_dim, use_viewdirs, unbounded
+        self.base_resolution, self.max_resolution = base_resolution, max_resolution
+        self.geo_feat_dim, self.n_levels, self.log2_hashmap_size = geo_feat_dim, n_levels, log2_hashmap_size
+        self.num_semantic_classes = num_semantic_classes
+        self.neurons, self.layers = neurons, layers
+
+        lib = L.load_library()
+        cfg = L.FieldConfig()
+        for i, v in enumerate(aabb.detach().cpu().float().tolist()):
+            cfg.aabb[i] = v
+        cfg.neurons, cfg.layers, cfg.num_semantic_classes = neurons, layers, num_semantic_classes
+        cfg.n_levels, cfg.n_features, cfg.log2_hashmap_size = n_levels, 4, log2_hashmap_size
+        cfg.base_resolution, cfg.max_resolution = base_resolution, max_resolution
+        self._cfg = cfg
+        self._handle = ctypes.c_void_p()
+        self._handle_device = None
+        self._loaded_versions = None
+
+        # parameter counts do not need a device; compute them like the C side does
+        W, Wh = neurons, neurons // 2
+        sem_pad = ((num_semantic_classes + 15) // 16) * 16
+        self._shapes = {
+            "base": [(W, 64)] + [(W, W)] * (layers - 1) + [(16, W)],
+            "head": [(Wh, 32), (Wh, Wh), (16, Wh)],
+            "sem": [(Wh, 16), (Wh, Wh), (sem_pad, Wh)],
+        }
+        table = self._table_entries()
+        n_base_mlp = sum(o * i for o, i in self._shapes["base"])
+        self.direction_encoding = _Params(0)
+        self.mlp_base = _Params(n_base_mlp + table * 4)
+        self.mlp_head = _Params(sum(o * i for o, i in self._shapes["head"]))
+        self.mlp_sem = _Params(sum(o * i for o, i in self._shapes["sem"]))
+        # tcnn initialisation: xavier-uniform MLPs, U(-1e-4, 1e-4) grid
+        gen = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            k = _xavier_uniform_(self.mlp_base.params, self._shapes["base"], gen)
+            self.mlp_base.params[k:] = (torch.rand(table * 4, generator=gen) * 2 - 1) * 1e-4
+            _xavier_uniform_(self.mlp_head.params, self._shapes["head"], gen)
+            _xavier_uniform_(self.mlp_sem.params, self._shapes["sem"], gen)
+
+    def _table_entries(self) -> int:
+        pls = math.exp((math.log(self.max_resolution) - math.log(self.base_resolution)) / (self.n_levels - 1))
+        total = 0
+        for l in range(self.n_levels):
+            scale = np.float32(2.0 ** (l * math.log2(pls)) * self.base_resolution - 1.0)
+            res = int(math.ceil(float(scale))) + 1
+            total += min(((res ** 3 + 7) // 8) * 8, 1 << self.log2_hashmap_size)
+        return total
+
+    # ---- handle management ------------------------------------------------------------
+    def _ensure_handle(self):
+        dev = self.mlp_base.params.device
+        if dev.type != "cuda":
+            raise L.MnfError("NGPRadianceField must be on a GPU (`.to('cuda')`): libmi355nerf has no CPU fallback")
+        lib = L.load_library()
+        if self._handle_device != dev:
+            if self._handle:
+                lib.mnf_field_destroy(self._handle)
+                self._handle = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                L.check(lib.mnf_field_create(ctypes.byref(self._cfg), ctypes.byref(self._handle)))
+            assert lib.mnf_field_param_count(self._handle, 0) == self.mlp_base.params.numel()
+            assert lib.mnf_field_param_count(self._handle, 1) == self.mlp_head.params.numel()
+            assert lib.mnf_field_param_count(self._handle, 2) == self.mlp_sem.params.numel()
+            self._handle_device = dev
+            self._loaded_versions = None
+        versions = (self.mlp_base.params._version, self.mlp_head.params._version, self.mlp_sem.params._version,
+                    self.mlp_base.params.data_ptr())
+        if versions != self._loaded_versions:
+            L.check(lib.mnf_field_set_params(self._handle, L.ptr(self.mlp_base.params), L.ptr(self.mlp_head.params),
+                                             L.ptr(self.mlp_sem.params), L.stream()))
+            self._loaded_versions = versions
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle:
+                L.load_library().mnf_field_destroy(self._handle)
+        except Exception:
+            pass
+
+    def grid_meta(self):
+        """(scale f32, res, size, offset, hashed) per level, as computed by the C library."""
+        h = self._ensure_handle()
+        n = self.n_levels
+        scale = (ctypes.c_float * n)(); res = (ctypes.c_int32 * n)(); size = (ctypes.c_int32 * n)()
+        off = (ctypes.c_int64 * n)(); hashed = (ctypes.c_int32 * n)()
+        L.check(L.load_library().mnf_field_grid_meta_host(h, scale, res, size, off, hashed))
+        return list(scale), list(res), list(size), list(off), list(hashed)
+
+    # ---- reference call surface -------------------------------------------------------
+    @torch.no_grad()
+    def query_density(self, x, return_feat: bool = False):
+        """ngp.py:171-200."""
+        if return_feat:
+            raise NotImplementedError("return_feat=True is internal to the reference's forward(); use forward()")
+        h = self._ensure_handle()
+        L.require_gpu(x)
+        shp = x.shape[:-1]
+        pos = L.contig(x.reshape(-1, 3), torch.float32)
+        out = torch.empty(pos.shape[0], 1, device=pos.device, dtype=torch.float32)
+        L.check(L.load_library().mnf_field_density(h, L.ptr(pos), pos.shape[0], L.ptr(out), L.stream()))
+        return out.view(*shp, 1)
+
+    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
+        """ngp.py:222-238 -> (rgb [N,3], density [N,1], sem_logits [N,C])."""
+        if directions is None:
+            raise NotImplementedError("forward() without directions is not reachable from pipeline.py")
+        assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "the differentiable forward (train_step) of the HIP field is not built yet (DESIGN.md §Scope); "
+                "call under torch.no_grad() for rendering / scoring")
+        h = self._ensure_handle()
+        L.require_gpu(positions, directions)
+        shp = positions.shape[:-1]
+        pos = L.contig(positions.reshape(-1, 3), torch.float32)
+        dirs = L.contig(directions.reshape(-1, 3), torch.float32)
+        n = pos.shape[0]
+        rgb = torch.empty(n, 3, device=pos.device, dtype=torch.float32)
+        sigma = torch.empty(n, 1, device=pos.device, dtype=torch.float32)
+        sem = torch.empty(n, self.num_semantic_classes, device=pos.device, dtype=torch.float32)
+        L.check(L.load_library().mnf_field_forward(h, L.ptr(pos), L.ptr(dirs), n, L.ptr(rgb), L.ptr(sigma), L.ptr(sem), L.stream()))
+        return rgb.view(*shp, 3), sigma.view(*shp, 1), sem.view(*shp, self.num_semantic_classes)
+
+    @torch.no_grad()
+    def forward_samples(self, rays_o, rays_d, ray_indices, t_starts, t_ends, density_only: bool = False):
+        """The closures `sigma_fn` / `rgb_sigma_sem_fn` of perception/models/utils.py:89-137 fused with the field:
+        positions are formed in-kernel from (ray, t_start, t_end)."""
+        h = self._ensure_handle()
+        L.require_gpu(rays_o, rays_d, ray_indices, t_starts, t_ends)
+        o, d = L.contig(rays_o, torch.float32), L.contig(rays_d, torch.float32)
+        ri, ts, te = L.contig(ray_indices, torch.int64), L.contig(t_starts, torch.float32), L.contig(t_ends, torch.float32)
+        n = ts.shape[0]
+        sigma = torch.empty(n, device=o.device, dtype=torch.float32)
+        rgb = sem = None
+        if not density_only:
+            rgb = torch.empty(n, 3, device=o.device, dtype=torch.float32)
+            sem = torch.empty(n, self.num_semantic_classes, device=o.device, dtype=torch.float32)
+        L.check(L.load_library().mnf_field_forward_samples(h, L.ptr(o), L.ptr(d), L.ptr(ri), L.ptr(ts), L.ptr(te), n,
+                                                           L.ptr(rgb), L.ptr(sigma), L.ptr(sem), L.stream()))
+        return (sigma,) if density_only else (rgb, sigma, sem)

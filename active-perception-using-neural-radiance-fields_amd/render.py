@@ -1,0 +1,302 @@
+"""Render orchestration with the reference's names and signatures
+(perception/models/utils.py, perception/data_proc/habitat_to_data.py, scripts/pipeline.py:666-798),
+running on libmi355nerf.so.
+
+  Rays                                            perception/models/datasets/utils.py:7
+  render_image_with_occgrid_test                  utils.py:555-779
+  render_probablistic_image_with_occgrid_test     utils.py:782-1032
+  render_image_with_occgrid_with_depth_guide      utils.py:63-219   (forward; see DESIGN.md §Scope for backward)
+  sem_rendering                                   utils.py:362-461
+  generate_image_rays / render_*_from_pose        habitat_to_data.py:274-549
+  probablistic_uncertainty -> score_views         pipeline.py:666-798
+"""
+import collections
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import nerfacc as NA
+
+Rays = collections.namedtuple("Rays", ("origins", "viewdirs"))
+
+_WORKSPACES = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    ws = _WORKSPACES.get(device)
+    if ws is None or ws.numel() < nbytes:
+        _WORKSPACES[device] = ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def _single_level(estimator):
+    if estimator.binaries.shape[0] != 1:
+        raise NotImplementedError("the fused renderer supports one occupancy level (the reference configs use "
+                                  "main_grid_nlvl: 1); use nerfacc.traverse_grids for multi-level grids")
+    b = estimator.binaries
+    return (b.contiguous().view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8).contiguous()), estimator.aabbs[0]
+
+
+def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane, render_step_size, render_bkgd,
+                 cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view=None, sync_every=8):
+    rays_shape = rays.origins.shape
+    o = L.contig(rays.origins.reshape(-1, 3), torch.float32)
+    d = L.contig(rays.viewdirs.reshape(-1, 3), torch.float32)
+    L.require_gpu(o, d)
+    n = o.shape[0]
+    C = radiance_field.num_semantic_classes
+    dev = o.device
+    handle = radiance_field._ensure_handle()
+    binaries, aabb = _single_level(estimator)
+    L.require_gpu(binaries)
+    rpv = n if rays_per_view is None else int(rays_per_view)
+    opts = L.RenderOpts()
+    opts.near_plane, opts.far_plane, opts.render_step_size = near_plane, far_plane, render_step_size
+    opts.cone_angle, opts.alpha_thre, opts.early_stop_eps = cone_angle, alpha_thre, early_stop_eps
+    bk = [0.0, 0.0, 0.0] if render_bkgd is None else [float(x) for x in render_bkgd.detach().cpu().reshape(-1)[:3]]
+    for i in range(3):
+        opts.render_bkgd[i] = bk[i]
+    opts.max_samples, opts.probabilistic, opts.rays_per_view, opts.sync_every = int(max_samples), int(probabilistic), rpv, sync_every
+    rgb = torch.empty(n, 3, device=dev); acc = torch.empty(n, 1, device=dev); depth = torch.empty(n, 1, device=dev)
+    sem = torch.empty(n, C, device=dev)
+    rgb_var = torch.empty(n, 3, device=dev) if probabilistic else None
+    depth_var = torch.empty(n, 1, device=dev) if probabilistic else None
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    lib = L.load_library()
+    if n:
+        nbytes = lib.mnf_render_workspace_bytes(n, rpv)
+        if nbytes < 0:
+            raise L.MnfError(f"n_rays ({n}) must be a positive multiple of rays_per_view ({rpv})")
+        ws = _workspace(dev, nbytes)
+        aabb_host = (ctypes.c_float * 6)(*[float(x) for x in aabb.detach().cpu().tolist()])
+        res = binaries.shape[1:]
+        L.check(lib.mnf_render_test(handle, L.ptr(binaries), res[0], res[1], res[2], aabb_host, L.ptr(o), L.ptr(d), n,
+                                    ctypes.byref(opts), L.ptr(rgb), L.ptr(acc), L.ptr(depth), L.ptr(sem), L.ptr(rgb_var),
+                                    L.ptr(depth_var), L.ptr(total), L.ptr(ws), nbytes, L.stream()))
+    shp = tuple(rays_shape[:-1])
+    out = dict(rgb=rgb.view(*shp, -1), acc=acc.view(*shp, -1), depth=depth.view(*shp, -1), sem=sem.view(*shp, -1), total=total)
+    if probabilistic:
+        out.update(rgb_var=rgb_var.view(*shp, -1), depth_var=depth_var.view(*shp, -1))
+    return out
+
+
+@torch.no_grad()
+def render_image_with_occgrid_test(max_samples: int, radiance_field, estimator, rays: Rays, near_plane: float = 0.0,
+                                   far_plane: float = 1e10, render_step_size: float = 1e-3,
+                                   render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0,
+                                   alpha_thre: float = 0.0, early_stop_eps: float = 1e-4, timestamps=None):
+    """utils.py:555-779 -> (rgb, acc, depth, sem, total_samples)."""
+    if timestamps is not None:
+        raise NotImplementedError("timestamps (D-NeRF) are not part of the hot path")
+    r = _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane, render_step_size, render_bkgd,
+                     cone_angle, alpha_thre, early_stop_eps, False)
+    return r["rgb"], r["acc"], r["depth"], r["sem"], int(r["total"].item())
+
+
+@torch.no_grad()
+def render_probablistic_image_with_occgrid_test(max_samples: int, radiance_field, estimator, rays: Rays,
+                                                near_plane: float = 0.0, far_plane: float = 1e10,
+                                                render_step_size: float = 1e-3, render_bkgd: Optional[torch.Tensor] = None,
+                                                cone_angle: float = 0.0, alpha_thre: float = 0.0,
+                                                early_stop_eps: float = 1e-4, timestamps=None):
+    """utils.py:782-1032 -> (rgb, rgb_var, acc, depth, depth_var, sem, total_samples)."""
+    if timestamps is not None:
+        raise NotImplementedError("timestamps (D-NeRF) are not part of the hot path")
+    r = _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane, render_step_size, render_bkgd,
+                     cone_angle, alpha_thre, early_stop_eps, True)
+    return r["rgb"], r["rgb_var"], r["acc"], r["depth"], r["depth_var"], r["sem"], int(r["total"].item())
+
+
+@torch.no_grad()
+def render_views(radiance_field, estimator, rays_o, rays_d, rays_per_view, max_samples=1024, near_plane=0.0,
+                 far_plane=1e10, render_step_size=1e-3, render_bkgd=None, cone_angle=0.0, alpha_thre=0.0,
+                 early_stop_eps=1e-4, probabilistic=False, sync_every=8):
+    """Batched form: rays_o/rays_d [V*rays_per_view, 3]; every group of rays_per_view rays is rendered exactly as one
+    call of the reference function (own round schedule), all views in the same launches.  Returns a dict of device tensors."""
+    return _render_test(max_samples, radiance_field, estimator, Rays(rays_o, rays_d), near_plane, far_plane, render_step_size,
+                        render_bkgd, cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view, sync_every)
+
+
+# ------------------------------------------------------------------ train-mode forward (utils.py:63-219, :362-461)
+@torch.no_grad()
+def sem_rendering(radiance_field, rays: Rays, t_starts, t_ends, ray_indices, n_rays, render_bkgd=None):
+    """utils.py:362-461 on packed samples (forward values)."""
+    C = radiance_field.num_semantic_classes
+    dev = t_starts.device
+    if t_starts.shape[0] != 0:
+        rgbs, sigmas, sems = radiance_field.forward_samples(rays.origins, rays.viewdirs, ray_indices, t_starts, t_ends)
+    else:
+        rgbs, sigmas, sems = torch.empty((0, 3), device=dev), torch.empty((0,), device=dev), torch.empty((0, C), device=dev)
+    weights, trans, alphas = NA.render_weight_from_density(t_starts, t_ends, sigmas, ray_indices=ray_indices, n_rays=n_rays)
+    colors = NA.accumulate_along_rays(weights, rgbs, ray_indices, n_rays)
+    opacities = NA.accumulate_along_rays(weights, None, ray_indices, n_rays)
+    depths = NA.accumulate_along_rays(weights, (t_starts + t_ends)[..., None] / 2.0, ray_indices, n_rays)
+    depths = depths / opacities.clamp_min(torch.finfo(rgbs.dtype).eps)
+    semantics = NA.accumulate_along_rays(weights, sems, ray_indices, n_rays)
+    if render_bkgd is not None:
+        colors = colors + render_bkgd * (1.0 - opacities)
+    return colors, opacities, depths, semantics, dict(weights=weights, alphas=alphas, trans=trans, sigmas=sigmas, rgbs=rgbs)
+
+
+@torch.no_grad()
+def render_image_with_occgrid_with_depth_guide(radiance_field, estimator, rays: Rays, near_plane: float = 0.0,
+                                               far_plane: float = 1e10, render_step_size: float = 1e-3,
+                                               render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0,
+                                               alpha_thre: float = 0.0, test_chunk_size: int = 8192, timestamps=None,
+                                               depth: Optional[torch.Tensor] = None):
+    """utils.py:63-219: occupancy sampling with the density pre-pass, then semantic volume rendering.
+    Forward values only in this round (no autograd graph); `depth` is accepted and ignored as in the reference."""
+    if timestamps is not None:
+        raise NotImplementedError("timestamps (D-NeRF) are not part of the hot path")
+    rays_shape = rays.origins.shape
+    o, d = rays.origins.reshape(-1, 3), rays.viewdirs.reshape(-1, 3)
+    num_rays = o.shape[0]
+    chunk = torch.iinfo(torch.int32).max if radiance_field.training else test_chunk_size
+    results = []
+    for i in range(0, num_rays, chunk):
+        co, cd = o[i:i + chunk], d[i:i + chunk]
+
+        def sigma_fn(t_starts, t_ends, ray_indices):
+            return radiance_field.forward_samples(co, cd, ray_indices, t_starts, t_ends, density_only=True)[0]
+
+        ray_indices, t_starts, t_ends = estimator.sampling(co, cd, sigma_fn=sigma_fn, near_plane=near_plane, far_plane=far_plane,
+                                                           render_step_size=render_step_size, stratified=radiance_field.training,
+                                                           cone_angle=cone_angle, alpha_thre=alpha_thre, depth=depth)
+        rgb, opacity, dep, semantics, _ = sem_rendering(radiance_field, Rays(co, cd), t_starts, t_ends, ray_indices, co.shape[0],
+                                                        render_bkgd)
+        results.append((rgb, opacity, dep, semantics, len(t_starts)))
+    colors, opacities, depths, semantics = (torch.cat([r[k] for r in results], 0) for k in range(4))
+    shp = tuple(rays_shape[:-1])
+    return colors.view(*shp, -1), opacities.view(*shp, -1), depths.view(*shp, -1), semantics.view(*shp, -1), sum(r[4] for r in results)
+
+
+# ------------------------------------------------------------------ habitat_to_data.py
+def pose_to_c2w(p: np.ndarray) -> np.ndarray:
+    """habitat_to_data.py:444-451: xyz + quaternion (x, y, z, w) -> 4x4 camera-to-world (float64 on the host)."""
+    from scipy.spatial.transform import Rotation as R
+    pose = np.eye(4)
+    pose[:3, :3] = R.from_quat(p[3:]).as_matrix()
+    pose[:3, 3] = p[:3]
+    return pose
+
+
+def subsample_indices(n_total: int, n_keep: int) -> np.ndarray:
+    """habitat_to_data.py:462-467 (np.round = half-to-even, evaluated in float64 on the host)."""
+    return np.round(np.linspace(0, n_total - 1, n_keep)).astype(np.int64)
+
+
+@torch.no_grad()
+def generate_image_rays(pose, width, height, K, device, pix_idx=None):
+    """Dataset.generate_image_rays (habitat_to_data.py:274-301) for `pose` [V,4,4] / [V,3,4]; K is the 3x3
+    intrinsics the reference builds (only K[0,0] is used, fx == fy, principal point = image centre).
+    With `pix_idx` only those flat pixel indices are generated (the reference builds all W*H rays and then indexes)."""
+    pose = torch.as_tensor(np.asarray(pose.detach().cpu()) if isinstance(pose, torch.Tensor) else np.asarray(pose), dtype=torch.float32)
+    c2w = pose[:, :3, :4].contiguous().to(device)
+    L.require_gpu(c2w)
+    K = np.asarray(K.detach().cpu()) if isinstance(K, torch.Tensor) else np.asarray(K)
+    if abs(K[0, 2] - width / 2) > 1e-9 or abs(K[1, 2] - height / 2) > 1e-9 or abs(K[0, 0] - K[1, 1]) > 1e-9:
+        raise NotImplementedError("generate_image_rays supports the reference intrinsics (fx == fy, centred principal point)")
+    V = c2w.shape[0]
+    idx_t = None
+    n_pix = width * height
+    if pix_idx is not None:
+        idx_t = torch.as_tensor(np.asarray(pix_idx), dtype=torch.int64).to(device)
+        n_pix = idx_t.shape[0]
+    origins = torch.empty(V, n_pix, 3, device=device)
+    viewdirs = torch.empty(V, n_pix, 3, device=device)
+    L.check(L.load_library().mnf_generate_rays(L.ptr(c2w), V, width, height, float(np.float32(K[0, 0])), L.ptr(idx_t), n_pix,
+                                               L.ptr(origins), L.ptr(viewdirs), L.stream()))
+    if V == 1:
+        return Rays(origins=origins[0], viewdirs=viewdirs[0])
+    return Rays(origins=origins, viewdirs=viewdirs)
+
+
+def _pose_rays(poses, width, height, focal, scale, device):
+    c2w = np.stack([pose_to_c2w(np.asarray(p, np.float64)) for p in poses]).astype(np.float32)
+    h, w = int(height * scale), int(width * scale)
+    idx = subsample_indices(width * height, h * w)
+    K = np.array([[focal, 0.0, width / 2], [0.0, focal, height / 2], [0.0, 0.0, 1.0]])
+    rays = generate_image_rays(torch.from_numpy(c2w), width, height, K, device, idx)
+    V = c2w.shape[0]
+    return rays.origins.reshape(V * h * w, 3), rays.viewdirs.reshape(V * h * w, 3), h, w
+
+
+@torch.no_grad()
+def render_image_from_pose(radiance_field, estimator, poses, width, height, focal, near_plane, render_step_size, scale,
+                           cone_angle, alpha_thre, downsample, device="cuda:0"):
+    """Dataset.render_image_from_pose (habitat_to_data.py:304-411): all poses rendered in one batched call;
+    returns host float64 arrays (images [P,h,w,3], depths [P,h,w], accs [P,h,w], sems [P,h,w,C])."""
+    poses = np.asarray(poses)
+    o, d, h, w = _pose_rays(poses, width, height, focal, scale, device)
+    r = render_views(radiance_field, estimator, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
+                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre)
+    P, C = poses.shape[0], radiance_field.num_semantic_classes
+    f64 = lambda t, *s: t.reshape(P, h, w, *s).double().cpu().numpy()
+    return f64(r["rgb"], 3), f64(r["depth"]), f64(r["acc"]), f64(r["sem"], C)
+
+
+@torch.no_grad()
+def render_probablistic_image_from_pose(radiance_field, estimator, poses, width, height, focal, near_plane,
+                                        render_step_size, scale, cone_angle, alpha_thre, downsample, device="cuda:0"):
+    """Dataset.render_probablistic_image_from_pose (habitat_to_data.py:413-549) ->
+    (images, images_var, depths, depths_var, accs, sems) host float64 arrays."""
+    poses = np.asarray(poses)
+    o, d, h, w = _pose_rays(poses, width, height, focal, scale, device)
+    r = render_views(radiance_field, estimator, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
+                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, probabilistic=True)
+    P, C = poses.shape[0], radiance_field.num_semantic_classes
+    f64 = lambda t, *s: t.reshape(P, h, w, *s).double().cpu().numpy()
+    return f64(r["rgb"], 3), f64(r["rgb_var"], 3), f64(r["depth"]), f64(r["depth_var"]), f64(r["acc"]), f64(r["sem"], C)
+
+
+# ------------------------------------------------------------------ scorer (pipeline.py:666-798)
+@torch.no_grad()
+def score_view_terms(rgb_var, depth_var, acc, sem):
+    """Per-view predictive-information terms on the device.  Inputs are member-major stacks of the probabilistic
+    renders of M ensemble members for the same V views of P pixels: rgb_var [M,V,P,3], depth_var [M,V,P],
+    acc [M,V,P], sem [M,V,P,C] (fp32, GPU).  Returns [V,4] float64: rgb, depth, semantic, occupancy (un-weighted)."""
+    L.require_gpu(rgb_var, depth_var, acc, sem)
+    M, V, P, C = sem.shape
+    rv, dv, ac, sm = (L.contig(t, torch.float32) for t in (rgb_var, depth_var, acc, sem))
+    terms = torch.empty(V, 4, dtype=torch.float64, device=sem.device)
+    L.check(L.load_library().mnf_score_views(L.ptr(rv), L.ptr(dv), L.ptr(ac), L.ptr(sm), M, V, P, C, L.ptr(terms), L.stream()))
+    return terms
+
+
+@torch.no_grad()
+def score_views(radiance_fields, estimators, poses, width, height, focal, near_plane, render_step_size, scale, cone_angle,
+                alpha_thre, device="cuda:0", group=None):
+    """Predictive information of candidate views, sharded over the ranks of `group` (pipeline.py:666-798 +
+    SURVEY.md §8e): every rank renders its contiguous slice of `poses` with every ensemble member, reduces to
+    per-view terms on the device, and one all-gather (RCCL over xGMI) of [V,4] float64 gives every rank all terms.
+    Returns (terms [V,4] float64 on device, score = mean_v(t0 + t1 + 3 t2 + 2 t3))."""
+    import torch.distributed as dist
+    poses = np.asarray(poses)
+    V = poses.shape[0]
+    world, rank = 1, 0
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (V + world - 1) // world
+    lo, hi = min(rank * per, V), min((rank + 1) * per, V)
+    terms_local = torch.zeros(per, 4, dtype=torch.float64, device=device)
+    if hi > lo:
+        o, d, h, w = _pose_rays(poses[lo:hi], width, height, focal, scale, device)
+        rv, dv, ac, sm = [], [], [], []
+        for rf, est in zip(radiance_fields, estimators):
+            r = render_views(rf, est, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
+                             render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, probabilistic=True)
+            n = hi - lo
+            rv.append(r["rgb_var"].reshape(n, h * w, 3)); dv.append(r["depth_var"].reshape(n, h * w))
+            ac.append(r["acc"].reshape(n, h * w)); sm.append(r["sem"].reshape(n, h * w, -1))
+        terms_local[:hi - lo] = score_view_terms(torch.stack(rv), torch.stack(dv), torch.stack(ac), torch.stack(sm))
+    if world > 1:
+        gathered = torch.empty(world * per, 4, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(gathered, terms_local, group=group)
+        terms = gathered[:V]
+    else:
+        terms = terms_local[:V]
+    score = (terms[:, 0] + terms[:, 1] + 3 * terms[:, 2] + 2 * terms[:, 3]).mean()
+    return terms, score

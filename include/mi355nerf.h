@@ -1,0 +1,181 @@
+/*
+ * mi355nerf.h — C ABI of libmi355nerf.so, the MI355X (gfx950) implementation of the
+ * reference's perception hot path.
+ *
+ * The reference has no FFI of its own: its native layer is (1) the pybind11 module
+ * `nerfacc_cuda` (perception/nerfacc/nerfacc/cuda/csrc/nerfacc.cpp:100-128) and (2) the
+ * un-vendored `tinycudann` torch extension (perception/models/radiance_fields/ngp.py:108-169).
+ * Each entry point below names the reference interface it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *     buffers are caller-owned, the library allocates nothing per call except inside handles;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
+ *     enqueues work unless documented otherwise;
+ *   - return value 0 = ok, negative = error; text via mnf_last_error() (thread-local);
+ *   - handles are thread-compatible, not thread-safe;
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef MI355NERF_H
+#define MI355NERF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNF_OK 0
+#define MNF_ERR_INVALID (-1)
+#define MNF_ERR_HIP (-2)
+#define MNF_ERR_UNSUPPORTED (-3)
+#define MNF_ERR_WORKSPACE (-4)
+
+typedef void *mnf_stream_t;
+typedef struct mnf_field_s *mnf_field_t;
+
+const char *mnf_last_error(void);
+int mnf_version(void);
+/* number of visible HIP devices (0 when there is none; never initialises a context) */
+int mnf_device_count(void);
+
+/* ---------------------------------------------------------------- nerfacc_cuda replacements */
+
+/* nerfacc.cpp:110 `ray_aabb_intersect` (grid.cu:477-519, kernel :284-313).
+ * t_mins,t_maxs [n_rays,n_aabbs] f32; hits [n_rays,n_aabbs] u8 (torch.bool layout). */
+int mnf_ray_aabb_intersect(const float *rays_o, const float *rays_d, int32_t n_rays,
+                           const float *aabbs, int32_t n_aabbs,
+                           float near_plane, float far_plane, float miss_value,
+                           float *t_mins, float *t_maxs, uint8_t *hits, mnf_stream_t stream);
+
+/* One launch of the reference's `traverse_grids_kernel` (grid.cu:68-282); the host-side
+ * count / cumsum / fill protocol of grid.cu:320-474 is driven by the caller exactly as the
+ * reference's C++ does (first_pass=1 writes chunk_cnts only; first_pass=0 fills at
+ * chunk_starts and rewrites chunk_cnts with the actual counts).  Pointers of a disabled output
+ * are NULL (iv_chunk_cnts==NULL disables intervals, sm_chunk_cnts==NULL disables samples).
+ * binaries [n_grids,X,Y,Z] u8; t_indices/ray_indices/chunk_* are int64 as in the reference. */
+int mnf_traverse_grids(const float *rays_o, const float *rays_d, const uint8_t *rays_mask, int32_t n_rays,
+                       const uint8_t *binaries, const float *aabbs, int32_t n_grids,
+                       int32_t res_x, int32_t res_y, int32_t res_z,
+                       const uint8_t *hits, const float *t_sorted, const int64_t *t_indices,
+                       const float *near_planes, const float *far_planes,
+                       float step_size, float cone_angle, int32_t traverse_steps_limit, int32_t first_pass,
+                       float *iv_vals, int64_t *iv_ray_indices, uint8_t *iv_is_left, uint8_t *iv_is_right,
+                       const int64_t *iv_chunk_starts, int64_t *iv_chunk_cnts,
+                       float *sm_vals, int64_t *sm_ray_indices, uint8_t *sm_is_valid,
+                       const int64_t *sm_chunk_starts, int64_t *sm_chunk_cnts,
+                       float *terminate_planes, mnf_stream_t stream);
+
+/* nerfacc.cpp:104 `exclusive_sum` (scan.cu:68-125); backward=1 is the reverse-direction scan
+ * used by the autograd rule (scan.py:226-228). */
+int mnf_exclusive_sum(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                      const float *inputs, float *outputs, int64_t n_edges, int32_t backward,
+                      mnf_stream_t stream);
+
+/* Fused render_weight_from_density (volrend.py:315-365) on packed samples:
+ * weights = T*alpha, trans, alphas with an optional per-sample prefix transmittance (may be NULL). */
+int mnf_render_weight_from_density(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                   const float *t_starts, const float *t_ends, const float *sigmas,
+                                   const float *prefix_trans, int64_t n_samples,
+                                   float *weights, float *trans, float *alphas, mnf_stream_t stream);
+
+/* ---------------------------------------------------------------- ray generation */
+
+/* Dataset.generate_image_rays (perception/data_proc/habitat_to_data.py:274-301) for n_views poses,
+ * restricted to the flat pixel indices pix_idx[n_pix] (int64; the np.round(np.linspace(...))
+ * sub-sampler of :462-467 is evaluated by the caller on the host in float64, as the reference does;
+ * NULL = all width*height pixels).  c2w [n_views,3,4] row-major f32.
+ * origins, viewdirs [n_views, n_pix, 3] f32. */
+int mnf_generate_rays(const float *c2w, int32_t n_views, int32_t width, int32_t height, float focal,
+                      const int64_t *pix_idx, int64_t n_pix, float *origins, float *viewdirs,
+                      mnf_stream_t stream);
+
+/* ---------------------------------------------------------------- radiance field (tinycudann replacement) */
+
+typedef struct {
+    float aabb[6];                 /* ngp.py:91 */
+    int32_t neurons;               /* ngp.py:77  (64 or 128) */
+    int32_t layers;                /* ngp.py:78  == tcnn n_hidden_layers of the base MLP (>=1) */
+    int32_t num_semantic_classes;  /* ngp.py:87  (1..32) */
+    int32_t n_levels;              /* ngp.py:84  (must be 16) */
+    int32_t n_features;            /* ngp.py:127 (must be 4) */
+    int32_t log2_hashmap_size;     /* ngp.py:85 */
+    int32_t base_resolution;       /* ngp.py:81 */
+    int32_t max_resolution;        /* ngp.py:82 */
+} mnf_field_config;
+
+/* tcnn.NetworkWithInputEncoding / tcnn.Network / tcnn.Encoding construction, ngp.py:108-169 */
+int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out);
+int mnf_field_destroy(mnf_field_t f);
+/* number of fp32 parameters of module `which` (0 = mlp_base incl. hash table, 1 = mlp_head, 2 = mlp_sem),
+ * i.e. the length of the reference state_dict entry `<module>.params` */
+int64_t mnf_field_param_count(mnf_field_t f, int32_t which);
+/* per-level metadata for tests: out arrays of n_levels entries (HOST pointers) */
+int mnf_field_grid_meta_host(mnf_field_t f, float *scale_host, int32_t *res_host, int32_t *size_host,
+                             int64_t *offset_host, int32_t *hashed_host);
+/* Load fp32 master parameters (device pointers, reference state_dict layout) and build the fp16
+ * hash table and MFMA-fragment-ordered fp16 weights held by the handle. */
+int mnf_field_set_params(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem,
+                         mnf_stream_t stream);
+
+/* NGPRadianceField.forward (ngp.py:222-238): positions,directions [n,3] f32 ->
+ * rgb [n,3], density [n,1], sem [n,C] f32 (any output may be NULL). */
+int mnf_field_forward(mnf_field_t f, const float *positions, const float *directions, int64_t n,
+                      float *rgb, float *density, float *sem, mnf_stream_t stream);
+/* NGPRadianceField.query_density (ngp.py:171-200): density [n,1] */
+int mnf_field_density(mnf_field_t f, const float *positions, int64_t n, float *density, mnf_stream_t stream);
+/* the closures sigma_fn / rgb_sigma_sem_fn of utils.py:89-137 fused with the field:
+ * positions = o[ray] + d[ray]*(t_start+t_end)/2, directions = d[ray]; ray_indices int64 */
+int mnf_field_forward_samples(mnf_field_t f, const float *rays_o, const float *rays_d,
+                              const int64_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                              float *rgb, float *density, float *sem, mnf_stream_t stream);
+
+/* ---------------------------------------------------------------- fused test-mode renderers */
+
+typedef struct {
+    float near_plane;        /* utils.py:563 */
+    float far_plane;         /* utils.py:564 */
+    float render_step_size;  /* utils.py:565 */
+    float cone_angle;        /* utils.py:567 */
+    float alpha_thre;        /* utils.py:568 */
+    float early_stop_eps;    /* utils.py:569 */
+    float render_bkgd[3];    /* utils.py:566 */
+    int32_t max_samples;     /* utils.py:557 */
+    int32_t probabilistic;   /* 0: render_image_with_occgrid_test, 1: render_probablistic_image_with_occgrid_test */
+    int32_t rays_per_view;   /* rays of one reference call; n_rays must be a multiple of it.  Each group of
+                                rays_per_view consecutive rays is rendered exactly as one call of the reference
+                                function (its own n_alive / n_samples round schedule, utils.py:667-672). */
+    int32_t sync_every;      /* host checks the device "all views finished" flag every this many rounds
+                                (stream sync); 0 = never (all ceil(max_samples/min_samples) rounds are enqueued) */
+} mnf_render_opts;
+
+/* bytes of workspace mnf_render_test needs for n_rays rays */
+int64_t mnf_render_workspace_bytes(int64_t n_rays, int32_t rays_per_view);
+
+/* render_image_with_occgrid_test (perception/models/utils.py:555-779) and
+ * render_probablistic_image_with_occgrid_test (utils.py:782-1032), single occupancy level.
+ * binaries [1,X,Y,Z] u8, aabb[6] = estimator.aabbs[0].
+ * Outputs: rgb [n,3], acc [n,1], depth [n,1], sem [n,C]; rgb_var [n,3], depth_var [n,1] (probabilistic only,
+ * may be NULL otherwise); total_samples: one int64 (device).  Synchronises the stream only as sync_every asks. */
+int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32_t res_y, int32_t res_z,
+                    const float *aabb_host, const float *rays_o, const float *rays_d, int64_t n_rays,
+                    const mnf_render_opts *opts,
+                    float *rgb, float *acc, float *depth, float *sem, float *rgb_var, float *depth_var,
+                    int64_t *total_samples, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
+
+/* ---------------------------------------------------------------- predictive-information scorer */
+
+/* scripts/pipeline.py:727-781 on device.  Inputs are the renders of n_members ensemble members for the
+ * same n_views views of n_pix pixels: member-major arrays rgb_var [M,V,P,3], depth_var [M,V,P], acc [M,V,P],
+ * sem [M,V,P,C] f32.  Output terms [V,4] f64 = per-view means of the rgb / depth / semantic / occupancy
+ * predictive-information terms (un-weighted); the trajectory score is
+ * mean_v(t0 + t1 + 3*t2 + 2*t3) (pipeline.py:775-781). */
+int mnf_score_views(const float *rgb_var, const float *depth_var, const float *acc, const float *sem,
+                    int32_t n_members, int32_t n_views, int32_t n_pix, int32_t n_classes,
+                    double *terms, mnf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

