@@ -204,9 +204,9 @@ extern "C" int mnf_traverse_grids(const float *rays_o, const float *rays_d, cons
     MNF_REQUIRE(rays_o && rays_d && binaries && aabbs && hits && t_sorted && t_indices && near_planes && far_planes,
                 "traverse_grids: null input pointer");
     if (!first_pass) {
-        MNF_REQUIRE(!iv_chunk_cnts || (iv_chunk_starts && iv_vals && iv_ray_indices && iv_is_left && iv_is_right),
-                    "traverse_grids: fill pass needs interval buffers");
-        MNF_REQUIRE(!sm_chunk_cnts || (sm_chunk_starts && sm_vals && sm_ray_indices), "traverse_grids: fill pass needs sample buffers");
+        // value buffers may legitimately be empty (NULL) when no ray produced a sample: the fill pass skips such rays
+        MNF_REQUIRE(!iv_chunk_cnts || iv_chunk_starts, "traverse_grids: fill pass needs interval chunk_starts");
+        MNF_REQUIRE(!sm_chunk_cnts || sm_chunk_starts, "traverse_grids: fill pass needs sample chunk_starts");
     }
     SegOut iv = {iv_vals, iv_ray_indices, iv_is_left, iv_is_right, nullptr, iv_chunk_starts, iv_chunk_cnts};
     SegOut sm = {sm_vals, sm_ray_indices, nullptr, nullptr, sm_is_valid, sm_chunk_starts, sm_chunk_cnts};

@@ -12,6 +12,8 @@
 // same launches, each with its own round schedule.
 //
 // Build with -ffp-contract=off (march_dev.h).
+#include <vector>
+
 #include "field.h"
 #include "march_dev.h"
 
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(kRayThreads) init_kernel(int64_t n_rays, int32
                                                            float a0, float a1, float a2, float a3, float a4, float a5,
                                                            float near_plane, RenderWs ws, RenderOut out) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r == 0) { *out.total_samples = 0; }
+    if (r == 0) { out.total_samples[0] = 0; out.total_samples[1] = 0; }
     if (r < n_rays / rays_per_view) { ws.alive_count[r] = rays_per_view; ws.iter_samples[r] = 0; }
     if (r >= n_rays) return;
     const float ab[6] = {a0, a1, a2, a3, a4, a5};
@@ -194,17 +196,19 @@ __global__ void __launch_bounds__(kRayThreads) composite_kernel(int64_t n_rays, 
                                                                 RenderWs ws, RenderOut out) {
     __shared__ int s_alive;
     __shared__ int s_kept;
-    if (threadIdx.x == 0) { s_alive = 0; s_kept = 0; }
+    __shared__ int s_marched;
+    if (threadIdx.x == 0) { s_alive = 0; s_kept = 0; s_marched = 0; }
     __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t r_first = (int64_t)blockIdx.x * blockDim.x;
     const int64_t r_last = min(r_first + (int64_t)blockDim.x, n_rays) - 1;
     const bool one_view = (r_first / rays_per_view) == (r_last / rays_per_view);
-    int kept = 0;
+    int kept = 0, marched = 0;
     bool still_alive = false;
     if (r < n_rays && ws.marched[r]) {
         const int v = (int)(r / rays_per_view);
         const int cnt = ws.cnt[r], col0 = ws.col0[r];
+        marched = cnt;
         float opacity = out.acc[r];
         const float prefix = 1.0f - opacity;                         // utils.py:712
         float c0 = out.rgb[3 * r], c1 = out.rgb[3 * r + 1], c2 = out.rgb[3 * r + 2];
@@ -263,17 +267,19 @@ __global__ void __launch_bounds__(kRayThreads) composite_kernel(int64_t n_rays, 
     }
     // block-aggregated counters
     const unsigned long long m_alive = __ballot(still_alive);
-    int wave_kept = kept;
+    int wave_kept = kept, wave_marched = marched;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wave_kept += __shfl_xor(wave_kept, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) { wave_kept += __shfl_xor(wave_kept, d, 64); wave_marched += __shfl_xor(wave_marched, d, 64); }
     if ((threadIdx.x & 63) == 0) {
         if (one_view && m_alive) atomicAdd(&s_alive, __popcll(m_alive));
         if (wave_kept) atomicAdd(&s_kept, wave_kept);
+        if (wave_marched) atomicAdd(&s_marched, wave_marched);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (one_view && s_alive) atomicAdd(&ws.alive_count[r_first / rays_per_view], s_alive);
         if (s_kept) atomicAdd((unsigned long long *)out.total_samples, (unsigned long long)s_kept);
+        if (s_marched) atomicAdd((unsigned long long *)out.total_samples + 1, (unsigned long long)s_marched);
     }
 }
 
@@ -371,9 +377,51 @@ __global__ void __launch_bounds__(256) score_kernel(const float *__restrict__ rg
     }
 }
 
+// ------------------------------------------------------------------ optional field-kernel timing (bench.py roofline)
+struct Profile {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs: start, stop
+    size_t used = 0;
+};
+static thread_local Profile g_prof;
+
+static void profile_mark(hipStream_t s, bool start) {
+    if (!g_prof.on) return;
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        g_prof.ev.push_back(e);
+    }
+    (void)start;
+    (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
+}
+
 }  // namespace mnf
 
 using namespace mnf;
+
+extern "C" int mnf_profile_begin(void) {
+    g_prof.on = true;
+    g_prof.used = 0;
+    return MNF_OK;
+}
+
+extern "C" int mnf_profile_end(double *field_ms_host, int64_t *launches_host) {
+    g_prof.on = false;
+    double ms = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        MNF_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+        float t = 0.f;
+        MNF_HIP(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+        ms += t;
+        ++n;
+    }
+    g_prof.used = 0;
+    if (field_ms_host) *field_ms_host = ms;
+    if (launches_host) *launches_host = n;
+    return MNF_OK;
+}
 
 extern "C" int64_t mnf_render_workspace_bytes(int64_t n_rays, int32_t rays_per_view) {
     if (n_rays <= 0 || rays_per_view <= 0 || n_rays % rays_per_view) return -1;
@@ -434,7 +482,9 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
         hipLaunchKernelGGL(round_march_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,
                            opts->rays_per_view, rays_o, rays_d, binaries, res, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
                            opts->far_plane, opts->render_step_size, opts->cone_angle, ws);
+        profile_mark(s, true);
         rc = launch_field(f, io, false, s);
+        profile_mark(s, false);
         if (rc) return rc;
         hipLaunchKernelGGL(composite_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,
                            opts->rays_per_view, C, opts->alpha_thre, opc_thre, opts->probabilistic, ws, out);

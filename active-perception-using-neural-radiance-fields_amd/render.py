@@ -64,7 +64,7 @@ def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_p
     sem = torch.empty(n, C, device=dev)
     rgb_var = torch.empty(n, 3, device=dev) if probabilistic else None
     depth_var = torch.empty(n, 1, device=dev) if probabilistic else None
-    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    total = torch.zeros(2, dtype=torch.int64, device=dev)   # [kept (reference total_samples), evaluated]
     lib = L.load_library()
     if n:
         nbytes = lib.mnf_render_workspace_bytes(n, rpv)
@@ -93,7 +93,7 @@ def render_image_with_occgrid_test(max_samples: int, radiance_field, estimator, 
         raise NotImplementedError("timestamps (D-NeRF) are not part of the hot path")
     r = _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane, render_step_size, render_bkgd,
                      cone_angle, alpha_thre, early_stop_eps, False)
-    return r["rgb"], r["acc"], r["depth"], r["sem"], int(r["total"].item())
+    return r["rgb"], r["acc"], r["depth"], r["sem"], int(r["total"][0].item())
 
 
 @torch.no_grad()
@@ -107,7 +107,7 @@ def render_probablistic_image_with_occgrid_test(max_samples: int, radiance_field
         raise NotImplementedError("timestamps (D-NeRF) are not part of the hot path")
     r = _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane, render_step_size, render_bkgd,
                      cone_angle, alpha_thre, early_stop_eps, True)
-    return r["rgb"], r["rgb_var"], r["acc"], r["depth"], r["depth_var"], r["sem"], int(r["total"].item())
+    return r["rgb"], r["rgb_var"], r["acc"], r["depth"], r["depth_var"], r["sem"], int(r["total"][0].item())
 
 
 @torch.no_grad()

@@ -157,12 +157,21 @@ int64_t mnf_render_workspace_bytes(int64_t n_rays, int32_t rays_per_view);
  * render_probablistic_image_with_occgrid_test (utils.py:782-1032), single occupancy level.
  * binaries [1,X,Y,Z] u8, aabb[6] = estimator.aabbs[0].
  * Outputs: rgb [n,3], acc [n,1], depth [n,1], sem [n,C]; rgb_var [n,3], depth_var [n,1] (probabilistic only,
- * may be NULL otherwise); total_samples: one int64 (device).  Synchronises the stream only as sync_every asks. */
+ * may be NULL otherwise); total_samples: TWO int64 (device): [0] = the reference's total_samples (samples kept
+ * after the alpha threshold, utils.py:757), [1] = samples evaluated by the field (all marched samples).
+ * Synchronises the stream only as sync_every asks. */
 int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32_t res_y, int32_t res_z,
                     const float *aabb_host, const float *rays_o, const float *rays_d, int64_t n_rays,
                     const mnf_render_opts *opts,
                     float *rgb, float *acc, float *depth, float *sem, float *rgb_var, float *depth_var,
                     int64_t *total_samples, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
+
+/* Optional in-library timing of the dominant kernel (the fused field kernel) for bench.py's roofline line:
+ * between begin and end every field-kernel launch made by mnf_render_test on this thread is bracketed by a
+ * hipEvent pair on the launch stream.  mnf_profile_end synchronises those events and returns the summed
+ * kernel milliseconds and the number of launches.  Not part of the reference surface. */
+int mnf_profile_begin(void);
+int mnf_profile_end(double *field_ms_host, int64_t *launches_host);
 
 /* ---------------------------------------------------------------- predictive-information scorer */
 

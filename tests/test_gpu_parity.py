@@ -85,7 +85,8 @@ def test_traverse_grids_two_pass_bit_exact(n_grids, cone):
     ref = M.traverse_grids(o, d, binaries, aabbs, near, far, 5e-3, cone)
     got = NA.traverse_grids(_cu(o), _cu(d), _cu(binaries), _cu(aabbs), _cu(near), _cu(far), 5e-3, cone)
     term, rterm = _assert_traverse_equal(got, ref)
-    np.testing.assert_array_equal(term.cpu().numpy(), rterm)
+    hit = ref[1].packed_info[:, 1] > 0      # the fill pass skips empty rays before writing their plane (grid.cu:106-110)
+    np.testing.assert_array_equal(term.cpu().numpy()[hit], rterm[hit])
     assert ref[1].packed_info[:, 1].sum() > 10000
     # reference property (tests/test_grid.py:39-68): every sample lies in an occupied cell
     iv, sm, _ = got
@@ -219,7 +220,9 @@ def test_field_forward_matches_oracle(neurons, layers, C, lh):
     np.testing.assert_allclose(sigma.cpu().numpy(), r_sigma.numpy(), rtol=2e-3, atol=1e-6)
     np.testing.assert_array_equal(dens.cpu().numpy(), sigma.cpu().numpy())      # density-only kernel == full kernel
     np.testing.assert_allclose(rgb.cpu().numpy()[inside], r_rgb.numpy()[inside], atol=1e-3, rtol=0)
-    np.testing.assert_allclose(sem.cpu().numpy()[inside], r_sem.numpy()[inside], atol=1e-3, rtol=0)
+    # head_gain=4 amplifies the logits (|sem| up to ~2): one fp16 rounding flip of a hidden activation moves a logit
+    # by ~1e-3 * |logit|, hence the relative term
+    np.testing.assert_allclose(sem.cpu().numpy()[inside], r_sem.numpy()[inside], atol=1e-3, rtol=2e-3)
     assert np.abs(r_sem.numpy()).max() > 0.5                                     # the comparison is not vacuous
 
 
@@ -251,7 +254,7 @@ def _check_render(out, ref, prob):
     if prob:
         np.testing.assert_allclose(out["rgb_var"].cpu().numpy(), ref["rgb_var"].numpy(), **tol)
         np.testing.assert_allclose(out["depth_var"].cpu().numpy(), ref["depth_var"].numpy(), atol=2e-3, rtol=2e-3)
-    tot = int(out["total"].item())
+    tot = int(out["total"][0].item())
     assert abs(tot - ref["total_samples"]) <= max(3, 0.002 * ref["total_samples"]), (tot, ref["total_samples"])
 
 
@@ -299,7 +302,7 @@ def test_render_batched_views_equal_single_calls(scene, fields):
     far_o = torch.full((64, 3), 100.0, device=DEV)
     far_d = torch.tensor([[0.0, 1.0, 0.0]], device=DEV).repeat(64, 1)
     miss = RD.render_views(hip, est, far_o, far_d, 64, 1024, render_bkgd=torch.tensor([0.2, 0.4, 0.8]), **H.RENDER_KW)
-    assert int(miss["total"].item()) == 0 and (miss["acc"] == 0).all()
+    assert int(miss["total"][0].item()) == 0 and (miss["acc"] == 0).all()
     np.testing.assert_allclose(miss["rgb"].cpu().numpy(), np.tile([[0.2, 0.4, 0.8]], (64, 1)), atol=1e-7)
 
 
