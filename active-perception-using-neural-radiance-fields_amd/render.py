@@ -32,12 +32,24 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+_AABB_HOST = {}
+
+
 def _single_level(estimator):
+    """-> (binaries u8 [1,X,Y,Z] on device, aabb as 6 host floats).  The host copy of the aabb is cached per
+    tensor version so that a render call does not synchronise the device."""
     if estimator.binaries.shape[0] != 1:
         raise NotImplementedError("the fused renderer supports one occupancy level (the reference configs use "
                                   "main_grid_nlvl: 1); use nerfacc.traverse_grids for multi-level grids")
     b = estimator.binaries
-    return (b.contiguous().view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8).contiguous()), estimator.aabbs[0]
+    b = b.contiguous().view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8).contiguous()
+    a = estimator.aabbs
+    key = (a.data_ptr(), a._version, a.device)
+    host = _AABB_HOST.get(id(estimator))
+    if host is None or host[0] != key:
+        host = (key, [float(x) for x in a[0].detach().cpu().tolist()])
+        _AABB_HOST[id(estimator)] = host
+    return b, host[1]
 
 
 def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane, render_step_size, render_bkgd,
@@ -71,7 +83,7 @@ def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_p
         if nbytes < 0:
             raise L.MnfError(f"n_rays ({n}) must be a positive multiple of rays_per_view ({rpv})")
         ws = _workspace(dev, nbytes)
-        aabb_host = (ctypes.c_float * 6)(*[float(x) for x in aabb.detach().cpu().tolist()])
+        aabb_host = (ctypes.c_float * 6)(*aabb)
         res = binaries.shape[1:]
         L.check(lib.mnf_render_test(handle, L.ptr(binaries), res[0], res[1], res[2], aabb_host, L.ptr(o), L.ptr(d), n,
                                     ctypes.byref(opts), L.ptr(rgb), L.ptr(acc), L.ptr(depth), L.ptr(sem), L.ptr(rgb_var),
@@ -266,12 +278,35 @@ def score_view_terms(rgb_var, depth_var, acc, sem):
     return terms
 
 
+def shard_views(n_views: int, world: int, rank: int):
+    """Contiguous view slice of `rank`: (lo, hi, per) with per = ceil(V / world) rows reserved per rank."""
+    per = (n_views + world - 1) // world
+    return min(rank * per, n_views), min((rank + 1) * per, n_views), per
+
+
+def gather_view_terms(terms_local: torch.Tensor, n_views: int, group=None) -> torch.Tensor:
+    """One all-gather of the per-rank [per,4] float64 term blocks (RCCL over xGMI on GPUs, gloo on CPU tensors);
+    returns the [V,4] terms on every rank.  With no process group it is the identity."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return terms_local[:n_views]
+    world = dist.get_world_size(group)
+    gathered = torch.empty(world * terms_local.shape[0], 4, dtype=terms_local.dtype, device=terms_local.device)
+    dist.all_gather_into_tensor(gathered, terms_local.contiguous(), group=group)
+    return gathered[:n_views]
+
+
+def trajectory_score(terms: torch.Tensor) -> torch.Tensor:
+    """pipeline.py:775-781: rgb + depth + 3*sem + 2*occ, averaged over the views."""
+    return (terms[:, 0] + terms[:, 1] + 3 * terms[:, 2] + 2 * terms[:, 3]).mean()
+
+
 @torch.no_grad()
 def score_views(radiance_fields, estimators, poses, width, height, focal, near_plane, render_step_size, scale, cone_angle,
                 alpha_thre, device="cuda:0", group=None):
     """Predictive information of candidate views, sharded over the ranks of `group` (pipeline.py:666-798 +
     SURVEY.md §8e): every rank renders its contiguous slice of `poses` with every ensemble member, reduces to
-    per-view terms on the device, and one all-gather (RCCL over xGMI) of [V,4] float64 gives every rank all terms.
+    per-view terms on the device, and one all-gather of [V,4] float64 gives every rank all terms.
     Returns (terms [V,4] float64 on device, score = mean_v(t0 + t1 + 3 t2 + 2 t3))."""
     import torch.distributed as dist
     poses = np.asarray(poses)
@@ -279,24 +314,17 @@ def score_views(radiance_fields, estimators, poses, width, height, focal, near_p
     world, rank = 1, 0
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-    per = (V + world - 1) // world
-    lo, hi = min(rank * per, V), min((rank + 1) * per, V)
+    lo, hi, per = shard_views(V, world, rank)
     terms_local = torch.zeros(per, 4, dtype=torch.float64, device=device)
     if hi > lo:
         o, d, h, w = _pose_rays(poses[lo:hi], width, height, focal, scale, device)
         rv, dv, ac, sm = [], [], [], []
+        n = hi - lo
         for rf, est in zip(radiance_fields, estimators):
             r = render_views(rf, est, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
                              render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, probabilistic=True)
-            n = hi - lo
             rv.append(r["rgb_var"].reshape(n, h * w, 3)); dv.append(r["depth_var"].reshape(n, h * w))
             ac.append(r["acc"].reshape(n, h * w)); sm.append(r["sem"].reshape(n, h * w, -1))
-        terms_local[:hi - lo] = score_view_terms(torch.stack(rv), torch.stack(dv), torch.stack(ac), torch.stack(sm))
-    if world > 1:
-        gathered = torch.empty(world * per, 4, dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(gathered, terms_local, group=group)
-        terms = gathered[:V]
-    else:
-        terms = terms_local[:V]
-    score = (terms[:, 0] + terms[:, 1] + 3 * terms[:, 2] + 2 * terms[:, 3]).mean()
-    return terms, score
+        terms_local[:n] = score_view_terms(torch.stack(rv), torch.stack(dv), torch.stack(ac), torch.stack(sm))
+    terms = gather_view_terms(terms_local, V, group)
+    return terms, trajectory_score(terms)
