@@ -30,6 +30,7 @@
 namespace mnf {
 
 typedef _Float16 half_t;
+typedef _Float16 half2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -74,6 +75,20 @@ __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// relu(round_to_fp16(x)) == round_to_fp16(relu(x)) (rounding is monotonic and sign-preserving), so pack first
+// (v_cvt_pk_f16_f32, two values per instruction) and clamp in packed fp16 (v_pk_max_f16).
+__device__ __forceinline__ half8 relu_pack8(const f32x16 &acc, int s) {
+    half8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        half2 p = {(half_t)acc[8 * s + j], (half_t)acc[8 * s + j + 1]};
+        const half2 z = {(half_t)0.0f, (half_t)0.0f};
+        p = __builtin_elementwise_max(p, z);
+        r[j] = p[0]; r[j + 1] = p[1];
+    }
+    return r;
+}
+
 // One hidden layer, fused with ReLU + fp16 packing, one 32-row output tile at a time so that only
 // CT accumulator tiles are live: o[ct][2*rt + s] <- relu(W(rt,:) * b[ct])
 template <int RT_OUT, int KS>
@@ -95,9 +110,7 @@ __device__ __forceinline__ void dense_relu(const half8 *__restrict__ w_lds, int 
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[ct][rt * 2 + s][j] = (half_t)fmaxf(acc[ct][8 * s + j], 0.0f);
+            for (int s = 0; s < 2; ++s) o[ct][rt * 2 + s] = relu_pack8(acc[ct], s);
     }
 }
 
@@ -130,8 +143,16 @@ __device__ __forceinline__ void exchange_halves(half8 &lo, half8 &hi) {
     lo = __builtin_bit_cast(half8, a); hi = __builtin_bit_cast(half8, b);
 }
 
-// One hash level (wave-uniform metadata) for the lane's sample: 8 gathers of 8 bytes, trilinear blend in fp32
-__device__ __forceinline__ void hash_level(const half4 *__restrict__ table, const LevelMeta m, const float xn[3], float (&f)[4]) {
+// One hash level (wave-uniform metadata) for the lane's sample, split in two so that the gathers of several
+// levels can be in flight together: hash_prep computes the 8 byte offsets and the separable trilinear weights,
+// hash_blend consumes the 8 loaded entries.  The blend weight of corner (bx,by,bz) is ((wx*wy)*wz), the same
+// association as the oracle's running product.
+struct LevelPrep {
+    uint32_t off[8];
+    float wxy[4], wz[2];
+};
+
+__device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], LevelPrep &o) {
     float frac[3];
     uint32_t cell[3];
 #pragma unroll
@@ -141,38 +162,46 @@ __device__ __forceinline__ void hash_level(const half4 *__restrict__ table, cons
         frac[d] = pos - fl;
         cell[d] = (uint32_t)(int32_t)fl;
     }
-    uint32_t byte_off[8];
-    float w[8];
+    const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]};
+    o.wz[0] = 1.0f - frac[2]; o.wz[1] = frac[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.wxy[k] = (1.0f * wx[k & 1]) * wy[k >> 1];
+    uint32_t ty[2], tz[2];   // per-axis terms, shared by the four corners that use them
+    if (m.hashed) {          // uniform branch; size is 2^k when hashed
+        ty[0] = cell[1] * 2654435761u; ty[1] = (cell[1] + 1u) * 2654435761u;
+        tz[0] = cell[2] * 805459861u;  tz[1] = (cell[2] + 1u) * 805459861u;
+    } else {
+        ty[0] = cell[1] * m.res; ty[1] = ty[0] + m.res;
+        const uint32_t r2 = m.res * m.res;
+        tz[0] = cell[2] * r2; tz[1] = tz[0] + r2;
+    }
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
-        float ww = 1.0f;
-        uint32_t p[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int bit = (corner >> d) & 1;
-            ww *= bit ? frac[d] : (1.0f - frac[d]);
-            p[d] = cell[d] + (uint32_t)bit;
-        }
+        const uint32_t px = cell[0] + (uint32_t)(corner & 1);
         uint32_t idx;
-        if (m.hashed) {   // uniform branch
-            idx = (p[0] ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u)) & (m.size - 1u);   // size is 2^k when hashed
+        if (m.hashed) {
+            idx = (px ^ ty[(corner >> 1) & 1] ^ tz[corner >> 2]) & (m.size - 1u);
         } else {
-            idx = p[0] + p[1] * m.res + p[2] * m.res * m.res;
+            idx = px + ty[(corner >> 1) & 1] + tz[corner >> 2];
             if (idx >= m.size) idx %= m.size;   // only out-of-box positions / the far corner
         }
-        w[corner] = ww;
-        // 32-bit byte offset from the uniform table base -> global_load with an SGPR base, no 64-bit VGPR address
-        byte_off[corner] = (m.offset + idx) * 8u;
+        o.off[corner] = (m.offset + idx) * 8u;   // 32-bit byte offset from the uniform table base (SGPR base + VGPR offset)
     }
-    half4 v[8];
+}
+
+__device__ __forceinline__ void hash_load(const half4 *__restrict__ table, const LevelPrep &p, half4 (&v)[8]) {
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner)
-        v[corner] = *reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + byte_off[corner]);
+        v[corner] = *reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + p.off[corner]);
+}
+
+__device__ __forceinline__ void hash_blend(const LevelPrep &p, const half4 (&v)[8], float *f) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
-        a0 += w[corner] * (float)v[corner][0]; a1 += w[corner] * (float)v[corner][1];
-        a2 += w[corner] * (float)v[corner][2]; a3 += w[corner] * (float)v[corner][3];
+        const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
+        a0 += w * (float)v[corner][0]; a1 += w * (float)v[corner][1];
+        a2 += w * (float)v[corner][2]; a3 += w * (float)v[corner][3];
     }
     f[0] = a0; f[1] = a1; f[2] = a2; f[3] = a3;
 }
@@ -256,19 +285,21 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         }
         if (!valid) { xn[0] = 0.5f; xn[1] = 0.5f; xn[2] = 0.5f; }
 
-        // ---- hash encode: all 16 levels of this lane's sample, then trade halves with lane^32 ----
+        // ---- hash encode: all 16 levels of this lane's sample (one k-step = 4 levels = 32 gathers in flight),
+        //      then trade halves with lane^32 ----
         half8 bfeat[CT][4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float f[16];
+            LevelPrep prep[4];
+            half4 v[4][8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float t[4];
-                hash_level(args.table, args.levels[4 * ks + q], xn, t);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) f[4 * q + i] = t[i];
-                if (q == 1) __builtin_amdgcn_sched_barrier(0);   // at most two levels (16 gathers / lane) in flight
+                hash_prep(args.levels[4 * ks + q], xn, prep[q]);
+                hash_load(args.table, prep[q], v[q]);
             }
+            float f[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hash_blend(prep[q], v[q], f + 4 * q);
             half8 lo, hi;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }

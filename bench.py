@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="render800", choices=["render800", "score256"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket field-kernel launches with hipEvents")
     ap.add_argument("--cpu-sample", type=int, default=80, help="cpu baseline renders a SxS sub-sample of one view")
     return ap.parse_args()
 
@@ -112,7 +113,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    L.check(lib.mnf_profile_begin())
+    if not args.no_kernel_timing:
+        L.check(lib.mnf_profile_begin())
     evaluated = torch.zeros((), dtype=torch.int64, device=dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
