@@ -53,6 +53,10 @@ SIGNATURES = {
     "mnf_field_density": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_field_forward_samples": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_field_train_workspace_bytes": (c_int64, [c_void_p, c_int64]),
+    "mnf_field_forward_train": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_field_backward": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_render_workspace_bytes": (c_int64, [c_int64, c_int32]),
     "mnf_render_test": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p, c_void_p,
                                   c_int64, POINTER(RenderOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

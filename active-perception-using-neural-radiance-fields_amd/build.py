@@ -18,6 +18,7 @@ SOURCES = {
     "march.hip": ["-ffp-contract=off"],
     "render.hip": ["-ffp-contract=off"],
     "field.hip": [],
+    "train.hip": [],
 }
 
 

@@ -32,6 +32,8 @@ struct mnf_field_s {
     void *d_frags;       // fp16 fragment-ordered MLP weights, blocks_total KiB
     int32_t *d_frag_src; // gather table: (buffer << 28) | index, or -1 for a structural zero
     bool params_loaded;
+    const float *master[3];   // fp32 master parameter vectors last passed to mnf_field_set_params (caller-owned)
+    void *train_state;        // lazily built by train.hip (transposed fragments, weight-gradient job table)
 };
 
 namespace mnf {
@@ -53,6 +55,8 @@ struct FieldIO {
     float *col_srgb, *col_sem;
 };
 
-int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream);
+struct TrainBuf;
+void free_train_state(mnf_field_t f);
+int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train = nullptr);
 
 }  // namespace mnf

@@ -22,218 +22,18 @@
 //
 // Precision: fp16 parameters, fp16 features/activations at every matrix-product input, fp32
 // accumulation, fp32 outputs (oracle/field.py states the same model).
-#include "field.h"
+#include "field_dev.h"
 
 #include <cmath>
 #include <cstring>
 
 namespace mnf {
 
-typedef _Float16 half_t;
-typedef _Float16 half2 __attribute__((ext_vector_type(2)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int CT = 2;                            // 32-sample column tiles per wave (lane = sample, 64 samples per wave)
-constexpr int kWavesPerBlock = 8;                // 512 samples per workgroup pass, two waves per SIMD
-constexpr int kThreads = kWavesPerBlock * 64;
-constexpr int kWaveSamples = 32 * CT;
-
-// ------------------------------------------------------------------ fragment block bookkeeping
-template <int W, int NH>
-struct Layout {
-    static constexpr int Wh = W / 2;
-    static constexpr int RT = W / 32;     // row tiles of a base hidden layer
-    static constexpr int RTh = Wh / 32;   // row tiles of a head hidden layer
-    static constexpr int KSW = W / 16;    // k-steps over a W-wide activation
-    static constexpr int KSh = Wh / 16;
-    static constexpr int o_b_in = 0;
-    static constexpr int o_b_hid = o_b_in + RT * 4;
-    static constexpr int o_b_out = o_b_hid + (NH - 1) * RT * KSW;
-    static constexpr int o_h_in = o_b_out + KSW;
-    static constexpr int o_h_hid = o_h_in + RTh * 2;
-    static constexpr int o_h_out = o_h_hid + RTh * KSh;
-    static constexpr int o_s_in = o_h_out + KSh;
-    static constexpr int o_s_hid = o_s_in + RTh * 1;
-    static constexpr int o_s_out = o_s_hid + RTh * KSh;
-    static constexpr int blocks = o_s_out + KSh;
-};
-
-struct KernelArgs {
-    const half4 *table;
-    const half8 *frags;
-    float aabb[6];
-    int C;
-    LevelMeta levels[16];   // wave-uniform: read with scalar loads
-    FieldIO io;
-};
-
-// ------------------------------------------------------------------ device helpers
-__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-// relu(round_to_fp16(x)) == round_to_fp16(relu(x)) (rounding is monotonic and sign-preserving), so pack first
-// (v_cvt_pk_f16_f32, two values per instruction) and clamp in packed fp16 (v_pk_max_f16).
-__device__ __forceinline__ half8 relu_pack8(const f32x16 &acc, int s) {
-    half8 r;
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        half2 p = {(half_t)acc[8 * s + j], (half_t)acc[8 * s + j + 1]};
-        const half2 z = {(half_t)0.0f, (half_t)0.0f};
-        p = __builtin_elementwise_max(p, z);
-        r[j] = p[0]; r[j + 1] = p[1];
-    }
-    return r;
-}
-
-// One hidden layer, fused with ReLU + fp16 packing, one 32-row output tile at a time so that only
-// CT accumulator tiles are live: o[ct][2*rt + s] <- relu(W(rt,:) * b[ct])
-template <int RT_OUT, int KS>
-__device__ __forceinline__ void dense_relu(const half8 *__restrict__ w_lds, int lane, const half8 (&b)[CT][KS],
-                                           half8 (&o)[CT][RT_OUT * 2]) {
-#pragma unroll
-    for (int rt = 0; rt < RT_OUT; ++rt) {
-        f32x16 acc[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const half8 a = w_lds[(rt * KS + ks) * 64 + lane];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma(a, b[ct][ks], acc[ct]);
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) o[ct][rt * 2 + s] = relu_pack8(acc[ct], s);
-    }
-}
-
-// Output layer (one 32-row tile, no activation)
-template <int KS>
-__device__ __forceinline__ void dense_out(const half8 *__restrict__ w_lds, int lane, const half8 (&b)[CT][KS], f32x16 (&o)[CT]) {
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[ct][i] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const half8 a = w_lds[ks * 64 + lane];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) o[ct] = mfma(a, b[ct][ks], o[ct]);
-    }
-}
-
-// Lane l (sample A = column l of tile 0) and lane l+32 (sample B = column l of tile 1) each hold all 16
-// features of a k-step of THEIR sample as lo = features 0..7, hi = features 8..15.  The MFMA B operand wants,
-// for tile t, lane half h to hold features 8h..8h+7 of the tile-t sample.  One v_permlane32_swap per dword
-// (lo's upper 32 lanes <-> hi's lower 32 lanes) produces exactly that: lo -> tile-0 fragment, hi -> tile-1 fragment.
-__device__ __forceinline__ void exchange_halves(half8 &lo, half8 &hi) {
-    u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const auto r = __builtin_amdgcn_permlane32_swap(a[i], b[i], false, false);
-        a[i] = r[0]; b[i] = r[1];
-    }
-    lo = __builtin_bit_cast(half8, a); hi = __builtin_bit_cast(half8, b);
-}
-
-// One hash level (wave-uniform metadata) for the lane's sample, split in two so that the gathers of several
-// levels can be in flight together: hash_prep computes the 8 byte offsets and the separable trilinear weights,
-// hash_blend consumes the 8 loaded entries.  The blend weight of corner (bx,by,bz) is ((wx*wy)*wz), the same
-// association as the oracle's running product.
-struct LevelPrep {
-    uint32_t off[8];
-    float wxy[4], wz[2];
-};
-
-__device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], LevelPrep &o) {
-    float frac[3];
-    uint32_t cell[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float pos = __builtin_fmaf(m.scale, xn[d], 0.5f);
-        const float fl = floorf(pos);
-        frac[d] = pos - fl;
-        cell[d] = (uint32_t)(int32_t)fl;
-    }
-    const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]};
-    o.wz[0] = 1.0f - frac[2]; o.wz[1] = frac[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o.wxy[k] = (1.0f * wx[k & 1]) * wy[k >> 1];
-    uint32_t ty[2], tz[2];   // per-axis terms, shared by the four corners that use them
-    if (m.hashed) {          // uniform branch; size is 2^k when hashed
-        ty[0] = cell[1] * 2654435761u; ty[1] = (cell[1] + 1u) * 2654435761u;
-        tz[0] = cell[2] * 805459861u;  tz[1] = (cell[2] + 1u) * 805459861u;
-    } else {
-        ty[0] = cell[1] * m.res; ty[1] = ty[0] + m.res;
-        const uint32_t r2 = m.res * m.res;
-        tz[0] = cell[2] * r2; tz[1] = tz[0] + r2;
-    }
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        const uint32_t px = cell[0] + (uint32_t)(corner & 1);
-        uint32_t idx;
-        if (m.hashed) {
-            idx = (px ^ ty[(corner >> 1) & 1] ^ tz[corner >> 2]) & (m.size - 1u);
-        } else {
-            idx = px + ty[(corner >> 1) & 1] + tz[corner >> 2];
-            if (idx >= m.size) idx %= m.size;   // only out-of-box positions / the far corner
-        }
-        o.off[corner] = (m.offset + idx) * 8u;   // 32-bit byte offset from the uniform table base (SGPR base + VGPR offset)
-    }
-}
-
-__device__ __forceinline__ void hash_load(const half4 *__restrict__ table, const LevelPrep &p, half4 (&v)[8]) {
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner)
-        v[corner] = *reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + p.off[corner]);
-}
-
-__device__ __forceinline__ void hash_blend(const LevelPrep &p, const half4 (&v)[8], float *f) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
-        a0 += w * (float)v[corner][0]; a1 += w * (float)v[corner][1];
-        a2 += w * (float)v[corner][2]; a3 += w * (float)v[corner][3];
-    }
-    f[0] = a0; f[1] = a1; f[2] = a2; f[3] = a3;
-}
-
-// tcnn SphericalHarmonics degree 4 on 2u-1, u = (d+1)/2 (ngp.py:205): all 16 values of the lane's sample
-__device__ __forceinline__ void sh4(const float d[3], half8 &lo, half8 &hi) {
-    const float x = ((d[0] + 1.0f) / 2.0f) * 2.0f - 1.0f;
-    const float y = ((d[1] + 1.0f) / 2.0f) * 2.0f - 1.0f;
-    const float z = ((d[2] + 1.0f) / 2.0f) * 2.0f - 1.0f;
-    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-    lo[0] = (half_t)0.28209479177387814f;
-    lo[1] = (half_t)(-0.48860251190291987f * y);
-    lo[2] = (half_t)(0.48860251190291987f * z);
-    lo[3] = (half_t)(-0.48860251190291987f * x);
-    lo[4] = (half_t)(1.0925484305920792f * xy);
-    lo[5] = (half_t)(-1.0925484305920792f * yz);
-    lo[6] = (half_t)(0.94617469575755997f * z2 - 0.31539156525251999f);
-    lo[7] = (half_t)(-1.0925484305920792f * xz);
-    hi[0] = (half_t)(0.54627421529603959f * x2 - 0.54627421529603959f * y2);
-    hi[1] = (half_t)(0.59004358992664352f * y * (-3.0f * x2 + y2));
-    hi[2] = (half_t)(2.8906114426405538f * xy * z);
-    hi[3] = (half_t)(0.45704579946446572f * y * (1.0f - 5.0f * z2));
-    hi[4] = (half_t)(0.3731763325901154f * z * (5.0f * z2 - 3.0f));
-    hi[5] = (half_t)(0.45704579946446572f * x * (1.0f - 5.0f * z2));
-    hi[6] = (half_t)(1.4453057213202769f * z * (x2 - y2));
-    hi[7] = (half_t)(0.59004358992664352f * x * (-x2 + 3.0f * y2));
-}
-
 // ------------------------------------------------------------------ the fused kernel
-template <int W, int NH, int MODE, bool DENSITY_ONLY>
+template <int W, int NH, int MODE, bool DENSITY_ONLY, bool SAVE = false>
 __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs args) {
     using L = Layout<W, NH>;
+    using T = TrainLayout<W, NH>;
     constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
     __shared__ half8 s_w[kBlocks * 64];
 
@@ -308,9 +108,32 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        // column of tile ct held by this lane in MFMA layout, and the mask-dump base of this tile
+        SaveOff so[CT];
+        if (SAVE) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(args.train, h, tile * kWaveSamples + (lane & 31) + 32 * ct);
+        }
+        half8 *mdump = SAVE ? args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
+        if (SAVE) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) save_rows<false>(args.train, T::rX + 16 * ks, so[ct], bfeat[ct][ks]);
+        }
+
         // ---- base MLP ----
         half8 hb[CT][L::KSW];
         dense_relu<L::RT, 4>(s_w + L::o_b_in * 64, lane, bfeat, hb);
+        if (SAVE) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int k = 0; k < L::KSW; ++k) {
+                    save_rows<true>(args.train, T::rH0 + 16 * k, so[ct], hb[ct][k]);
+                    mdump[((T::mH0 + k) * CT + ct) * 64] = hb[ct][k];
+                }
+        }
 #pragma unroll
         for (int l = 0; l < NH - 1; ++l) {
             half8 hn[CT][L::KSW];
@@ -319,6 +142,15 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int k = 0; k < L::KSW; ++k) hb[ct][k] = hn[ct][k];
+            if (SAVE) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int k = 0; k < L::KSW; ++k) {
+                        save_rows<true>(args.train, T::rH0 + (l + 1) * W + 16 * k, so[ct], hb[ct][k]);
+                        mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = hb[ct][k];
+                    }
+            }
         }
         f32x16 bo[CT];
         dense_out<L::KSW>(s_w + L::o_b_out * 64, lane, hb, bo);
@@ -350,15 +182,35 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             hin[0][0] = lo; hin[1][0] = hi;
             hin[0][1] = bgeo[0][0]; hin[1][1] = bgeo[1][0];
         }
+        if (SAVE) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                save_rows<false>(args.train, T::rS, so[ct], hin[ct][0]);
+                save_rows<true>(args.train, T::rG, so[ct], hin[ct][1]);
+            }
+        }
         half8 h1[CT][L::KSh], h2[CT][L::KSh];
         f32x16 out_rgb[CT], out_sem[CT];
+        auto save_hidden = [&](const half8 (&a)[CT][L::KSh], int row0, int mblk) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int k = 0; k < L::KSh; ++k) {
+                    save_rows<true>(args.train, row0 + 16 * k, so[ct], a[ct][k]);
+                    mdump[((mblk + k) * CT + ct) * 64] = a[ct][k];
+                }
+        };
         // rgb head (ngp.py:143-156, :202-213)
         dense_relu<L::RTh, 2>(s_w + L::o_h_in * 64, lane, hin, h1);
+        if (SAVE) save_hidden(h1, T::rHH1, T::mHH1);
         dense_relu<L::RTh, L::KSh>(s_w + L::o_h_hid * 64, lane, h1, h2);
+        if (SAVE) save_hidden(h2, T::rHH2, T::mHH2);
         dense_out<L::KSh>(s_w + L::o_h_out * 64, lane, h2, out_rgb);
         // semantic head (ngp.py:158-169, :215-220)
         dense_relu<L::RTh, 1>(s_w + L::o_s_in * 64, lane, bgeo, h1);
+        if (SAVE) save_hidden(h1, T::rHS1, T::mHS1);
         dense_relu<L::RTh, L::KSh>(s_w + L::o_s_hid * 64, lane, h1, h2);
+        if (SAVE) save_hidden(h2, T::rHS2, T::mHS2);
         dense_out<L::KSh>(s_w + L::o_s_out * 64, lane, h2, out_sem);
 
         // ---- write out ----
@@ -506,8 +358,9 @@ static std::vector<int32_t> build_frag_table(const mnf_field_config &cfg) {
 }
 
 template <int W, int NH>
-static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, int grid, hipStream_t stream) {
+static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, int grid, hipStream_t stream, const TrainBuf *train) {
     KernelArgs a;
+    a.train = train ? *train : TrainBuf{nullptr, nullptr, 0};
     a.table = reinterpret_cast<const half4 *>(f->d_table);
     a.frags = reinterpret_cast<const half8 *>(f->d_frags);
     std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));
@@ -515,7 +368,9 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     std::memcpy(a.levels, f->levels, sizeof(a.levels));
     a.io = io;
 #define MNF_LAUNCH(MODE, DO) hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO>), dim3(grid), dim3(kThreads), 0, stream, a)
-    if (density_only) {
+    if (train) {
+        hipLaunchKernelGGL((field_kernel<W, NH, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    } else if (density_only) {
         if (io.mode == 0) MNF_LAUNCH(0, true); else if (io.mode == 1) MNF_LAUNCH(1, true); else MNF_LAUNCH(2, true);
     } else {
         if (io.mode == 0) MNF_LAUNCH(0, false); else if (io.mode == 1) MNF_LAUNCH(1, false); else MNF_LAUNCH(2, false);
@@ -524,7 +379,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     return launch_status("field_kernel");
 }
 
-int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream) {
+int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train) {
     MNF_REQUIRE(f && f->params_loaded, "field: parameters not loaded (call mnf_field_set_params first)");
     int grid = 256;  // one persistent workgroup per CU (LDS-limited), grid-stride over 64-sample tiles
     if (io.mode != 2) {
@@ -534,7 +389,7 @@ int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_
         if (wgs < grid) grid = (int)wgs;
     }
     const int W = f->cfg.neurons, NH = f->cfg.layers;
-#define MNF_CASE(w, nh) if (W == w && NH == nh) return launch_variant<w, nh>(f, io, density_only, grid, stream)
+#define MNF_CASE(w, nh) if (W == w && NH == nh) return launch_variant<w, nh>(f, io, density_only, grid, stream, train)
 #ifdef MNF_DEV_ONLY_128x2
     MNF_CASE(128, 2);
 #else
@@ -570,6 +425,7 @@ extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
     std::vector<int32_t> table = build_frag_table(*cfg);
     f->shape = {W, NH, Wh, cfg->num_semantic_classes, (int)(table.size() / 512)};
     f->d_table = nullptr; f->d_frags = nullptr; f->d_frag_src = nullptr; f->params_loaded = false;
+    f->master[0] = f->master[1] = f->master[2] = nullptr; f->train_state = nullptr;
     hipError_t e = hipMalloc(&f->d_table, (size_t)f->table_entries * 4 * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc(&f->d_frags, table.size() * sizeof(uint16_t) + sizeof(LevelMeta) * 16);
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_frag_src, table.size() * sizeof(int32_t));
@@ -586,6 +442,7 @@ extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
 
 extern "C" int mnf_field_destroy(mnf_field_t f) {
     if (!f) return MNF_OK;
+    free_train_state(f);
     if (f->d_table) (void)hipFree(f->d_table);
     if (f->d_frags) (void)hipFree(f->d_frags);
     if (f->d_frag_src) (void)hipFree(f->d_frag_src);
@@ -624,6 +481,7 @@ extern "C" int mnf_field_set_params(mnf_field_t f, const float *mlp_base, const 
     rc = launch_status("gather_frags_kernel");
     if (rc) return rc;
     f->params_loaded = true;
+    f->master[0] = mlp_base; f->master[1] = mlp_head; f->master[2] = mlp_sem;
     return MNF_OK;
 }
 

@@ -1,0 +1,276 @@
+// Device-side building blocks of the fused field kernels (inference: field.hip, training: train.hip):
+// fp16 vector types, fragment-block bookkeeping, MFMA layer helpers, the lane<->lane+32 half exchange,
+// hash-level index math and degree-4 spherical harmonics.  See the header of field.hip for the data flow.
+#pragma once
+#include "field.h"
+
+namespace mnf {
+
+typedef _Float16 half_t;
+typedef _Float16 half2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CT = 2;                            // 32-sample column tiles per wave (lane = sample, 64 samples per wave)
+constexpr int kWavesPerBlock = 8;                // 512 samples per workgroup pass, two waves per SIMD
+constexpr int kThreads = kWavesPerBlock * 64;
+constexpr int kWaveSamples = 32 * CT;
+
+// ------------------------------------------------------------------ fragment block bookkeeping
+template <int W, int NH>
+struct Layout {
+    static constexpr int Wh = W / 2;
+    static constexpr int RT = W / 32;     // row tiles of a base hidden layer
+    static constexpr int RTh = Wh / 32;   // row tiles of a head hidden layer
+    static constexpr int KSW = W / 16;    // k-steps over a W-wide activation
+    static constexpr int KSh = Wh / 16;
+    static constexpr int o_b_in = 0;
+    static constexpr int o_b_hid = o_b_in + RT * 4;
+    static constexpr int o_b_out = o_b_hid + (NH - 1) * RT * KSW;
+    static constexpr int o_h_in = o_b_out + KSW;
+    static constexpr int o_h_hid = o_h_in + RTh * 2;
+    static constexpr int o_h_out = o_h_hid + RTh * KSh;
+    static constexpr int o_s_in = o_h_out + KSh;
+    static constexpr int o_s_hid = o_s_in + RTh * 1;
+    static constexpr int o_s_out = o_s_hid + RTh * KSh;
+    static constexpr int blocks = o_s_out + KSh;
+};
+
+// Training-time activation storage.  Two views of the same values:
+//  * `act`: feature-major fp16 matrix ACT[row][Np] (Np = samples rounded up to 64) — every row is one feature
+//    over all samples, so the weight-gradient GEMM reads its MFMA operands (8 consecutive samples of one
+//    feature) as plain 16-byte loads;
+//  * `masks`: the post-ReLU hidden activations dumped as the half8 B fragments they already are
+//    ([tile][block][ct][lane]), which line up register-for-register with the accumulators of the backward chain.
+template <int W, int NH>
+struct TrainLayout {
+    static constexpr int Wh = W / 2;
+    static constexpr int KSW = W / 16, KSh = Wh / 16;
+    // forward rows
+    static constexpr int rX = 0;
+    static constexpr int rH0 = 64;                    // H(l) = rH0 + l*W, l = 0..NH-1
+    static constexpr int rS = rH0 + NH * W;           // SH (16) then geo fragment (16): contiguous = head input
+    static constexpr int rG = rS + 16;
+    static constexpr int rHH1 = rG + 16, rHH2 = rHH1 + Wh, rHS1 = rHH2 + Wh, rHS2 = rHS1 + Wh;
+    static constexpr int fwd_rows = rHS2 + Wh;
+    // backward rows (written by the dgrad kernel)
+    static constexpr int rdYr = fwd_rows;             // 16
+    static constexpr int rdZr2 = rdYr + 16, rdZr1 = rdZr2 + Wh;
+    static constexpr int rdYs = rdZr1 + Wh;           // 32
+    static constexpr int rdZs2 = rdYs + 32, rdZs1 = rdZs2 + Wh;
+    static constexpr int rdBO = rdZs1 + Wh;           // 16
+    static constexpr int rdZ0 = rdBO + 16;            // dZ(l) = rdZ0 + l*W, l = 0..NH-1
+    static constexpr int rows = rdZ0 + NH * W;
+    // mask blocks per tile
+    static constexpr int mH0 = 0;                     // H(l): mH0 + l*KSW
+    static constexpr int mHH1 = NH * KSW, mHH2 = mHH1 + KSh, mHS1 = mHH2 + KSh, mHS2 = mHS1 + KSh;
+    static constexpr int mask_blocks = mHS2 + KSh;
+};
+
+struct TrainBuf {
+    half_t *act;      // [rows][Np]
+    half8 *masks;     // [tiles][mask_blocks][CT][64]
+    int64_t Np;
+};
+
+struct KernelArgs {
+    const half4 *table;
+    const half8 *frags;
+    float aabb[6];
+    int C;
+    LevelMeta levels[16];   // wave-uniform: read with scalar loads
+    FieldIO io;
+    TrainBuf train;
+};
+
+// feature index of element j of lane half h inside a 16-wide k-step, by fragment kind
+__device__ __forceinline__ int feat_natural(int h, int j) { return 8 * h + j; }
+__device__ __forceinline__ int feat_acc(int h, int j) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// Store one B fragment feature-major: ACT[row0 + feat(h, j)][col] = frag[j].  The row term that does not depend on
+// the lane (row0 + 8*(j>>2) + (j&3), or row0 + j) is folded into a scalar base; the lane-dependent part
+// (column, and the 4h / 8h row offset of the lane half) is one 32-bit byte offset per lane, so every store is
+// `global_store_short v_off, v_data, s[base]` with no 64-bit VGPR address.
+struct SaveOff {
+    uint32_t acc, nat;   // byte offsets for accumulator-order and natural-order fragments
+};
+__device__ __forceinline__ SaveOff save_offsets(const TrainBuf &tb, int h, int64_t col) {
+    SaveOff o;
+    o.acc = (uint32_t)((col + (int64_t)4 * h * tb.Np) * 2);
+    o.nat = (uint32_t)((col + (int64_t)8 * h * tb.Np) * 2);
+    return o;
+}
+template <bool ACC_ORDER>
+__device__ __forceinline__ void save_rows(const TrainBuf &tb, int row0, const SaveOff &so, const half8 &frag) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int srow = row0 + (ACC_ORDER ? 8 * (j >> 2) + (j & 3) : j);   // uniform part of the row
+        char *base = reinterpret_cast<char *>(tb.act) + (int64_t)srow * tb.Np * 2;
+        *reinterpret_cast<half_t *>(base + (ACC_ORDER ? so.acc : so.nat)) = frag[j];
+    }
+}
+
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// relu(round_to_fp16(x)) == round_to_fp16(relu(x)) (rounding is monotonic and sign-preserving), so pack first
+// (v_cvt_pk_f16_f32, two values per instruction) and clamp in packed fp16 (v_pk_max_f16).
+__device__ __forceinline__ half8 relu_pack8(const f32x16 &acc, int s) {
+    half8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        half2 p = {(half_t)acc[8 * s + j], (half_t)acc[8 * s + j + 1]};
+        const half2 z = {(half_t)0.0f, (half_t)0.0f};
+        p = __builtin_elementwise_max(p, z);
+        r[j] = p[0]; r[j + 1] = p[1];
+    }
+    return r;
+}
+
+// One hidden layer, fused with ReLU + fp16 packing, one 32-row output tile at a time so that only
+// CT accumulator tiles are live: o[ct][2*rt + s] <- relu(W(rt,:) * b[ct])
+template <int RT_OUT, int KS>
+__device__ __forceinline__ void dense_relu(const half8 *__restrict__ w_lds, int lane, const half8 (&b)[CT][KS],
+                                           half8 (&o)[CT][RT_OUT * 2]) {
+#pragma unroll
+    for (int rt = 0; rt < RT_OUT; ++rt) {
+        f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 a = w_lds[(rt * KS + ks) * 64 + lane];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma(a, b[ct][ks], acc[ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) o[ct][rt * 2 + s] = relu_pack8(acc[ct], s);
+    }
+}
+
+// Output layer (one 32-row tile, no activation)
+template <int KS>
+__device__ __forceinline__ void dense_out(const half8 *__restrict__ w_lds, int lane, const half8 (&b)[CT][KS], f32x16 (&o)[CT]) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[ct][i] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const half8 a = w_lds[ks * 64 + lane];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) o[ct] = mfma(a, b[ct][ks], o[ct]);
+    }
+}
+
+// Lane l (sample A = column l of tile 0) and lane l+32 (sample B = column l of tile 1) each hold all 16
+// features of a k-step of THEIR sample as lo = features 0..7, hi = features 8..15.  The MFMA B operand wants,
+// for tile t, lane half h to hold features 8h..8h+7 of the tile-t sample.  One v_permlane32_swap per dword
+// (lo's upper 32 lanes <-> hi's lower 32 lanes) produces exactly that: lo -> tile-0 fragment, hi -> tile-1 fragment.
+__device__ __forceinline__ void exchange_halves(half8 &lo, half8 &hi) {
+    u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(a[i], b[i], false, false);
+        a[i] = r[0]; b[i] = r[1];
+    }
+    lo = __builtin_bit_cast(half8, a); hi = __builtin_bit_cast(half8, b);
+}
+
+// One hash level (wave-uniform metadata) for the lane's sample, split in two so that the gathers of several
+// levels can be in flight together: hash_prep computes the 8 byte offsets and the separable trilinear weights,
+// hash_blend consumes the 8 loaded entries.  The blend weight of corner (bx,by,bz) is ((wx*wy)*wz), the same
+// association as the oracle's running product.
+struct LevelPrep {
+    uint32_t off[8];
+    float wxy[4], wz[2];
+};
+
+__device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], LevelPrep &o) {
+    float frac[3];
+    uint32_t cell[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float pos = __builtin_fmaf(m.scale, xn[d], 0.5f);
+        const float fl = floorf(pos);
+        frac[d] = pos - fl;
+        cell[d] = (uint32_t)(int32_t)fl;
+    }
+    const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]};
+    o.wz[0] = 1.0f - frac[2]; o.wz[1] = frac[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.wxy[k] = (1.0f * wx[k & 1]) * wy[k >> 1];
+    uint32_t ty[2], tz[2];   // per-axis terms, shared by the four corners that use them
+    if (m.hashed) {          // uniform branch; size is 2^k when hashed
+        ty[0] = cell[1] * 2654435761u; ty[1] = (cell[1] + 1u) * 2654435761u;
+        tz[0] = cell[2] * 805459861u;  tz[1] = (cell[2] + 1u) * 805459861u;
+    } else {
+        ty[0] = cell[1] * m.res; ty[1] = ty[0] + m.res;
+        const uint32_t r2 = m.res * m.res;
+        tz[0] = cell[2] * r2; tz[1] = tz[0] + r2;
+    }
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const uint32_t px = cell[0] + (uint32_t)(corner & 1);
+        uint32_t idx;
+        if (m.hashed) {
+            idx = (px ^ ty[(corner >> 1) & 1] ^ tz[corner >> 2]) & (m.size - 1u);
+        } else {
+            idx = px + ty[(corner >> 1) & 1] + tz[corner >> 2];
+            if (idx >= m.size) idx %= m.size;   // only out-of-box positions / the far corner
+        }
+        o.off[corner] = (m.offset + idx) * 8u;   // 32-bit byte offset from the uniform table base (SGPR base + VGPR offset)
+    }
+}
+
+__device__ __forceinline__ void hash_load(const half4 *__restrict__ table, const LevelPrep &p, half4 (&v)[8]) {
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner)
+        v[corner] = *reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + p.off[corner]);
+}
+
+__device__ __forceinline__ void hash_blend(const LevelPrep &p, const half4 (&v)[8], float *f) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
+        a0 += w * (float)v[corner][0]; a1 += w * (float)v[corner][1];
+        a2 += w * (float)v[corner][2]; a3 += w * (float)v[corner][3];
+    }
+    f[0] = a0; f[1] = a1; f[2] = a2; f[3] = a3;
+}
+
+// tcnn SphericalHarmonics degree 4 on 2u-1, u = (d+1)/2 (ngp.py:205): all 16 values of the lane's sample
+__device__ __forceinline__ void sh4(const float d[3], half8 &lo, half8 &hi) {
+    const float x = ((d[0] + 1.0f) / 2.0f) * 2.0f - 1.0f;
+    const float y = ((d[1] + 1.0f) / 2.0f) * 2.0f - 1.0f;
+    const float z = ((d[2] + 1.0f) / 2.0f) * 2.0f - 1.0f;
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    lo[0] = (half_t)0.28209479177387814f;
+    lo[1] = (half_t)(-0.48860251190291987f * y);
+    lo[2] = (half_t)(0.48860251190291987f * z);
+    lo[3] = (half_t)(-0.48860251190291987f * x);
+    lo[4] = (half_t)(1.0925484305920792f * xy);
+    lo[5] = (half_t)(-1.0925484305920792f * yz);
+    lo[6] = (half_t)(0.94617469575755997f * z2 - 0.31539156525251999f);
+    lo[7] = (half_t)(-1.0925484305920792f * xz);
+    hi[0] = (half_t)(0.54627421529603959f * x2 - 0.54627421529603959f * y2);
+    hi[1] = (half_t)(0.59004358992664352f * y * (-3.0f * x2 + y2));
+    hi[2] = (half_t)(2.8906114426405538f * xy * z);
+    hi[3] = (half_t)(0.45704579946446572f * y * (1.0f - 5.0f * z2));
+    hi[4] = (half_t)(0.3731763325901154f * z * (5.0f * z2 - 3.0f));
+    hi[5] = (half_t)(0.45704579946446572f * x * (1.0f - 5.0f * z2));
+    hi[6] = (half_t)(1.4453057213202769f * z * (x2 - y2));
+    hi[7] = (half_t)(0.59004358992664352f * x * (-x2 + 3.0f * y2));
+}
+
+}  // namespace mnf

@@ -1,0 +1,532 @@
+// Backward pass of the radiance field (the tiny-cuda-nn backward the reference reaches through
+// `loss.backward()`, scripts/pipeline.py:518; forward call sites perception/models/radiance_fields/ngp.py:171-238):
+//
+//   dgrad_kernel   dL/d(rgb, sigma, sem) per sample -> pre-activation gradients of every layer (kept in MFMA
+//                  registers from layer to layer exactly like the forward chain, with the TRANSPOSED weight
+//                  fragments as the A operand), stored feature-major for the weight-gradient GEMMs, and
+//                  dL/d(hash features) per sample.
+//   wgrad_kernel   dW[n][k] = sum_samples dOut^T[n][c] * In^T[k][c]: the contraction runs over samples, and with
+//                  feature-major fp16 activations both MFMA operands are plain 16-byte loads; split over sample
+//                  chunks, fp32 atomics into the flat parameter-gradient vectors.
+//   hash_bwd_kernel  trilinear scatter of dL/d(features) into the dense fp32 table gradient (float atomics).
+//
+// Gradients of activations travel in fp16 scaled by `loss_scale` (tcnn does the same with its default scale of
+// 128); parameter gradients are accumulated and returned in fp32, un-scaled.
+#include <cstring>
+#include <vector>
+
+#include "field_dev.h"
+
+namespace mnf {
+
+// ------------------------------------------------------------------ transposed-fragment bookkeeping
+template <int W, int NH>
+struct LayoutT {
+    static constexpr int Wh = W / 2, RT = W / 32, RTh = Wh / 32, KSW = W / 16, KSh = Wh / 16;
+    static constexpr int o_r3 = 0;                         // rgb head out^T : RTh x 1
+    static constexpr int o_r2 = o_r3 + RTh * 1;            // rgb head hid^T : RTh x KSh
+    static constexpr int o_r1 = o_r2 + RTh * KSh;          // rgb head in^T (geo rows) : 1 x KSh
+    static constexpr int o_s3 = o_r1 + KSh;                // sem head out^T : RTh x 2
+    static constexpr int o_s2 = o_s3 + RTh * 2;
+    static constexpr int o_s1 = o_s2 + RTh * KSh;
+    static constexpr int o_bo = o_s1 + KSh;                // base out^T : RT x 1
+    static constexpr int o_bh = o_bo + RT * 1;             // base hidden^T l : RT x KSW each, l = 0..NH-2
+    static constexpr int o_b1 = o_bh + (NH - 1) * RT * KSW;  // base in^T : 2 x KSW
+    static constexpr int blocks = o_b1 + 2 * KSW;
+};
+
+struct BwdArgs {
+    const half8 *fragsT;
+    const float *d_rgb, *d_sigma, *d_sem;   // [N,3], [N], [N,C]
+    const float *rgb, *sigma;               // forward outputs [N,3], [N]
+    float *dX;                              // [Np][16][4] fp32, un-scaled
+    int64_t n;
+    int C;
+    float loss_scale;
+    TrainBuf train;
+};
+
+// acc[ct] = sum_ks A(rt, ks) * b[ct][ks] for one 32-row tile
+template <int KS>
+__device__ __forceinline__ void dense_tile(const half8 *__restrict__ w_lds, int lane, const half8 (&b)[CT][KS], f32x16 (&acc)[CT]) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ct][i] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const half8 a = w_lds[ks * 64 + lane];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma(a, b[ct][ks], acc[ct]);
+    }
+}
+
+// One backward layer through a ReLU: dz[ct][2rt+s] = pack(W^T(rt,:) * dOut[ct]) masked by the saved activation,
+// stored feature-major at row0 for the weight gradient.
+template <int RT_OUT, int KS>
+__device__ __forceinline__ void dense_mask(const half8 *__restrict__ w_lds, int lane, int h, const half8 (&b)[CT][KS],
+                                           const half8 *__restrict__ masks, const TrainBuf &tb, int row0, const SaveOff (&so)[CT],
+                                           half8 (&o)[CT][RT_OUT * 2]) {
+#pragma unroll
+    for (int rt = 0; rt < RT_OUT; ++rt) {
+        f32x16 acc[CT];
+        dense_tile<KS>(w_lds + rt * KS * 64, lane, b, acc);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const half8 m = masks[((rt * 2 + s) * CT + ct) * 64];
+                half8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (m[j] != (half_t)0.0f) ? (half_t)acc[ct][8 * s + j] : (half_t)0.0f;
+                o[ct][rt * 2 + s] = v;
+                save_rows<true>(tb, row0 + 16 * (rt * 2 + s), so[ct], v);
+            }
+        __builtin_amdgcn_sched_barrier(0);   // keep the row-tile iterations from interleaving (register pressure)
+    }
+}
+
+template <int W, int NH>
+__global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) {
+    using L = LayoutT<W, NH>;
+    using T = TrainLayout<W, NH>;
+    __shared__ half8 s_w[L::blocks * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+    const int64_t n = args.n;
+    const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
+    if ((int64_t)blockIdx.x * kWavesPerBlock >= n_tiles) return;
+    for (int i = threadIdx.x; i < L::blocks * 64; i += kThreads) s_w[i] = args.fragsT[i];
+    __syncthreads();
+    const float ls = args.loss_scale;
+
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t fcol0 = tile * kWaveSamples + c;
+        SaveOff so[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(args.train, h, fcol0 + 32 * ct);
+        const half8 *mdump = args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane;
+        // ---- output-layer gradients, built directly as natural-order B fragments ----
+        half8 dyr[CT][1], dys[CT][2];
+        float dlogit[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int64_t col = fcol0 + 32 * ct;
+            const bool ok = col < n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dyr[ct][0][j] = (half_t)0.0f;
+            if (ok && h == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float y = args.rgb[3 * col + k];
+                    dyr[ct][0][k] = (half_t)(args.d_rgb[3 * col + k] * y * (1.0f - y) * ls);   // sigmoid'
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int row = 16 * s + 8 * h + j;
+                    dys[ct][s][j] = (ok && row < args.C) ? (half_t)(args.d_sem[col * args.C + row] * ls) : (half_t)0.0f;
+                }
+            // trunc_exp backward (ngp.py:34-39): g * exp(min(x, 15)) with exp(x) = sigma (0 outside the aabb)
+            dlogit[ct] = ok ? args.d_sigma[col] * fminf(args.sigma[col], 3269017.3724721107f) * ls : 0.0f;
+            save_rows<false>(args.train, T::rdYr, so[ct], dyr[ct][0]);
+            save_rows<false>(args.train, T::rdYs, so[ct], dys[ct][0]);
+            save_rows<false>(args.train, T::rdYs + 16, so[ct], dys[ct][1]);
+        }
+        // ---- heads ----
+        half8 dz2[CT][L::KSh], dz1[CT][L::KSh];
+        f32x16 dgeo_r[CT], dgeo_s[CT];
+        dense_mask<L::RTh, 1>(s_w + L::o_r3 * 64, lane, h, dyr, mdump + T::mHH2 * CT * 64, args.train, T::rdZr2, so, dz2);
+        dense_mask<L::RTh, L::KSh>(s_w + L::o_r2 * 64, lane, h, dz2, mdump + T::mHH1 * CT * 64, args.train, T::rdZr1, so, dz1);
+        dense_tile<L::KSh>(s_w + L::o_r1 * 64, lane, dz1, dgeo_r);
+        dense_mask<L::RTh, 2>(s_w + L::o_s3 * 64, lane, h, dys, mdump + T::mHS2 * CT * 64, args.train, T::rdZs2, so, dz2);
+        dense_mask<L::RTh, L::KSh>(s_w + L::o_s2 * 64, lane, h, dz2, mdump + T::mHS1 * CT * 64, args.train, T::rdZs1, so, dz1);
+        dense_tile<L::KSh>(s_w + L::o_s1 * 64, lane, dz1, dgeo_s);
+        // ---- base output gradient: geo rows from both heads, row 0 = density logit ----
+        half8 dbo[CT][1];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dbo[ct][0][j] = (half_t)(dgeo_r[ct][j] + dgeo_s[ct][j]);
+            if (h == 0) dbo[ct][0][0] = (half_t)dlogit[ct];
+            save_rows<true>(args.train, T::rdBO, so[ct], dbo[ct][0]);
+        }
+        // ---- base MLP ----
+        half8 dz[CT][L::KSW];
+        dense_mask<L::RT, 1>(s_w + L::o_bo * 64, lane, h, dbo, mdump + (T::mH0 + (NH - 1) * L::KSW) * CT * 64, args.train,
+                             T::rdZ0 + (NH - 1) * W, so, dz);
+#pragma unroll
+        for (int l = NH - 2; l >= 0; --l) {
+            half8 dn[CT][L::KSW];
+            dense_mask<L::RT, L::KSW>(s_w + (L::o_bh + l * L::RT * L::KSW) * 64, lane, h, dz, mdump + (T::mH0 + l * L::KSW) * CT * 64,
+                                      args.train, T::rdZ0 + l * W, so, dn);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int k = 0; k < L::KSW; ++k) dz[ct][k] = dn[ct][k];
+        }
+        // ---- gradient of the 64 hash features: rows 32rt + 8g + 4h + i == level (8rt + 2g + h), feature i ----
+        const float inv = 1.0f / ls;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x16 acc[CT];
+            dense_tile<L::KSW>(s_w + (L::o_b1 + rt * L::KSW) * 64, lane, dz, acc);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                float4 *dst = reinterpret_cast<float4 *>(args.dX + (fcol0 + 32 * ct) * 64);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v = {acc[ct][4 * g] * inv, acc[ct][4 * g + 1] * inv, acc[ct][4 * g + 2] * inv, acc[ct][4 * g + 3] * inv};
+                    dst[8 * rt + 2 * g + h] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight gradients
+struct WgradJob {
+    int32_t dout_row0, in_row0;   // rows of ACT
+    int32_t buf;                  // 0 base, 1 head, 2 sem
+    int32_t param_off, stride;    // dW[n][k] lands at param_off + n*stride + colmap[k]
+    int32_t n_valid;              // rows of this 32-row tile that exist in the parameter matrix
+    int32_t n0;
+    int32_t colmap[32];           // parameter column of in-row k of this tile, -1 = none
+};
+
+// one wave = one (job, sample chunk): D[32][32] += dOut^T[32][16 samples] * In^T[16 samples][32]
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__ jobs, int n_jobs, int split, const half_t *__restrict__ act,
+                                                    int64_t Np, float inv_scale, float *g0, float *g1, float *g2) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= n_jobs * split) return;
+    const WgradJob &jb = jobs[wid / split];
+    const int part = wid % split;
+    const int64_t steps = Np / 16;
+    const int64_t s0 = steps * part / split, s1 = steps * (part + 1) / split;
+    const int r = lane & 31, h = lane >> 5;
+    const half_t *pa = act + (int64_t)(jb.dout_row0 + r) * Np + 8 * h;
+    const half_t *pb = act + (int64_t)(jb.in_row0 + r) * Np + 8 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll 4
+    for (int64_t s = s0; s < s1; ++s) {
+        const half8 a = *reinterpret_cast<const half8 *>(pa + 16 * s);
+        const half8 b = *reinterpret_cast<const half8 *>(pb + 16 * s);
+        acc = mfma(a, b, acc);
+    }
+    float *g = jb.buf == 0 ? g0 : (jb.buf == 1 ? g1 : g2);
+    const int col = jb.colmap[r];
+    if (col < 0) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (row < jb.n_valid) atomicAdd(g + jb.param_off + (int64_t)(jb.n0 + row) * jb.stride + col, acc[i] * inv_scale);
+    }
+}
+
+// ------------------------------------------------------------------ hash-grid gradient scatter
+struct HashBwdArgs {
+    const float *positions;
+    const float *dX;      // [Np][16][4]
+    float *g_table;       // fp32 [entries][4]
+    int64_t n;
+    float aabb[6];
+    LevelMeta levels[16];
+};
+
+__global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= args.n) return;
+    float xn[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) xn[d] = (args.positions[3 * i + d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);
+#pragma unroll 1
+    for (int l = 0; l < 16; ++l) {
+        LevelPrep p;
+        hash_prep(args.levels[l], xn, p);
+        const float4 g = reinterpret_cast<const float4 *>(args.dX + i * 64)[l];
+        if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
+            float *dst = args.g_table + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
+            atomicAdd(dst + 0, w * g.x); atomicAdd(dst + 1, w * g.y); atomicAdd(dst + 2, w * g.z); atomicAdd(dst + 3, w * g.w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side: transposed fragments and job table
+enum KMapT { T_NATURAL, T_ACC };
+enum ColMap { C_IDENT, C_GEO_RGB, C_GEO_SEM };
+
+static int colmap(ColMap m, int i, int n_in_real) {
+    if (m == C_IDENT) return i < n_in_real ? i : -1;
+    if (i >= 16) return -1;
+    if (m == C_GEO_RGB) return i == 0 ? 31 : 15 + i;
+    return i == 0 ? 15 : i - 1;
+}
+
+// blocks of W^T for one matrix W[n_out][stride]: rows = input features (row_tiles x 32), K = output index n
+static void append_matrix_T(std::vector<int32_t> &t, int buf, int64_t off, int n_out_real, int stride, int n_in_real,
+                            int row_tiles, ColMap cm, KMapT km, int n_ksteps) {
+    for (int rt = 0; rt < row_tiles; ++rt)
+        for (int ks = 0; ks < n_ksteps; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int r = lane & 31, h = lane >> 5;
+                    const int col = colmap(cm, 32 * rt + r, n_in_real);
+                    const int n = 16 * ks + (km == T_NATURAL ? 8 * h + j : 8 * (j >> 2) + 4 * h + (j & 3));
+                    int32_t v = -1;
+                    if (col >= 0 && n < n_out_real) v = (int32_t)((buf << 28) | (int32_t)(off + (int64_t)n * stride + col));
+                    t.push_back(v);
+                }
+}
+
+struct TrainTables {
+    std::vector<int32_t> fragT;
+    std::vector<WgradJob> jobs;
+    int rows, mask_blocks;
+};
+
+static void add_jobs(std::vector<WgradJob> &jobs, int buf, int64_t off, int n_out_real, int stride, int n_in_real,
+                     int dout_row0, int n_out_tiles, int in_row0, int n_in_tiles, ColMap cm) {
+    for (int ot = 0; ot < n_out_tiles; ++ot)
+        for (int it = 0; it < n_in_tiles; ++it) {
+            WgradJob j;
+            j.dout_row0 = dout_row0 + 32 * ot; j.in_row0 = in_row0 + 32 * it; j.buf = buf; j.param_off = (int32_t)off; j.stride = stride;
+            j.n0 = 32 * ot;
+            j.n_valid = n_out_real - 32 * ot < 32 ? n_out_real - 32 * ot : 32;
+            if (j.n_valid < 0) j.n_valid = 0;
+            for (int k = 0; k < 32; ++k) j.colmap[k] = colmap(cm, 32 * it + k, n_in_real);
+            jobs.push_back(j);
+        }
+}
+
+template <int W, int NH>
+static TrainTables build_tables(int C) {
+    using T = TrainLayout<W, NH>;
+    constexpr int Wh = W / 2;
+    const int sem_pad = ((C + 15) / 16) * 16;
+    TrainTables tt;
+    tt.rows = T::rows; tt.mask_blocks = T::mask_blocks;
+    // parameter offsets (reference state_dict layout)
+    int64_t b_in = 0, b_hid = (int64_t)W * 64, b_out = b_hid + (int64_t)(NH - 1) * W * W;
+    int64_t h_in = 0, h_hid = (int64_t)Wh * 32, h_out = h_hid + (int64_t)Wh * Wh;
+    int64_t s_in = 0, s_hid = (int64_t)Wh * 16, s_out = s_hid + (int64_t)Wh * Wh;
+    auto &t = tt.fragT;
+    append_matrix_T(t, 1, h_out, 16, Wh, Wh, Wh / 32, C_IDENT, T_NATURAL, 1);          // o_r3
+    append_matrix_T(t, 1, h_hid, Wh, Wh, Wh, Wh / 32, C_IDENT, T_ACC, Wh / 16);         // o_r2
+    append_matrix_T(t, 1, h_in, Wh, 32, 32, 1, C_GEO_RGB, T_ACC, Wh / 16);              // o_r1
+    append_matrix_T(t, 2, s_out, sem_pad, Wh, Wh, Wh / 32, C_IDENT, T_NATURAL, 2);     // o_s3
+    append_matrix_T(t, 2, s_hid, Wh, Wh, Wh, Wh / 32, C_IDENT, T_ACC, Wh / 16);         // o_s2
+    append_matrix_T(t, 2, s_in, Wh, 16, 16, 1, C_GEO_SEM, T_ACC, Wh / 16);              // o_s1
+    append_matrix_T(t, 0, b_out, 16, W, W, W / 32, C_IDENT, T_ACC, 1);                  // o_bo
+    for (int l = 0; l < NH - 1; ++l) append_matrix_T(t, 0, b_hid + (int64_t)l * W * W, W, W, W, W / 32, C_IDENT, T_ACC, W / 16);   // o_bh
+    append_matrix_T(t, 0, b_in, W, 64, 64, 2, C_IDENT, T_ACC, W / 16);                  // o_b1
+    // weight-gradient jobs: (dOut rows, In rows)
+    auto &j = tt.jobs;
+    add_jobs(j, 0, b_in, W, 64, 64, T::rdZ0, W / 32, T::rX, 2, C_IDENT);
+    for (int l = 0; l < NH - 1; ++l)
+        add_jobs(j, 0, b_hid + (int64_t)l * W * W, W, W, W, T::rdZ0 + (l + 1) * W, W / 32, T::rH0 + l * W, W / 32, C_IDENT);
+    add_jobs(j, 0, b_out, 16, W, W, T::rdBO, 1, T::rH0 + (NH - 1) * W, W / 32, C_IDENT);
+    // rgb head: in = [SH(16) | geo fragment(16)] (contiguous rows rS..rS+31): SH rows map to columns 0..15
+    {
+        std::vector<WgradJob> tmp;
+        add_jobs(tmp, 1, h_in, Wh, 32, 32, T::rdZr1, Wh / 32, T::rS, 1, C_IDENT);
+        for (auto &jb : tmp) { for (int k = 0; k < 16; ++k) { jb.colmap[k] = k; jb.colmap[16 + k] = colmap(C_GEO_RGB, k, 32); } j.push_back(jb); }
+    }
+    add_jobs(j, 1, h_hid, Wh, Wh, Wh, T::rdZr2, Wh / 32, T::rHH1, Wh / 32, C_IDENT);
+    add_jobs(j, 1, h_out, 16, Wh, Wh, T::rdYr, 1, T::rHH2, Wh / 32, C_IDENT);
+    add_jobs(j, 2, s_in, Wh, 16, 16, T::rdZs1, Wh / 32, T::rG, 1, C_GEO_SEM);
+    add_jobs(j, 2, s_hid, Wh, Wh, Wh, T::rdZs2, Wh / 32, T::rHS1, Wh / 32, C_IDENT);
+    add_jobs(j, 2, s_out, sem_pad, Wh, Wh, T::rdYs, 1, T::rHS2, Wh / 32, C_IDENT);
+    return tt;
+}
+
+static bool tables_for(int W, int NH, int C, TrainTables &tt) {
+#define MNF_CASE(w, nh) if (W == w && NH == nh) { tt = build_tables<w, nh>(C); return true; }
+#ifdef MNF_DEV_ONLY_128x2
+    MNF_CASE(128, 2)
+#else
+    MNF_CASE(128, 1) MNF_CASE(128, 2) MNF_CASE(128, 3) MNF_CASE(128, 4)
+    MNF_CASE(64, 1) MNF_CASE(64, 2) MNF_CASE(64, 3) MNF_CASE(64, 4)
+#endif
+#undef MNF_CASE
+    return false;
+}
+
+__global__ void __launch_bounds__(256) gather_fragsT_kernel(const int32_t *__restrict__ src_idx, const float *__restrict__ p0,
+                                                            const float *__restrict__ p1, const float *__restrict__ p2,
+                                                            half_t *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t s = src_idx[i];
+    float v = 0.0f;
+    if (s >= 0) {
+        const int buf = s >> 28, idx = s & 0x0FFFFFFF;
+        v = buf == 0 ? p0[idx] : (buf == 1 ? p1[idx] : p2[idx]);
+    }
+    dst[i] = (half_t)v;
+}
+
+struct TrainState {
+    TrainTables tt;
+    int32_t *d_fragT_src = nullptr;
+    half_t *d_fragT = nullptr;
+    WgradJob *d_jobs = nullptr;
+};
+
+static int ensure_train_state(mnf_field_t f) {
+    if (f->train_state) return MNF_OK;
+    TrainState *ts = new TrainState();
+    if (!tables_for(f->cfg.neurons, f->cfg.layers, f->cfg.num_semantic_classes, ts->tt)) {
+        delete ts;
+        set_error("train: unsupported neurons=%d layers=%d", f->cfg.neurons, f->cfg.layers);
+        return MNF_ERR_UNSUPPORTED;
+    }
+    hipError_t e = hipMalloc((void **)&ts->d_fragT_src, ts->tt.fragT.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ts->d_fragT, ts->tt.fragT.size() * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ts->d_jobs, ts->tt.jobs.size() * sizeof(WgradJob));
+    if (e == hipSuccess) e = hipMemcpy(ts->d_fragT_src, ts->tt.fragT.data(), ts->tt.fragT.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ts->d_jobs, ts->tt.jobs.data(), ts->tt.jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("train: %s", hipGetErrorString(e));
+        delete ts;
+        return MNF_ERR_HIP;
+    }
+    f->train_state = ts;
+    return MNF_OK;
+}
+
+void free_train_state(mnf_field_t f) {
+    TrainState *ts = reinterpret_cast<TrainState *>(f->train_state);
+    if (!ts) return;
+    if (ts->d_fragT_src) (void)hipFree(ts->d_fragT_src);
+    if (ts->d_fragT) (void)hipFree(ts->d_fragT);
+    if (ts->d_jobs) (void)hipFree(ts->d_jobs);
+    delete ts;
+    f->train_state = nullptr;
+}
+
+struct WsView {
+    half_t *act; half8 *masks; float *dX;
+    int64_t Np, bytes;
+};
+
+static WsView carve_train(const TrainTables &tt, void *base, int64_t n) {
+    WsView v;
+    v.Np = ceil_div(n, 64) * 64;
+    size_t off = 0;
+    auto take = [&](size_t b) { char *p = base ? (char *)base + off : nullptr; off += (b + 255) & ~(size_t)255; return p; };
+    v.act = (half_t *)take((size_t)tt.rows * v.Np * 2);
+    v.masks = (half8 *)take((size_t)(v.Np / 64) * tt.mask_blocks * CT * 64 * 16);
+    v.dX = (float *)take((size_t)v.Np * 64 * 4);
+    v.bytes = (int64_t)off;
+    return v;
+}
+
+template <int W, int NH>
+static void launch_dgrad(const BwdArgs &a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((dgrad_kernel<W, NH>), dim3(grid), dim3(kThreads), 0, s, a);
+}
+
+}  // namespace mnf
+
+using namespace mnf;
+
+extern "C" int64_t mnf_field_train_workspace_bytes(mnf_field_t f, int64_t n) {
+    if (!f || n < 0) return -1;
+    TrainTables tt;
+    if (!tables_for(f->cfg.neurons, f->cfg.layers, f->cfg.num_semantic_classes, tt)) return -1;
+    return carve_train(tt, nullptr, n).bytes;
+}
+
+extern "C" int mnf_field_forward_train(mnf_field_t f, const float *positions, const float *directions, int64_t n,
+                                       float *rgb, float *density, float *sem, void *workspace, int64_t workspace_bytes,
+                                       mnf_stream_t stream) {
+    MNF_REQUIRE(f && f->params_loaded, "field_forward_train: parameters not loaded");
+    MNF_REQUIRE(n >= 0, "field_forward_train: negative n");
+    if (n == 0) return MNF_OK;
+    MNF_REQUIRE(positions && directions && rgb && density && sem, "field_forward_train: null pointer");
+    int rc = ensure_train_state(f);
+    if (rc) return rc;
+    TrainState *ts = reinterpret_cast<TrainState *>(f->train_state);
+    WsView v = carve_train(ts->tt, workspace, n);
+    if (!workspace || workspace_bytes < v.bytes) {
+        set_error("field_forward_train: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)v.bytes);
+        return MNF_ERR_WORKSPACE;
+    }
+    FieldIO io = {};
+    io.mode = 0; io.positions = positions; io.directions = directions; io.n = n;
+    io.rgb = rgb; io.density = density; io.sem = sem;
+    TrainBuf tb = {v.act, v.masks, v.Np};
+    return launch_field(f, io, false, as_stream(stream), &tb);
+}
+
+extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t n,
+                                  const float *d_rgb, const float *d_density, const float *d_sem,
+                                  const float *rgb, const float *density,
+                                  void *workspace, int64_t workspace_bytes, float loss_scale,
+                                  float *g_base, float *g_head, float *g_sem, mnf_stream_t stream) {
+    MNF_REQUIRE(f && f->params_loaded, "field_backward: parameters not loaded");
+    MNF_REQUIRE(n >= 0 && loss_scale > 0.f, "field_backward: bad arguments");
+    MNF_REQUIRE(g_base && g_head && g_sem, "field_backward: null gradient buffer");
+    hipStream_t s = as_stream(stream);
+    MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));
+    MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
+    MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
+    if (n == 0) return MNF_OK;
+    MNF_REQUIRE(positions && d_rgb && d_density && d_sem && rgb && density, "field_backward: null pointer");
+    int rc = ensure_train_state(f);
+    if (rc) return rc;
+    TrainState *ts = reinterpret_cast<TrainState *>(f->train_state);
+    WsView v = carve_train(ts->tt, workspace, n);
+    if (!workspace || workspace_bytes < v.bytes) {
+        set_error("field_backward: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)v.bytes);
+        return MNF_ERR_WORKSPACE;
+    }
+    // transposed fp16 weight fragments from the current fp32 master parameters (held by the forward's set_params)
+    const int64_t n_frag = (int64_t)ts->tt.fragT.size();
+    hipLaunchKernelGGL(gather_fragsT_kernel, dim3((unsigned)ceil_div(n_frag, 256)), dim3(256), 0, s, ts->d_fragT_src,
+                       f->master[0], f->master[1], f->master[2], ts->d_fragT, n_frag);
+    BwdArgs a;
+    a.fragsT = reinterpret_cast<const half8 *>(ts->d_fragT);
+    a.d_rgb = d_rgb; a.d_sigma = d_density; a.d_sem = d_sem; a.rgb = rgb; a.sigma = density;
+    a.dX = v.dX; a.n = n; a.C = f->cfg.num_semantic_classes; a.loss_scale = loss_scale;
+    a.train = {v.act, v.masks, v.Np};
+    int grid = 256;
+    const int64_t wgs = ceil_div(ceil_div(n, kWaveSamples), kWavesPerBlock);
+    if (wgs < grid) grid = (int)wgs;
+    const int W = f->cfg.neurons, NH = f->cfg.layers;
+    bool ok = false;
+#define MNF_CASE(w, nh) if (W == w && NH == nh) { launch_dgrad<w, nh>(a, grid, s); ok = true; }
+#ifdef MNF_DEV_ONLY_128x2
+    MNF_CASE(128, 2)
+#else
+    MNF_CASE(128, 1) MNF_CASE(128, 2) MNF_CASE(128, 3) MNF_CASE(128, 4)
+    MNF_CASE(64, 1) MNF_CASE(64, 2) MNF_CASE(64, 3) MNF_CASE(64, 4)
+#endif
+#undef MNF_CASE
+    MNF_REQUIRE(ok, "field_backward: unsupported shape");
+    rc = launch_status("dgrad_kernel");
+    if (rc) return rc;
+    // weight gradients
+    const int n_jobs = (int)ts->tt.jobs.size();
+    int split = (int)(v.Np / 16 / 64);   // >= 64 MFMA steps per wave
+    if (split < 1) split = 1;
+    if (split > 64) split = 64;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_jobs * split, 4)), dim3(256), 0, s, ts->d_jobs, n_jobs, split,
+                       v.act, v.Np, 1.0f / loss_scale, g_base, g_head, g_sem);
+    rc = launch_status("wgrad_kernel");
+    if (rc) return rc;
+    // hash-table gradient
+    HashBwdArgs hb;
+    hb.positions = positions; hb.dX = v.dX; hb.g_table = g_base + f->n_base_mlp; hb.n = n;
+    std::memcpy(hb.aabb, f->cfg.aabb, sizeof(hb.aabb));
+    std::memcpy(hb.levels, f->levels, sizeof(hb.levels));
+    hipLaunchKernelGGL(hash_bwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, hb);
+    return launch_status("hash_bwd_kernel");
+}

@@ -35,6 +35,48 @@ def _xavier_uniform_(flat: torch.Tensor, shapes, gen: torch.Generator):
     return k
 
 
+class _FieldFunction(torch.autograd.Function):
+    """Differentiable field evaluation: what `loss.backward()` reaches inside tiny-cuda-nn in the reference
+    (scripts/pipeline.py:518).  Forward keeps the activations in a workspace; backward returns dL/d(params) for the
+    three flat parameter vectors (positions and directions get no gradient, as in the reference's use)."""
+
+    @staticmethod
+    def forward(ctx, module, pos, dirs, p_base, p_head, p_sem):
+        lib = L.load_library()
+        h = module._ensure_handle()
+        n = pos.shape[0]
+        dev = pos.device
+        rgb = torch.empty(n, 3, device=dev); sigma = torch.empty(n, 1, device=dev)
+        sem = torch.empty(n, module.num_semantic_classes, device=dev)
+        nbytes = lib.mnf_field_train_workspace_bytes(h, n)
+        ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+        if n:
+            L.check(lib.mnf_field_forward_train(h, L.ptr(pos), L.ptr(dirs), n, L.ptr(rgb), L.ptr(sigma), L.ptr(sem), L.ptr(ws),
+                                                nbytes, L.stream()))
+        ctx.module, ctx.ws, ctx.nbytes, ctx.n = module, ws, nbytes, n
+        ctx.save_for_backward(pos, rgb, sigma)
+        return rgb, sigma, sem
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_sigma, g_sem):
+        lib = L.load_library()
+        module = ctx.module
+        pos, rgb, sigma = ctx.saved_tensors
+        dev = pos.device
+        h = module._handle
+        g_base = torch.empty_like(module.mlp_base.params)
+        g_head = torch.empty_like(module.mlp_head.params)
+        g_s = torch.empty_like(module.mlp_sem.params)
+        zeros = lambda g, shape: torch.zeros(shape, device=dev) if g is None else L.contig(g, torch.float32)
+        g_rgb, g_sigma = zeros(g_rgb, rgb.shape), zeros(g_sigma, sigma.shape)
+        g_sem = zeros(g_sem, (ctx.n, module.num_semantic_classes))
+        L.check(lib.mnf_field_backward(h, L.ptr(pos), ctx.n, L.ptr(g_rgb), L.ptr(g_sigma), L.ptr(g_sem), L.ptr(rgb), L.ptr(sigma),
+                                       L.ptr(ctx.ws), ctx.nbytes, float(module.loss_scale), L.ptr(g_base), L.ptr(g_head), L.ptr(g_s),
+                                       L.stream()))
+        ctx.ws = None
+        return None, None, None, g_base, g_head, g_s
+
+
 class NGPRadianceField(torch.nn.Module):
     """Instant-NGP radiance field with a semantic head (ngp.py:69-169)."""
 
@@ -56,6 +98,7 @@ class NGPRadianceField(torch.nn.Module):
         self.geo_feat_dim, self.n_levels, self.log2_hashmap_size = geo_feat_dim, n_levels, log2_hashmap_size
         self.num_semantic_classes = num_semantic_classes
         self.neurons, self.layers = neurons, layers
+        self.loss_scale = 128.0   # fp16 activation-gradient scale of the backward kernels (tcnn's default)
 
         lib = L.load_library()
         cfg = L.FieldConfig()
@@ -160,16 +203,15 @@ class NGPRadianceField(torch.nn.Module):
         if directions is None:
             raise NotImplementedError("forward() without directions is not reachable from pipeline.py")
         assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "the differentiable forward (train_step) of the HIP field is not built yet (DESIGN.md §Scope); "
-                "call under torch.no_grad() for rendering / scoring")
         h = self._ensure_handle()
         L.require_gpu(positions, directions)
         shp = positions.shape[:-1]
-        pos = L.contig(positions.reshape(-1, 3), torch.float32)
-        dirs = L.contig(directions.reshape(-1, 3), torch.float32)
+        pos = L.contig(positions.detach().reshape(-1, 3), torch.float32)
+        dirs = L.contig(directions.detach().reshape(-1, 3), torch.float32)
         n = pos.shape[0]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            rgb, sigma, sem = _FieldFunction.apply(self, pos, dirs, self.mlp_base.params, self.mlp_head.params, self.mlp_sem.params)
+            return rgb.view(*shp, 3), sigma.view(*shp, 1), sem.view(*shp, self.num_semantic_classes)
         rgb = torch.empty(n, 3, device=pos.device, dtype=torch.float32)
         sigma = torch.empty(n, 1, device=pos.device, dtype=torch.float32)
         sem = torch.empty(n, self.num_semantic_classes, device=pos.device, dtype=torch.float32)

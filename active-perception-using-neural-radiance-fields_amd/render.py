@@ -133,12 +133,19 @@ def render_views(radiance_field, estimator, rays_o, rays_d, rays_per_view, max_s
 
 
 # ------------------------------------------------------------------ train-mode forward (utils.py:63-219, :362-461)
-@torch.no_grad()
 def sem_rendering(radiance_field, rays: Rays, t_starts, t_ends, ray_indices, n_rays, render_bkgd=None):
-    """utils.py:362-461 on packed samples (forward values)."""
+    """utils.py:362-461 on packed samples.  With autograd enabled the field is evaluated through its differentiable
+    forward (positions formed as in the closure utils.py:122-137) and the compositing below is plain torch autograd,
+    as in the reference; otherwise the fused no-grad kernel forms the positions itself."""
     C = radiance_field.num_semantic_classes
     dev = t_starts.device
-    if t_starts.shape[0] != 0:
+    differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in radiance_field.parameters())
+    if t_starts.shape[0] != 0 and differentiable:
+        t_dirs = rays.viewdirs[ray_indices]
+        positions = rays.origins[ray_indices] + t_dirs * (t_starts + t_ends)[:, None] / 2.0
+        rgbs, sigmas, sems = radiance_field(positions, t_dirs)
+        sigmas = sigmas.squeeze(-1)
+    elif t_starts.shape[0] != 0:
         rgbs, sigmas, sems = radiance_field.forward_samples(rays.origins, rays.viewdirs, ray_indices, t_starts, t_ends)
     else:
         rgbs, sigmas, sems = torch.empty((0, 3), device=dev), torch.empty((0,), device=dev), torch.empty((0, C), device=dev)
@@ -153,14 +160,14 @@ def sem_rendering(radiance_field, rays: Rays, t_starts, t_ends, ray_indices, n_r
     return colors, opacities, depths, semantics, dict(weights=weights, alphas=alphas, trans=trans, sigmas=sigmas, rgbs=rgbs)
 
 
-@torch.no_grad()
 def render_image_with_occgrid_with_depth_guide(radiance_field, estimator, rays: Rays, near_plane: float = 0.0,
                                                far_plane: float = 1e10, render_step_size: float = 1e-3,
                                                render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0,
                                                alpha_thre: float = 0.0, test_chunk_size: int = 8192, timestamps=None,
                                                depth: Optional[torch.Tensor] = None):
-    """utils.py:63-219: occupancy sampling with the density pre-pass, then semantic volume rendering.
-    Forward values only in this round (no autograd graph); `depth` is accepted and ignored as in the reference."""
+    """utils.py:63-219: occupancy sampling with the density pre-pass (no grad), then semantic volume rendering.
+    Differentiable w.r.t. the field parameters when autograd is enabled (the reference's training forward);
+    `depth` is accepted and ignored as in the reference."""
     if timestamps is not None:
         raise NotImplementedError("timestamps (D-NeRF) are not part of the hot path")
     rays_shape = rays.origins.shape

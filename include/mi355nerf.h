@@ -131,6 +131,28 @@ int mnf_field_forward_samples(mnf_field_t f, const float *rays_o, const float *r
                               const int64_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                               float *rgb, float *density, float *sem, mnf_stream_t stream);
 
+/* ---------------------------------------------------------------- training: differentiable field
+ * What `loss.backward()` reaches inside tiny-cuda-nn in the reference (scripts/pipeline.py:518): the forward
+ * that keeps activations and the backward to the flat parameter vectors.  Compositing, the loss and the optimizer
+ * stay with the caller exactly as in the reference (perception/models/utils.py:362-461, pipeline.py:506-535). */
+
+/* bytes of workspace the train forward/backward pair needs for n samples (activations, masks, feature gradients) */
+int64_t mnf_field_train_workspace_bytes(mnf_field_t f, int64_t n);
+/* NGPRadianceField.forward with activations saved into `workspace` for the following backward */
+int mnf_field_forward_train(mnf_field_t f, const float *positions, const float *directions, int64_t n,
+                            float *rgb, float *density, float *sem, void *workspace, int64_t workspace_bytes,
+                            mnf_stream_t stream);
+/* Backward of the forward above: d_rgb [n,3], d_density [n], d_sem [n,C] are dL/d(outputs); rgb/density are the
+ * forward outputs; `workspace` is the one the forward filled.  g_base / g_head / g_sem receive dL/d(params) in the
+ * state_dict layout (fp32, overwritten).  Activation gradients are carried in fp16 scaled by loss_scale (tcnn's
+ * default is 128); the returned gradients are un-scaled.  The parameters are the ones last passed to
+ * mnf_field_set_params (they must still be alive). */
+int mnf_field_backward(mnf_field_t f, const float *positions, int64_t n,
+                       const float *d_rgb, const float *d_density, const float *d_sem,
+                       const float *rgb, const float *density,
+                       void *workspace, int64_t workspace_bytes, float loss_scale,
+                       float *g_base, float *g_head, float *g_sem, mnf_stream_t stream);
+
 /* ---------------------------------------------------------------- fused test-mode renderers */
 
 typedef struct {

@@ -121,7 +121,13 @@ def init_params(cfg: FieldConfig, seed: int = 0) -> Dict[str, np.ndarray]:
 
 
 def _q(x: torch.Tensor, precision: str) -> torch.Tensor:
-    return x.half().float() if precision == "f16" else x
+    """fp16 rounding with a straight-through gradient (d round(x)/dx := 1), so that torch autograd through this
+    oracle yields the fp32 gradient of the fp16-rounded forward — the reference the HIP backward is checked against."""
+    if precision != "f16":
+        return x
+    if x.requires_grad:
+        return x + (x.detach().half().float() - x.detach())
+    return x.half().float()
 
 
 def _split_mlp(flat: torch.Tensor, shapes) -> List[torch.Tensor]:
@@ -135,26 +141,34 @@ def _split_mlp(flat: torch.Tensor, shapes) -> List[torch.Tensor]:
 class OracleField:
     """forward / query_density with the ngp.py call surface, torch CPU fp32."""
 
-    def __init__(self, cfg: FieldConfig, params: Dict[str, np.ndarray], precision: str = "f16"):
+    def __init__(self, cfg: FieldConfig, params: Dict[str, np.ndarray], precision: str = "f16", requires_grad: bool = False):
         self.cfg = cfg
         self.precision = precision
         self.num_semantic_classes = cfg.num_semantic_classes
         self.aabb = torch.tensor(cfg.aabb, dtype=torch.float32)
         self.levels, self.table_entries = grid_levels(cfg)
-        shapes = mlp_shapes(cfg)
-        pb = torch.from_numpy(np.asarray(params["mlp_base"], np.float32))
-        n_mlp = sum(o * i for o, i in shapes["base"])
-        self.w_base = [_q(w, precision) for w in _split_mlp(pb[:n_mlp], shapes["base"])]
-        self.table = _q(pb[n_mlp:].view(self.table_entries, cfg.n_features), precision)
-        self.w_head = [_q(w, precision) for w in _split_mlp(torch.from_numpy(np.asarray(params["mlp_head"], np.float32)), shapes["head"])]
-        self.w_sem = [_q(w, precision) for w in _split_mlp(torch.from_numpy(np.asarray(params["mlp_sem"], np.float32)), shapes["sem"])]
+        self.shapes = mlp_shapes(cfg)
+        # leaf parameter vectors in the reference state_dict layout
+        self.p_base = torch.from_numpy(np.asarray(params["mlp_base"], np.float32).copy()).requires_grad_(requires_grad)
+        self.p_head = torch.from_numpy(np.asarray(params["mlp_head"], np.float32).copy()).requires_grad_(requires_grad)
+        self.p_sem = torch.from_numpy(np.asarray(params["mlp_sem"], np.float32).copy()).requires_grad_(requires_grad)
+        self._derive()
+
+    def _derive(self):
+        """(re)build the fp16-rounded weight views from the leaf vectors (call again after changing them)"""
+        precision = self.precision
+        n_mlp = sum(o * i for o, i in self.shapes["base"])
+        self.w_base = [_q(w, precision) for w in _split_mlp(self.p_base[:n_mlp], self.shapes["base"])]
+        self.table = _q(self.p_base[n_mlp:].view(self.table_entries, self.cfg.n_features), precision)
+        self.w_head = [_q(w, precision) for w in _split_mlp(self.p_head, self.shapes["head"])]
+        self.w_sem = [_q(w, precision) for w in _split_mlp(self.p_sem, self.shapes["sem"])]
 
     # ---- encodings -------------------------------------------------------------------
     def hash_encode(self, x: torch.Tensor) -> torch.Tensor:
         """x: [N,3] in aabb-normalised coordinates -> [N, n_levels*n_features] fp32."""
         N = x.shape[0]
         F = self.cfg.n_features
-        out = torch.empty(N, self.cfg.n_levels * F, dtype=torch.float32)
+        outs = []
         xd = x.double()
         for l, lv in enumerate(self.levels):
             pos = (xd * float(lv["scale"]) + 0.5).float()          # fmaf(scale, x, 0.5)
@@ -178,8 +192,8 @@ class OracleField:
                     res = lv["res"]
                     index = ((idx3[0] + idx3[1] * res + idx3[2] * res * res) & 0xFFFFFFFF) % lv["n"]
                 acc = acc + w[:, None] * self.table[lv["offset"] + index]
-            out[:, l * F:(l + 1) * F] = acc
-        return out
+            outs.append(acc)
+        return torch.cat(outs, -1)
 
     @staticmethod
     def sh4(dirs01: torch.Tensor) -> torch.Tensor:

@@ -25,8 +25,21 @@ def _t(a, dtype=torch.float32):
 
 
 # ---------------------------------------------------------------- volrend
+class _ExclusiveSum(torch.autograd.Function):
+    """scan.py:206-229: the gradient of a packed exclusive sum is the reverse-direction exclusive sum of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, packed_info):
+        ctx.packed_info = packed_info
+        return torch.from_numpy(M.exclusive_sum(x.detach().numpy(), packed_info))
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.from_numpy(M.exclusive_sum(g.contiguous().numpy(), ctx.packed_info, backward=True)), None
+
+
 def exclusive_sum(x: torch.Tensor, packed_info: np.ndarray) -> torch.Tensor:
-    return torch.from_numpy(M.exclusive_sum(x.numpy(), packed_info))
+    return _ExclusiveSum.apply(x, packed_info)
 
 
 def render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info, prefix_trans=None):
@@ -120,8 +133,9 @@ def sampling(binaries, aabbs, occs_mean: float, rays_o, rays_d, sigma_fn: Option
     n_all = t_starts.shape[0]
     if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None:
         alpha_thre = min(alpha_thre, occs_mean)                      # occ_grid.py:199
-        sigmas = sigma_fn(t_starts, t_ends, ray_indices) if n_all else torch.empty(0)
-        masks = render_visibility_from_density(t_starts, t_ends, sigmas, packed_info, early_stop_eps, alpha_thre)
+        with torch.no_grad():                                        # occ_grid.py:80 (@torch.no_grad)
+            sigmas = sigma_fn(t_starts, t_ends, ray_indices) if n_all else torch.empty(0)
+            masks = render_visibility_from_density(t_starts, t_ends, sigmas, packed_info, early_stop_eps, alpha_thre)
         ray_indices, t_starts, t_ends = ray_indices[masks], t_starts[masks], t_ends[masks]
     return ray_indices, t_starts, t_ends, n_all
 

@@ -19,11 +19,11 @@ def make_scene(scene="102344250", neurons=128, layers=2, C=29, seed=0, log2_hash
                 neurons=neurons, layers=layers, C=C, log2_hashmap_size=log2_hashmap_size)
 
 
-def oracle_field(scene, precision="f16"):
+def oracle_field(scene, precision="f16", requires_grad=False):
     from oracle.field import FieldConfig, OracleField
     cfg = FieldConfig(aabb=tuple(float(x) for x in scene["aabb"]), neurons=scene["neurons"], layers=scene["layers"],
                       num_semantic_classes=scene["C"], log2_hashmap_size=scene["log2_hashmap_size"])
-    return OracleField(cfg, scene["params"], precision)
+    return OracleField(cfg, scene["params"], precision, requires_grad)
 
 
 def hip_field(scene, device="cuda:0"):

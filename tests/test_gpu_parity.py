@@ -318,8 +318,9 @@ def test_train_mode_forward_matches_oracle(scene, fields):
     ref = R.render_train(orc, scene["occ"], scene["aabb"][None], float(est.occs.mean().item()), o, d, near,
                          render_bkgd=bk, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01)
     hip.eval()   # eval: no stratified jitter (the jitter comes from the device RNG), single 8192-ray chunk
-    rgb, acc, depth, sem, n = RD.render_image_with_occgrid_with_depth_guide(
-        hip, est, RD.Rays(o.to(DEV), d.to(DEV)), render_bkgd=bk.to(DEV), **H.RENDER_KW)
+    with torch.no_grad():   # forward values through the fused no-grad kernels (the differentiable path: test_train_step_matches_oracle)
+        rgb, acc, depth, sem, n = RD.render_image_with_occgrid_with_depth_guide(
+            hip, est, RD.Rays(o.to(DEV), d.to(DEV)), render_bkgd=bk.to(DEV), **H.RENDER_KW)
     assert abs(n - ref[4]) <= max(3, 0.002 * ref[4]) and ref[4] > 1000
     np.testing.assert_allclose(rgb.cpu().numpy(), ref[0].numpy(), atol=1e-3)
     np.testing.assert_allclose(acc.cpu().numpy(), ref[1].numpy(), atol=1e-3)
@@ -369,3 +370,90 @@ def test_score_views_end_to_end(scene):
     stack = lambda key: np.asarray([[[o[key].numpy().reshape(16, 16, -1) for o in per]] for per in outs])
     ref = SC.per_view_terms(stack("rgb_var"), stack("depth_var")[..., 0], stack("acc")[..., 0], stack("sem"))
     np.testing.assert_allclose(terms.cpu().numpy(), ref, atol=5e-3, rtol=5e-3)
+
+
+# ------------------------------------------------------------------ training: backward of the field and the train step
+def _grad_close(got, want, name, rel=2e-2, cos=0.9995):
+    got, want = got.double().cpu().numpy().ravel(), want.double().numpy().ravel()
+    denom = np.linalg.norm(want)
+    assert denom > 0, name
+    err = np.linalg.norm(got - want) / denom
+    c = float(got @ want / (np.linalg.norm(got) * denom + 1e-300))
+    assert err < rel and c > cos, f"{name}: rel L2 err {err:.3e}, cos {c:.6f}"
+
+
+@pytest.mark.parametrize("neurons,layers,C,lh", [(128, 2, 29, 14), (64, 4, 13, 12)])
+def test_field_backward_matches_oracle(neurons, layers, C, lh):
+    """dL/d(params) of the HIP backward (fp16 activation gradients, loss scale 128) against torch autograd through the
+    oracle (fp32 gradient of the same fp16-rounded forward).  Tolerance: 2e-2 relative L2, cosine > 0.9995 per parameter group."""
+    sc = H.make_scene(neurons=neurons, layers=layers, C=C, log2_hashmap_size=lh, head_gain=2.0)
+    hip = H.hip_field(sc).train()
+    orc = H.oracle_field(sc, requires_grad=True)
+    rng = np.random.default_rng(7)
+    n = 3000 + 21
+    a = sc["aabb"]
+    pos = (rng.random((n, 3)) * (a[3:] - a[:3]) * 0.98 + a[:3] + 0.01 * (a[3:] - a[:3])).astype(np.float32)
+    pos[:5] = a[:3] - 1.0                                          # outside the box: density gradient must vanish
+    d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    g_rgb = (rng.normal(size=(n, 3)) * 1e-3).astype(np.float32)
+    g_sig = (rng.normal(size=(n, 1)) * 1e-5).astype(np.float32)
+    g_sem = (rng.normal(size=(n, C)) * 1e-3).astype(np.float32)
+    rgb, sigma, sem = hip(_cu(pos), _cu(d))
+    assert rgb.requires_grad and sem.requires_grad
+    torch.autograd.backward([rgb, sigma, sem], [_cu(g_rgb), _cu(g_sig), _cu(g_sem)])
+    r_rgb, r_sigma, r_sem = orc(torch.from_numpy(pos), torch.from_numpy(d))
+    np.testing.assert_allclose(rgb.detach().cpu().numpy()[5:], r_rgb.detach().numpy()[5:], atol=1e-3)       # train forward == inference forward
+    torch.autograd.backward([r_rgb, r_sigma, r_sem], [torch.from_numpy(g_rgb), torch.from_numpy(g_sig), torch.from_numpy(g_sem)])
+    n_mlp = sum(o * i for o, i in orc.shapes["base"])
+    _grad_close(hip.mlp_base.params.grad[:n_mlp], orc.p_base.grad[:n_mlp], "base mlp")
+    _grad_close(hip.mlp_base.params.grad[n_mlp:], orc.p_base.grad[n_mlp:], "hash table")
+    _grad_close(hip.mlp_head.params.grad, orc.p_head.grad, "rgb head")
+    _grad_close(hip.mlp_sem.params.grad, orc.p_sem.grad, "sem head")
+    # entries never touched by a sample get exactly zero gradient
+    untouched = (orc.p_base.grad[n_mlp:] == 0).numpy()
+    assert (hip.mlp_base.params.grad[n_mlp:].cpu().numpy()[untouched] == 0).all()
+
+
+def test_train_step_matches_oracle(scene):
+    """utils.py:63-219 forward + the loss of pipeline.py:506-511 + backward, then one Adam step (pipeline.py:173-178)."""
+    import torch.nn.functional as F
+    from apnrf_amd import render as RD
+    from oracle import render as R
+    sc = H.make_scene(log2_hashmap_size=15)
+    hip, orc = H.hip_field(sc), H.oracle_field(sc, requires_grad=True)
+    hip.eval()     # no stratified jitter (device RNG); gradients still flow
+    est = H.hip_estimator(sc)
+    o, d = H.view_rays(sc, 4, h=12, w=12)
+    rng = np.random.default_rng(3)
+    pix = torch.from_numpy(rng.random((144, 3)).astype(np.float32))
+    dep = torch.from_numpy(rng.uniform(0.5, 4.0, 144).astype(np.float32))
+    lab = torch.from_numpy(rng.integers(0, 29, 144))
+    bk = torch.tensor([0.5, 0.2, 0.9])
+
+    def loss_fn(rgb, depth, sem, pix, dep, lab):
+        return F.smooth_l1_loss(rgb, pix) * 10 + F.smooth_l1_loss(depth, dep.unsqueeze(1)) / 5 + F.cross_entropy(sem, lab) / 2
+
+    opt = torch.optim.Adam(hip.parameters(), lr=1e-3, eps=1e-15)
+    rgb, acc, depth, sem, n = RD.render_image_with_occgrid_with_depth_guide(hip, est, RD.Rays(o.to(DEV), d.to(DEV)),
+                                                                            render_bkgd=bk.to(DEV), **H.RENDER_KW)
+    assert n > 1000 and rgb.requires_grad
+    loss = loss_fn(rgb, depth, sem, pix.to(DEV), dep.to(DEV), lab.to(DEV))
+    opt.zero_grad()
+    loss.backward()
+    ref = R.render_train(orc, sc["occ"], sc["aabb"][None], float(est.occs.mean().item()), o, d, torch.full((144,), 0.1),
+                         render_bkgd=bk, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01)
+    r_loss = loss_fn(ref[0], ref[2], ref[3], pix, dep, lab)
+    r_loss.backward()
+    np.testing.assert_allclose(loss.item(), r_loss.item(), rtol=1e-4)
+    n_mlp = sum(o_ * i_ for o_, i_ in orc.shapes["base"])
+    _grad_close(hip.mlp_base.params.grad[:n_mlp], orc.p_base.grad[:n_mlp], "base mlp", rel=3e-2, cos=0.999)
+    _grad_close(hip.mlp_base.params.grad[n_mlp:], orc.p_base.grad[n_mlp:], "hash table", rel=3e-2, cos=0.999)
+    _grad_close(hip.mlp_head.params.grad, orc.p_head.grad, "rgb head", rel=3e-2, cos=0.999)
+    _grad_close(hip.mlp_sem.params.grad, orc.p_sem.grad, "sem head", rel=3e-2, cos=0.999)
+    before = hip.mlp_head.params.detach().clone()
+    assert not any(torch.isnan(p.grad).any() for p in hip.parameters() if p.grad is not None)     # pipeline.py:520-524
+    opt.step()
+    assert (hip.mlp_head.params.detach() != before).any()
+    with torch.no_grad():                                          # the updated parameters are picked up by the kernels
+        rgb2, *_ = RD.render_image_with_occgrid_with_depth_guide(hip, est, RD.Rays(o.to(DEV), d.to(DEV)), render_bkgd=bk.to(DEV), **H.RENDER_KW)
+    assert (rgb2 - rgb.detach()).abs().max() > 0
