@@ -12,6 +12,7 @@
 //
 // Gradients of activations travel in fp16 scaled by `loss_scale` (tcnn does the same with its default scale of
 // 128); parameter gradients are accumulated and returned in fp32, un-scaled.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -237,23 +238,67 @@ struct HashBwdArgs {
     LevelMeta levels[16];
 };
 
+// Samples arrive sorted by ray and by distance along the ray, so neighbouring lanes usually sit in the same grid cell
+// of a level (always at the coarse levels, often at the fine ones).  A scattered float atomic is the slow operation
+// here (MI355X: ~17x below the contiguous rate), so each wave first sums the 8 corners x 4 features of runs of lanes
+// that share a cell (segmented inclusive scan over the lanes) and only the last lane of every run issues atomics.
+template <bool PRE>
 __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= args.n) return;
-    float xn[3];
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < args.n;
+    float xn[3] = {0.5f, 0.5f, 0.5f};
+    if (valid) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) xn[d] = (args.positions[3 * i + d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);
+        for (int d = 0; d < 3; ++d) xn[d] = (args.positions[3 * i + d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);
+    }
 #pragma unroll 1
     for (int l = 0; l < 16; ++l) {
+        const LevelMeta m = args.levels[l];
         LevelPrep p;
-        hash_prep(args.levels[l], xn, p);
-        const float4 g = reinterpret_cast<const float4 *>(args.dX + i * 64)[l];
-        if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
+        hash_prep(m, xn, p);
+        float4 g = {0.f, 0.f, 0.f, 0.f};
+        if (valid) g = reinterpret_cast<const float4 *>(args.dX + i * 64)[l];
+        // cell identity: the three integer cell coordinates (recomputed exactly as hash_prep does)
+        int cell[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) cell[d] = (int)floorf(__builtin_fmaf(m.scale, xn[d], 0.5f));
+        bool head = true;
+        if (PRE) {
+            const int px = __shfl_up(cell[0], 1, 64), py = __shfl_up(cell[1], 1, 64), pz = __shfl_up(cell[2], 1, 64);
+            const int pv = __shfl_up((int)valid, 1, 64);
+            if (lane > 0 && pv && valid && px == cell[0] && py == cell[1] && pz == cell[2]) head = false;
+        }
+        float v[32];
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) {
             const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
-            float *dst = args.g_table + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
-            atomicAdd(dst + 0, w * g.x); atomicAdd(dst + 1, w * g.y); atomicAdd(dst + 2, w * g.z); atomicAdd(dst + 3, w * g.w);
+            v[4 * corner + 0] = w * g.x; v[4 * corner + 1] = w * g.y; v[4 * corner + 2] = w * g.z; v[4 * corner + 3] = w * g.w;
+        }
+        // segmented inclusive scan (Hillis-Steele) over the wave
+        bool f = head;
+#pragma unroll
+        for (int d = 1; PRE && d < 64; d <<= 1) {
+            const int fu = __shfl_up((int)f, d, 64);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const float t = __shfl_up(v[k], d, 64);
+                if (lane >= d && !f) v[k] += t;
+            }
+            if (lane >= d) f = f || (fu != 0);
+        }
+        // the last lane of a run holds the run total
+        const unsigned long long brk = __ballot(head || !valid);   // lanes that start a run (or are past the end)
+        const bool tail = valid && (lane == 63 || ((brk >> (lane + 1)) & 1ull));
+        if (tail) {
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                float *dst = args.g_table + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
+                if (v[4 * corner] != 0.f) atomicAdd(dst + 0, v[4 * corner]);
+                if (v[4 * corner + 1] != 0.f) atomicAdd(dst + 1, v[4 * corner + 1]);
+                if (v[4 * corner + 2] != 0.f) atomicAdd(dst + 2, v[4 * corner + 2]);
+                if (v[4 * corner + 3] != 0.f) atomicAdd(dst + 3, v[4 * corner + 3]);
+            }
         }
     }
 }
@@ -527,6 +572,8 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     hb.positions = positions; hb.dX = v.dX; hb.g_table = g_base + f->n_base_mlp; hb.n = n;
     std::memcpy(hb.aabb, f->cfg.aabb, sizeof(hb.aabb));
     std::memcpy(hb.levels, f->levels, sizeof(hb.levels));
-    hipLaunchKernelGGL(hash_bwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, hb);
+    static const bool simple = getenv("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane and corner
+    if (simple) hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, hb);
+    else hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, hb);
     return launch_status("hash_bwd_kernel");
 }

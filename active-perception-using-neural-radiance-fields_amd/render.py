@@ -192,6 +192,46 @@ def render_image_with_occgrid_with_depth_guide(radiance_field, estimator, rays: 
     return colors.view(*shp, -1), opacities.view(*shp, -1), depths.view(*shp, -1), semantics.view(*shp, -1), sum(r[4] for r in results)
 
 
+def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, sem, render_bkgd, step: int,
+               near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-3, scheduler=None):
+    """One model's training iteration exactly as scripts/pipeline.py:447-532 sequences it: occupancy refresh every 16th
+    step (:447-470), train render (:472-489), loss 10*smoothL1(rgb) + smoothL1(depth)/5 + CE(sem)/2 (:506-511),
+    backward (:518), NaN-gradient guard (:520-529), optimizer and scheduler step (:531-532).
+    Returns dict(loss, loss_rgb, loss_dep, loss_sem as device tensors, n_rendering_samples, skipped)."""
+    import torch.nn.functional as F
+    radiance_field.train()
+    estimator.train()
+
+    def occ_eval_fn(x):
+        return radiance_field.query_density(x) * render_step_size
+
+    estimator.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre)
+    rgb, acc, depth, semantic, n_rendering_samples = render_image_with_occgrid_with_depth_guide(
+        radiance_field, estimator, rays, near_plane=near_plane, render_step_size=render_step_size, render_bkgd=render_bkgd,
+        cone_angle=cone_angle, alpha_thre=alpha_thre, depth=dep)
+    if n_rendering_samples == 0:
+        return dict(loss=None, n_rendering_samples=0, skipped=True)
+    loss_rgb = F.smooth_l1_loss(rgb, pixels)
+    loss_dep = F.smooth_l1_loss(depth, dep.unsqueeze(1))
+    loss_sem = F.cross_entropy(semantic, sem)
+    loss = loss_rgb * 10 + loss_dep / 5 + loss_sem / 2
+    optimizer.zero_grad()
+    loss.backward()
+    bad = torch.zeros((), device=rgb.device)
+    for p_ in radiance_field.parameters():
+        if p_.grad is not None:
+            bad = bad + torch.isnan(p_.grad).sum()
+    skipped = bool(bad.item() > 0)          # one host sync (the reference syncs once per parameter)
+    if skipped:
+        optimizer.zero_grad()
+    else:
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+    return dict(loss=loss.detach(), loss_rgb=loss_rgb.detach(), loss_dep=loss_dep.detach(), loss_sem=loss_sem.detach(),
+                n_rendering_samples=n_rendering_samples, skipped=skipped)
+
+
 # ------------------------------------------------------------------ habitat_to_data.py
 def pose_to_c2w(p: np.ndarray) -> np.ndarray:
     """habitat_to_data.py:444-451: xyz + quaternion (x, y, z, w) -> 4x4 camera-to-world (float64 on the host)."""

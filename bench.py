@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="render800", choices=["render800", "score256"])
+    ap.add_argument("--workload", default="render800", choices=["render800", "score256", "train"])
+    ap.add_argument("--train-rays", type=int, default=8192, help="rays per train step (BASELINE config 5: 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket field-kernel launches with hipEvents")
     ap.add_argument("--cpu-sample", type=int, default=80, help="cpu baseline renders a SxS sub-sample of one view")
@@ -108,6 +109,30 @@ def main():
             return RD.render_views(field, est, rays.origins[k], rays.viewdirs[k], n_per_step, 1024, render_bkgd=bk, **H.RENDER_KW)
         units_per_step = n_per_step
         workload = "scene 102344529 (synthetic stand-in), 800x800 RGB+depth+29-class semantic render, hash-grid 16x4 T=2^19 + MLP 128x2 + 64x2 heads"
+    elif args.workload == "train":
+        # BASELINE config 5 shape: scene 102344280, 8192-ray train batches; targets are synthetic (no Habitat data offline)
+        scene = H.make_scene("102344280", n_poses=8)
+        field, est = H.hip_field(scene, dev), H.hip_estimator(scene, dev)
+        opt = torch.optim.Adam(field.parameters(), lr=1e-3, eps=1e-15)
+        R_ = args.train_rays
+        c2w = np.stack([RD.pose_to_c2w(p) for p in scene["poses"]]).astype(np.float32)
+        K = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
+        g = torch.Generator(device="cpu").manual_seed(rank)
+        batches = []
+        for k in range(8):
+            idx = torch.randint(0, 640 * 640, (R_,), generator=g).numpy()
+            r = RD.generate_image_rays(torch.from_numpy(c2w[k:k + 1]), 640, 640, K, dev, idx)
+            batches.append((r, torch.rand(R_, 3, generator=g).to(dev), (torch.rand(R_, generator=g) * 4 + 0.5).to(dev),
+                            torch.randint(0, 29, (R_,), generator=g).to(dev)))
+        state = {"samples": 0}
+
+        def step(i):
+            r, pix, dep_, lab = batches[i % 8]
+            out = RD.train_step(field, est, opt, r, pix, dep_, lab, torch.rand(3, device=dev), step=i, **H.RENDER_KW)
+            state["samples"] += out["n_rendering_samples"]
+            return None
+        units_per_step = R_
+        workload = f"train step, scene 102344280 (synthetic stand-in), {R_} rays/step, hash-grid + MLP 128x2, loss+backward+Adam (torch)"
     else:
         scene = H.make_scene("102344250", n_poses=256)
         sc2 = dict(scene); sc2["params"] = H.S.make_field_params(seed=1)
@@ -179,6 +204,10 @@ def main():
                                 "samples_per_ray": samples / (units_per_step * args.steps),
                                 "field_kernel_share_of_step": field_ms * 1e-3 / dt,
                                 "timing": "second pass of the same K steps with hipEvent pairs around each launch"}
+        if args.workload == "train":
+            line["metric"] = "train-step ms"
+            line["train"] = {"ms_per_step": 1e3 * dt / args.steps, "rays_per_step": args.train_rays,
+                             "rendering_samples_per_step": state["samples"] / max(1, 2 * args.steps + args.warmup) }
         if world == 1 and not args.no_cpu_baseline and args.workload == "render800":
             line["cpu_baseline"] = cpu_baseline(scene, scene["poses"], width, height, focal, args.cpu_sample)
         print(json.dumps(line))
