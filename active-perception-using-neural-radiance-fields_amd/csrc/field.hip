@@ -112,14 +112,14 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         SaveOff so[CT];
         if (SAVE) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(args.train, h, tile * kWaveSamples + (lane & 31) + 32 * ct);
+            for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(h, (lane & 31) + 32 * ct);
         }
         half8 *mdump = SAVE ? args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
         if (SAVE) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) save_rows<false>(args.train, T::rX + 16 * ks, so[ct], bfeat[ct][ks]);
+                for (int ks = 0; ks < 4; ++ks) save_rows<false>(args.train, tile, T::rX + 16 * ks, so[ct], bfeat[ct][ks]);
         }
 
         // ---- base MLP ----
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int k = 0; k < L::KSW; ++k) {
-                    save_rows<true>(args.train, T::rH0 + 16 * k, so[ct], hb[ct][k]);
+                    save_rows<true>(args.train, tile, T::rH0 + 16 * k, so[ct], hb[ct][k]);
                     mdump[((T::mH0 + k) * CT + ct) * 64] = hb[ct][k];
                 }
         }
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int k = 0; k < L::KSW; ++k) {
-                        save_rows<true>(args.train, T::rH0 + (l + 1) * W + 16 * k, so[ct], hb[ct][k]);
+                        save_rows<true>(args.train, tile, T::rH0 + (l + 1) * W + 16 * k, so[ct], hb[ct][k]);
                         mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = hb[ct][k];
                     }
             }
@@ -185,8 +185,8 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         if (SAVE) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                save_rows<false>(args.train, T::rS, so[ct], hin[ct][0]);
-                save_rows<true>(args.train, T::rG, so[ct], hin[ct][1]);
+                save_rows<false>(args.train, tile, T::rS, so[ct], hin[ct][0]);
+                save_rows<true>(args.train, tile, T::rG, so[ct], hin[ct][1]);
             }
         }
         half8 h1[CT][L::KSh], h2[CT][L::KSh];
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int k = 0; k < L::KSh; ++k) {
-                    save_rows<true>(args.train, row0 + 16 * k, so[ct], a[ct][k]);
+                    save_rows<true>(args.train, tile, row0 + 16 * k, so[ct], a[ct][k]);
                     mdump[((mblk + k) * CT + ct) * 64] = a[ct][k];
                 }
         };
@@ -360,7 +360,7 @@ static std::vector<int32_t> build_frag_table(const mnf_field_config &cfg) {
 template <int W, int NH>
 static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, int grid, hipStream_t stream, const TrainBuf *train) {
     KernelArgs a;
-    a.train = train ? *train : TrainBuf{nullptr, nullptr, 0};
+    a.train = train ? *train : TrainBuf{nullptr, nullptr, 0, 0};
     a.table = reinterpret_cast<const half4 *>(f->d_table);
     a.frags = reinterpret_cast<const half8 *>(f->d_frags);
     std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));

@@ -39,9 +39,9 @@ struct Layout {
 };
 
 // Training-time activation storage.  Two views of the same values:
-//  * `act`: feature-major fp16 matrix ACT[row][Np] (Np = samples rounded up to 64) — every row is one feature
-//    over all samples, so the weight-gradient GEMM reads its MFMA operands (8 consecutive samples of one
-//    feature) as plain 16-byte loads;
+//  * `act`: feature-major fp16 tiles ACT[tile][row][64 samples] (Np = samples rounded up to 64) — every row is one
+//    feature over the 64 samples of a tile, so the weight-gradient GEMM reads its MFMA operands (8 consecutive
+//    samples of one feature) as plain 16-byte loads, and the 32 rows of an operand tile are one contiguous 4 KB block;
 //  * `masks`: the post-ReLU hidden activations dumped as the half8 B fragments they already are
 //    ([tile][block][ct][lane]), which line up register-for-register with the accumulators of the backward chain.
 template <int W, int NH>
@@ -70,9 +70,10 @@ struct TrainLayout {
 };
 
 struct TrainBuf {
-    half_t *act;      // [rows][Np]
+    half_t *act;      // [tiles][rows][64]
     half8 *masks;     // [tiles][mask_blocks][CT][64]
     int64_t Np;
+    int32_t rows;
 };
 
 struct KernelArgs {
@@ -89,31 +90,31 @@ struct KernelArgs {
 __device__ __forceinline__ int feat_natural(int h, int j) { return 8 * h + j; }
 __device__ __forceinline__ int feat_acc(int h, int j) { return 8 * (j >> 2) + 4 * h + (j & 3); }
 
-// Store one B fragment feature-major: ACT[row0 + feat(h, j)][col] = frag[j].  The row term that does not depend on
-// the lane (row0 + 8*(j>>2) + (j&3), or row0 + j) is folded into a scalar base; the lane-dependent part
-// (column, and the 4h / 8h row offset of the lane half) is one 32-bit byte offset per lane, so every store is
+// Store one B fragment into the activation matrix.  Layout (tile-major): ACT[tile][row][64 samples] fp16, i.e. for
+// one 64-sample tile all `rows` feature rows are contiguous 128-byte lines — the weight-gradient GEMM then reads the
+// 32 rows of an operand tile as one contiguous 4 KB block.  The part of the address that does not depend on the lane
+// (tile, and row0 + 8*(j>>2) + (j&3) or row0 + j) is a scalar base; the lane part (column within the tile and the
+// 4h / 8h row offset of the lane half) is one 32-bit byte offset, so every store is
 // `global_store_short v_off, v_data, s[base]` with no 64-bit VGPR address.
 struct SaveOff {
     uint32_t acc, nat;   // byte offsets for accumulator-order and natural-order fragments
 };
-__device__ __forceinline__ SaveOff save_offsets(const TrainBuf &tb, int h, int64_t col) {
+__device__ __forceinline__ SaveOff save_offsets(int h, int col_in_tile) {
     SaveOff o;
-    o.acc = (uint32_t)((col + (int64_t)4 * h * tb.Np) * 2);
-    o.nat = (uint32_t)((col + (int64_t)8 * h * tb.Np) * 2);
+    o.acc = (uint32_t)((col_in_tile + 4 * h * 64) * 2);
+    o.nat = (uint32_t)((col_in_tile + 8 * h * 64) * 2);
     return o;
 }
 template <bool ACC_ORDER>
-__device__ __forceinline__ void save_rows(const TrainBuf &tb, int row0, const SaveOff &so, const half8 &frag) {
+__device__ __forceinline__ void save_rows(const TrainBuf &tb, int64_t tile, int row0, const SaveOff &so, const half8 &frag) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int srow = row0 + (ACC_ORDER ? 8 * (j >> 2) + (j & 3) : j);   // uniform part of the row
-        char *base = reinterpret_cast<char *>(tb.act) + (int64_t)srow * tb.Np * 2;
+        char *base = reinterpret_cast<char *>(tb.act) + ((tile * tb.rows + srow) * 64) * 2;
         *reinterpret_cast<half_t *>(base + (ACC_ORDER ? so.acc : so.nat)) = frag[j];
     }
 }
 
-
-// ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }

@@ -66,8 +66,8 @@ __device__ __forceinline__ void dense_tile(const half8 *__restrict__ w_lds, int 
 // stored feature-major at row0 for the weight gradient.
 template <int RT_OUT, int KS>
 __device__ __forceinline__ void dense_mask(const half8 *__restrict__ w_lds, int lane, int h, const half8 (&b)[CT][KS],
-                                           const half8 *__restrict__ masks, const TrainBuf &tb, int row0, const SaveOff (&so)[CT],
-                                           half8 (&o)[CT][RT_OUT * 2]) {
+                                           const half8 *__restrict__ masks, const TrainBuf &tb, int64_t tile, int row0,
+                                           const SaveOff (&so)[CT], half8 (&o)[CT][RT_OUT * 2]) {
 #pragma unroll
     for (int rt = 0; rt < RT_OUT; ++rt) {
         f32x16 acc[CT];
@@ -81,7 +81,7 @@ __device__ __forceinline__ void dense_mask(const half8 *__restrict__ w_lds, int 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (m[j] != (half_t)0.0f) ? (half_t)acc[ct][8 * s + j] : (half_t)0.0f;
                 o[ct][rt * 2 + s] = v;
-                save_rows<true>(tb, row0 + 16 * (rt * 2 + s), so[ct], v);
+                save_rows<true>(tb, tile, row0 + 16 * (rt * 2 + s), so[ct], v);
             }
         __builtin_amdgcn_sched_barrier(0);   // keep the row-tile iterations from interleaving (register pressure)
     }
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
         const int64_t fcol0 = tile * kWaveSamples + c;
         SaveOff so[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(args.train, h, fcol0 + 32 * ct);
+        for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(h, c + 32 * ct);
         const half8 *mdump = args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane;
         // ---- output-layer gradients, built directly as natural-order B fragments ----
         half8 dyr[CT][1], dys[CT][2];
@@ -131,18 +131,18 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
                 }
             // trunc_exp backward (ngp.py:34-39): g * exp(min(x, 15)) with exp(x) = sigma (0 outside the aabb)
             dlogit[ct] = ok ? args.d_sigma[col] * fminf(args.sigma[col], 3269017.3724721107f) * ls : 0.0f;
-            save_rows<false>(args.train, T::rdYr, so[ct], dyr[ct][0]);
-            save_rows<false>(args.train, T::rdYs, so[ct], dys[ct][0]);
-            save_rows<false>(args.train, T::rdYs + 16, so[ct], dys[ct][1]);
+            save_rows<false>(args.train, tile, T::rdYr, so[ct], dyr[ct][0]);
+            save_rows<false>(args.train, tile, T::rdYs, so[ct], dys[ct][0]);
+            save_rows<false>(args.train, tile, T::rdYs + 16, so[ct], dys[ct][1]);
         }
         // ---- heads ----
         half8 dz2[CT][L::KSh], dz1[CT][L::KSh];
         f32x16 dgeo_r[CT], dgeo_s[CT];
-        dense_mask<L::RTh, 1>(s_w + L::o_r3 * 64, lane, h, dyr, mdump + T::mHH2 * CT * 64, args.train, T::rdZr2, so, dz2);
-        dense_mask<L::RTh, L::KSh>(s_w + L::o_r2 * 64, lane, h, dz2, mdump + T::mHH1 * CT * 64, args.train, T::rdZr1, so, dz1);
+        dense_mask<L::RTh, 1>(s_w + L::o_r3 * 64, lane, h, dyr, mdump + T::mHH2 * CT * 64, args.train, tile, T::rdZr2, so, dz2);
+        dense_mask<L::RTh, L::KSh>(s_w + L::o_r2 * 64, lane, h, dz2, mdump + T::mHH1 * CT * 64, args.train, tile, T::rdZr1, so, dz1);
         dense_tile<L::KSh>(s_w + L::o_r1 * 64, lane, dz1, dgeo_r);
-        dense_mask<L::RTh, 2>(s_w + L::o_s3 * 64, lane, h, dys, mdump + T::mHS2 * CT * 64, args.train, T::rdZs2, so, dz2);
-        dense_mask<L::RTh, L::KSh>(s_w + L::o_s2 * 64, lane, h, dz2, mdump + T::mHS1 * CT * 64, args.train, T::rdZs1, so, dz1);
+        dense_mask<L::RTh, 2>(s_w + L::o_s3 * 64, lane, h, dys, mdump + T::mHS2 * CT * 64, args.train, tile, T::rdZs2, so, dz2);
+        dense_mask<L::RTh, L::KSh>(s_w + L::o_s2 * 64, lane, h, dz2, mdump + T::mHS1 * CT * 64, args.train, tile, T::rdZs1, so, dz1);
         dense_tile<L::KSh>(s_w + L::o_s1 * 64, lane, dz1, dgeo_s);
         // ---- base output gradient: geo rows from both heads, row 0 = density logit ----
         half8 dbo[CT][1];
@@ -151,17 +151,17 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
 #pragma unroll
             for (int j = 0; j < 8; ++j) dbo[ct][0][j] = (half_t)(dgeo_r[ct][j] + dgeo_s[ct][j]);
             if (h == 0) dbo[ct][0][0] = (half_t)dlogit[ct];
-            save_rows<true>(args.train, T::rdBO, so[ct], dbo[ct][0]);
+            save_rows<true>(args.train, tile, T::rdBO, so[ct], dbo[ct][0]);
         }
         // ---- base MLP ----
         half8 dz[CT][L::KSW];
-        dense_mask<L::RT, 1>(s_w + L::o_bo * 64, lane, h, dbo, mdump + (T::mH0 + (NH - 1) * L::KSW) * CT * 64, args.train,
+        dense_mask<L::RT, 1>(s_w + L::o_bo * 64, lane, h, dbo, mdump + (T::mH0 + (NH - 1) * L::KSW) * CT * 64, args.train, tile,
                              T::rdZ0 + (NH - 1) * W, so, dz);
 #pragma unroll
         for (int l = NH - 2; l >= 0; --l) {
             half8 dn[CT][L::KSW];
             dense_mask<L::RT, L::KSW>(s_w + (L::o_bh + l * L::RT * L::KSW) * 64, lane, h, dz, mdump + (T::mH0 + l * L::KSW) * CT * 64,
-                                      args.train, T::rdZ0 + l * W, so, dn);
+                                      args.train, tile, T::rdZ0 + l * W, so, dn);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -196,27 +196,31 @@ struct WgradJob {
     int32_t colmap[32];           // parameter column of in-row k of this tile, -1 = none
 };
 
-// one wave = one (job, sample chunk): D[32][32] += dOut^T[32][16 samples] * In^T[16 samples][32]
+// one wave = one (job, chunk of 64-sample tiles): D[32][32] += dOut^T[32][16 samples] * In^T[16 samples][32], four MFMA
+// steps per tile; the 32 rows of each operand are one contiguous 4 KB block of the tile-major activation matrix
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__ jobs, int n_jobs, int split, const half_t *__restrict__ act,
-                                                    int64_t Np, float inv_scale, float *g0, float *g1, float *g2) {
+                                                    int64_t n_tiles, int rows, float inv_scale, float *g0, float *g1, float *g2) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= n_jobs * split) return;
     const WgradJob &jb = jobs[wid / split];
     const int part = wid % split;
-    const int64_t steps = Np / 16;
-    const int64_t s0 = steps * part / split, s1 = steps * (part + 1) / split;
+    const int64_t t0 = n_tiles * part / split, t1 = n_tiles * (part + 1) / split;
     const int r = lane & 31, h = lane >> 5;
-    const half_t *pa = act + (int64_t)(jb.dout_row0 + r) * Np + 8 * h;
-    const half_t *pb = act + (int64_t)(jb.in_row0 + r) * Np + 8 * h;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-#pragma unroll 4
-    for (int64_t s = s0; s < s1; ++s) {
-        const half8 a = *reinterpret_cast<const half8 *>(pa + 16 * s);
-        const half8 b = *reinterpret_cast<const half8 *>(pb + 16 * s);
-        acc = mfma(a, b, acc);
+    for (int64_t t = t0; t < t1; ++t) {
+        const half_t *pa = act + ((t * rows + jb.dout_row0 + r) * 64) + 8 * h;
+        const half_t *pb = act + ((t * rows + jb.in_row0 + r) * 64) + 8 * h;
+        half8 a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = *reinterpret_cast<const half8 *>(pa + 16 * q);
+            b[q] = *reinterpret_cast<const half8 *>(pb + 16 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = mfma(a[q], b[q], acc);
     }
     float *g = jb.buf == 0 ? g0 : (jb.buf == 1 ? g1 : g2);
     const int col = jb.colmap[r];
@@ -244,6 +248,8 @@ struct HashBwdArgs {
 // that share a cell (segmented inclusive scan over the lanes) and only the last lane of every run issues atomics.
 template <bool PRE>
 __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
+    __shared__ float s_val[4][64 * 32];
+    __shared__ uint32_t s_off[4][64 * 8];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = i < args.n;
@@ -290,15 +296,37 @@ __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
         // the last lane of a run holds the run total
         const unsigned long long brk = __ballot(head || !valid);   // lanes that start a run (or are past the end)
         const bool tail = valid && (lane == 63 || ((brk >> (lane + 1)) & 1ull));
-        if (tail) {
+        if (!PRE) {
+            if (tail) {
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                float *dst = args.g_table + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
-                if (v[4 * corner] != 0.f) atomicAdd(dst + 0, v[4 * corner]);
-                if (v[4 * corner + 1] != 0.f) atomicAdd(dst + 1, v[4 * corner + 1]);
-                if (v[4 * corner + 2] != 0.f) atomicAdd(dst + 2, v[4 * corner + 2]);
-                if (v[4 * corner + 3] != 0.f) atomicAdd(dst + 3, v[4 * corner + 3]);
+                for (int corner = 0; corner < 8; ++corner) {
+                    float *dst = args.g_table + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (v[4 * corner + k] != 0.f) atomicAdd(dst + k, v[4 * corner + k]);
+                }
             }
+            continue;
+        }
+        // Transpose through LDS so that one atomic wave-instruction covers 16 (sample, corner) pairs x 4 consecutive
+        // floats: the four floats of a table entry share one 64-byte memory-side atomic request, so a wave issues 16
+        // requests per instruction instead of 64 scattered dwords.
+        float *w_val = s_val[threadIdx.x >> 6];
+        uint32_t *w_off = s_off[threadIdx.x >> 6];
+        __syncthreads();   // previous level's readers are done
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            float4 q = {v[4 * corner], v[4 * corner + 1], v[4 * corner + 2], v[4 * corner + 3]};
+            reinterpret_cast<float4 *>(w_val)[lane * 8 + corner] = q;
+            w_off[lane * 8 + corner] = tail ? p.off[corner] : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int sidx = 0; sidx < 32; ++sidx) {
+            const int pi = 16 * sidx + (lane >> 2);          // (sample, corner) pair handled by this lane quad
+            const uint32_t off = w_off[pi];
+            const float val = w_val[pi * 4 + (lane & 3)];
+            if (off != 0xFFFFFFFFu && val != 0.f) atomicAdd(args.g_table + (off >> 1) + (lane & 3), val);
         }
     }
 }
@@ -507,7 +535,7 @@ extern "C" int mnf_field_forward_train(mnf_field_t f, const float *positions, co
     FieldIO io = {};
     io.mode = 0; io.positions = positions; io.directions = directions; io.n = n;
     io.rgb = rgb; io.density = density; io.sem = sem;
-    TrainBuf tb = {v.act, v.masks, v.Np};
+    TrainBuf tb = {v.act, v.masks, v.Np, ts->tt.rows};
     return launch_field(f, io, false, as_stream(stream), &tb);
 }
 
@@ -541,7 +569,7 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     a.fragsT = reinterpret_cast<const half8 *>(ts->d_fragT);
     a.d_rgb = d_rgb; a.d_sigma = d_density; a.d_sem = d_sem; a.rgb = rgb; a.sigma = density;
     a.dX = v.dX; a.n = n; a.C = f->cfg.num_semantic_classes; a.loss_scale = loss_scale;
-    a.train = {v.act, v.masks, v.Np};
+    a.train = {v.act, v.masks, v.Np, ts->tt.rows};
     int grid = 256;
     const int64_t wgs = ceil_div(ceil_div(n, kWaveSamples), kWavesPerBlock);
     if (wgs < grid) grid = (int)wgs;
@@ -560,11 +588,14 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     if (rc) return rc;
     // weight gradients
     const int n_jobs = (int)ts->tt.jobs.size();
-    int split = (int)(v.Np / 16 / 64);   // >= 64 MFMA steps per wave
+    // enough sample chunks to fill the chip with waves (the loop is load-latency bound: ~32 waves per CU), but
+    // at least 16 MFMA steps per wave so the final atomics stay negligible
+    const int64_t n_tiles = v.Np / 64;
+    int split = (int)(256 * 32 / n_jobs);
+    if (split > n_tiles / 4) split = (int)(n_tiles / 4);
     if (split < 1) split = 1;
-    if (split > 64) split = 64;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_jobs * split, 4)), dim3(256), 0, s, ts->d_jobs, n_jobs, split,
-                       v.act, v.Np, 1.0f / loss_scale, g_base, g_head, g_sem);
+                       v.act, n_tiles, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem);
     rc = launch_status("wgrad_kernel");
     if (rc) return rc;
     // hash-table gradient
