@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) traverse_kernel(int32_t n_rays, const flo
             const float this_tmin = fmaxf(t_sorted[i], near_plane);
             const float this_tmax = fminf(t_sorted[i + 1], far_plane);
             if (this_tmin >= this_tmax) continue;
-            march_segment(org, dir, inv, this_tmin, this_tmax, aabbs + level * 6, res, binaries + level * cells,
+            march_segment(org, dir, inv, this_tmin, this_tmax, aabbs + level * 6, res, ByteGrid{binaries + level * cells},
                           step_size, cone_angle, limit, st, sink);
         }
         if (terminate_planes) terminate_planes[tid] = st.t_last;

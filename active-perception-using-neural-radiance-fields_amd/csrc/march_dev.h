@@ -62,13 +62,24 @@ struct MarchState {
     int32_t n_samples;
 };
 
-// March one [this_tmin, this_tmax] segment of one grid level.  `binaries` points at that level's
-// [X,Y,Z] byte grid.  Returns through `st`; `sink.sample(t_last, t_next, continuous)` per sample.
-template <class Sink>
+// Occupancy accessors: the byte grid exactly as `estimator.binaries` ([X,Y,Z] bools), or a bit-packed copy
+// (bit `cell & 31` of word `cell >> 5`), e.g. staged in LDS.
+struct ByteGrid {
+    const uint8_t *__restrict__ p;
+    __device__ __forceinline__ bool operator()(int64_t cell) const { return p[cell] != 0; }
+};
+struct BitGrid {
+    const uint32_t *p;
+    __device__ __forceinline__ bool operator()(int64_t cell) const { return (p[cell >> 5] >> (cell & 31)) & 1u; }
+};
+
+// March one [this_tmin, this_tmax] segment of one grid level.  `occupied(cell)` answers for that level's
+// [X,Y,Z] grid.  Returns through `st`; `sink.sample(t_last, t_next, continuous)` per sample.
+template <class Sink, class Occ>
 __device__ __forceinline__ void march_segment(const F3 org, const F3 dir, const F3 inv,
                                               float this_tmin, float this_tmax,
                                               const float *__restrict__ ab, const I3 res,
-                                              const uint8_t *__restrict__ binaries,
+                                              const Occ occupied,
                                               float step_size, float cone_angle, int32_t limit,
                                               MarchState &st, Sink &sink) {
     const float eps = 1e-6f;
@@ -112,7 +123,7 @@ __device__ __forceinline__ void march_segment(const F3 org, const F3 dir, const 
         float t_traverse = fminf(tdist.x, fminf(tdist.y, tdist.z));
         t_traverse = fminf(t_traverse, this_tmax);
         const int64_t cell = (int64_t)cur.x * res.y * res.z + (int64_t)cur.y * res.z + cur.z;
-        if (!binaries[cell]) {
+        if (!occupied(cell)) {
             if (step_size <= 0.0f) {
                 st.t_last = t_traverse;
             } else {

@@ -20,6 +20,8 @@
 namespace mnf {
 
 constexpr int kRayThreads = 256;
+constexpr int kMarchThreads = 1024;            // one bit-packed occupancy grid in LDS shared by 16 waves
+constexpr int kMaxGridWords = 16384;           // 64 KB of LDS = 524 288 cells (largest reference grid: 396 900)
 
 struct RenderWs {
     // per ray
@@ -30,6 +32,7 @@ struct RenderWs {
     int32_t *alive_count, *n_samples, *iter_samples, *active;
     // global
     int32_t *n_cols, *any_active;
+    uint32_t *bitgrid;   // bit-packed copy of the occupancy grid (built once per call)
     // per column
     int32_t *col_ray;
     float *col_ts, *col_te, *col_srgb, *col_sem;
@@ -57,6 +60,7 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     p = take(n_views * 4); if (ws) ws->iter_samples = (int32_t *)p;
     p = take(n_views * 4); if (ws) ws->active = (int32_t *)p;
     p = take(256); if (ws) { ws->n_cols = (int32_t *)p; ws->any_active = (int32_t *)p + 1; }
+    p = take(kMaxGridWords * 4); if (ws) ws->bitgrid = (uint32_t *)p;
     p = take(col_cap * 4); if (ws) ws->col_ray = (int32_t *)p;
     p = take(col_cap * 4); if (ws) ws->col_ts = (float *)p;
     p = take(col_cap * 4); if (ws) ws->col_te = (float *)p;
@@ -140,14 +144,29 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
     return v;
 }
 
-// utils.py:674-696: one traversal of <= n_samples steps per alive ray (over-allocated mode of grid.cu:364-404)
-__global__ void __launch_bounds__(kRayThreads) round_march_kernel(int64_t n_rays, int32_t rays_per_view,
-                                                                  const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                                  const uint8_t *__restrict__ binaries, I3 res,
-                                                                  float a0, float a1, float a2, float a3, float a4, float a5,
-                                                                  float far_plane, float step_size, float cone_angle, RenderWs ws) {
-    __shared__ int s_wave_tot[kRayThreads / 64];
+// bit-pack the [X,Y,Z] byte grid once per call: word w holds cells 32w .. 32w+31
+__global__ void __launch_bounds__(256) pack_grid_kernel(const uint8_t *__restrict__ binaries, int64_t cells, uint32_t *__restrict__ bits, int n_words) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t v = 0;
+    for (int b = 0; b < 32; ++b) {
+        const int64_t c = (int64_t)w * 32 + b;
+        if (c < cells && binaries[c]) v |= 1u << b;
+    }
+    bits[w] = v;
+}
+
+// utils.py:674-696: one traversal of <= n_samples steps per alive ray (over-allocated mode of grid.cu:364-404).
+// The occupancy grid is read from a bit-packed copy staged in LDS (<= 64 KB) once per workgroup.
+template <bool LDS_GRID>
+__global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_rays, int32_t rays_per_view,
+                                                                    const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                                    const uint8_t *__restrict__ binaries, I3 res, int n_words,
+                                                                    float a0, float a1, float a2, float a3, float a4, float a5,
+                                                                    float far_plane, float step_size, float cone_angle, RenderWs ws) {
+    __shared__ int s_wave_tot[kMarchThreads / 64];
     __shared__ int s_base;
+    __shared__ uint32_t s_bits[LDS_GRID ? kMaxGridWords : 1];
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool go = false;
@@ -163,10 +182,15 @@ __global__ void __launch_bounds__(kRayThreads) round_march_kernel(int64_t n_rays
     __syncthreads();
     if (threadIdx.x == 0) {
         int tot = 0;
-        for (int w = 0; w < kRayThreads / 64; ++w) tot += s_wave_tot[w];
-        s_base = tot ? atomicAdd(ws.n_cols, tot) : 0;
+        for (int w = 0; w < kMarchThreads / 64; ++w) tot += s_wave_tot[w];
+        s_base = tot ? atomicAdd(ws.n_cols, tot) : -1;
     }
     __syncthreads();
+    if (s_base < 0) return;   // uniform: no ray of this workgroup marches this round
+    if (LDS_GRID) {
+        for (int i = threadIdx.x; i < n_words; i += kMarchThreads) s_bits[i] = ws.bitgrid[i];
+        __syncthreads();
+    }
     if (!go) return;
     int col0 = s_base + incl - ns;
     for (int w = 0; w < wave; ++w) col0 += s_wave_tot[w];
@@ -181,8 +205,10 @@ __global__ void __launch_bounds__(kRayThreads) round_march_kernel(int64_t n_rays
     if (ws.hit[r]) {   // single grid level: the only interval is [t_min, t_max] (grid.cu:125-151 with n_grids == 1)
         const float this_tmin = fmaxf(ws.t_min[r], near_plane);
         const float this_tmax = fminf(ws.t_max[r], far_plane);
-        if (this_tmin < this_tmax)
-            march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, binaries, step_size, cone_angle, ns, st, sink);
+        if (this_tmin < this_tmax) {
+            if (LDS_GRID) march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, BitGrid{s_bits}, step_size, cone_angle, ns, st, sink);
+            else march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, ByteGrid{binaries}, step_size, cone_angle, ns, st, sink);
+        }
     }
     for (int k = st.n_samples; k < ns; ++k) ws.col_ray[col0 + k] = -1;   // unused columns of this ray's allocation
     ws.col0[r] = col0;
@@ -460,6 +486,11 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     const int32_t min_samples = opts->cone_angle == 0.f ? 1 : 4;                      // utils.py:645
     const float opc_thre = 1.0f - opts->early_stop_eps;                                // utils.py:664
 
+    const int64_t cells = (int64_t)res_x * res_y * res_z;
+    const int n_words = (int)ceil_div(cells, 32);
+    const bool lds_grid = n_words <= kMaxGridWords;
+    if (lds_grid)
+        hipLaunchKernelGGL(pack_grid_kernel, dim3((int)ceil_div(n_words, 256)), dim3(256), 0, s, binaries, cells, ws.bitgrid, n_words);
     hipLaunchKernelGGL(init_kernel, dim3(ray_blocks), dim3(kRayThreads), 0, s, n_rays, opts->rays_per_view, C, rays_o, rays_d,
                        ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], opts->near_plane, ws, out);
     int rc = launch_status("init_kernel");
@@ -479,9 +510,14 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
             MNF_HIP(hipStreamSynchronize(s));
             if (!any) break;
         }
-        hipLaunchKernelGGL(round_march_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,
-                           opts->rays_per_view, rays_o, rays_d, binaries, res, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
-                           opts->far_plane, opts->render_step_size, opts->cone_angle, ws);
+        if (lds_grid)
+            hipLaunchKernelGGL(round_march_kernel<true>, dim3((int)ceil_div(n_rays, kMarchThreads)), dim3(kMarchThreads), 0, s, n_rays,
+                               opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
+                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws);
+        else
+            hipLaunchKernelGGL(round_march_kernel<false>, dim3((int)ceil_div(n_rays, kMarchThreads)), dim3(kMarchThreads), 0, s, n_rays,
+                               opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
+                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws);
         profile_mark(s, true);
         rc = launch_field(f, io, false, s);
         profile_mark(s, false);
