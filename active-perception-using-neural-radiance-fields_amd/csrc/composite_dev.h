@@ -1,0 +1,191 @@
+// Volumetric compositing of one render round, fused into the field kernel's epilogue (mode 2).
+//
+// Reference semantics: perception/models/utils.py:704-757 (+ :984-999 for the probabilistic variant) on top of
+// perception/nerfacc/nerfacc/volrend.py:258-267, :361-365 — per ray: transmittance from the exclusive sum of
+// sigma*dt carried by `1 - opacity` of the previous rounds, alpha threshold, weighted sums of rgb / depth / the 29
+// raw semantic logits, variance terms against the post-round running means, ray retirement.
+//
+// The tile layout guarantees that a ray's samples are consecutive lanes of ONE wave (lane = sample), so every
+// per-ray sum is a segmented scan over lanes (the reference's packed exclusive_sum / index_add_ pair), and the
+// per-sample rgb / sigma / logits never leave registers.
+#pragma once
+#include "field_dev.h"
+
+namespace mnf {
+
+// inclusive segmented scan over the 64 lanes of a wave; `head` marks the first lane of every segment
+// (`maxlen` = wave-uniform upper bound of the segment length: only ceil(log2(maxlen)) steps are needed)
+template <int N>
+__device__ __forceinline__ void seg_scan64(float (&v)[N], bool head, int lane, int maxlen) {
+    bool f = head;
+#pragma unroll 1
+    for (int d = 1; d < maxlen; d <<= 1) {
+        const int fu = __shfl_up((int)f, d, 64);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float t = __shfl_up(v[k], d, 64);
+            if (lane >= d && !f) v[k] += t;
+        }
+        if (lane >= d) f = f || (fu != 0);
+    }
+}
+
+// the same over each 32-lane half independently (MFMA layout: column c = lane & 31)
+__device__ __forceinline__ void seg_scan32(f32x16 &v, bool head, int c, int maxlen) {
+    bool f = head;
+    const int lim = maxlen < 32 ? maxlen : 32;
+#pragma unroll 1
+    for (int d = 1; d < lim; d <<= 1) {
+        const int fu = __shfl_up((int)f, d, 32);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float t = __shfl_up(v[k], d, 32);
+            if (c >= d && !f) v[k] += t;
+        }
+        if (c >= d) f = f || (fu != 0);
+    }
+}
+
+// Wave-uniform counters carried across the tiles a wave processes and flushed with ONE atomic each at the end
+// (same-address atomics serialise at ~12 ns apiece: one per tile would cost more than the compositing itself).
+struct WaveCounters {
+    int view = -1, alive = 0;
+    float kept = 0.f, marched = 0.f;
+};
+
+__device__ __forceinline__ void flush_alive(const FusedRender &fr, WaveCounters &wc, int lane) {
+    if (lane == 0 && wc.view >= 0 && wc.alive > 0) atomicAdd(&fr.alive_count[wc.view], wc.alive);
+    wc.alive = 0;
+}
+
+__device__ __forceinline__ void flush_counters(const FusedRender &fr, WaveCounters &wc, int lane) {
+    flush_alive(fr, wc, lane);
+    if (lane == 0) {
+        if (wc.kept > 0.f) atomicAdd(fr.totals, (unsigned long long)(wc.kept + 0.5f));
+        if (wc.marched > 0.f) atomicAdd(fr.totals + 1, (unsigned long long)(wc.marched + 0.5f));
+    }
+    wc.kept = 0.f; wc.marched = 0.f;
+}
+
+struct TileSample {     // this lane's sample (lane = sample)
+    int ray;            // -1: unused column
+    int stride;         // wave-uniform: columns per ray slot in this tile (upper bound of a run length)
+    bool valid;
+    float ts, te;
+    float opac0;        // opacity of the ray before this round (prefetched)
+};
+
+__device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, int lane, const TileSample &sm,
+                                                float sigma, const float (&rgb)[3], const f32x16 (&sem)[CT], WaveCounters &wc) {
+    const int c = lane & 31, h = lane >> 5;
+    // run structure from the per-column ray ids: valid columns of a ray are consecutive lanes
+    const int prev_ray = __shfl_up(sm.ray, 1, 64);
+    const bool head = lane == 0 || prev_ray != sm.ray || sm.ray < 0;
+    const unsigned long long heads = __ballot(head);
+    const bool tail = sm.ray >= 0 && (lane == 63 || ((heads >> (lane + 1)) & 1ull));
+    const bool owner = sm.ray >= 0 && head;                            // one bookkeeping lane per ray
+    // lane of this run's tail: first head bit above this lane, minus one
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int tail_lane = above ? lane + (__ffsll(above) - 1) : 63;
+    const int maxlen = sm.stride;
+    // ---- weights: w = exp(-excl_sum(sigma*dt)) * (1 - opacity_before) * alpha ----
+    const float sdt = sm.valid ? sigma * (sm.te - sm.ts) : 0.0f;
+    float sc[1] = {sdt};
+    seg_scan64(sc, head, lane, maxlen);
+    const float excl = sc[0] - sdt;
+    const float alpha = 1.0f - expf(-sdt);
+    const float opac0 = sm.opac0;
+    const float w = expf(-excl) * (1.0f - opac0) * alpha;               // volrend.py:258-267, :361-365; utils.py:712
+    const bool keep = sm.valid && !(fr.alpha_thre > 0.f && !(alpha >= fr.alpha_thre));   // utils.py:714-725
+    const float wk = keep ? w : 0.0f;
+    const float tmid = (sm.ts + sm.te) / 2.0f;
+    // ---- per-ray sums of the lane=sample quantities ----
+    float acc5[7] = {wk, wk * rgb[0], wk * rgb[1], wk * rgb[2], wk * tmid, keep ? 1.0f : 0.0f, sm.valid ? 1.0f : 0.0f};
+    seg_scan64(acc5, head, lane, maxlen);
+    float tot[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) tot[k] = __shfl(acc5[k], tail_lane, 64);
+    const int cnt = (int)(tot[6] + 0.5f);                              // samples of this ray in this round
+    float c_prev[3] = {0.f, 0.f, 0.f}, d_prev = 0.f;
+    if (sm.ray >= 0 && (owner || fr.probabilistic)) {
+        c_prev[0] = fr.rgb[3 * sm.ray]; c_prev[1] = fr.rgb[3 * sm.ray + 1]; c_prev[2] = fr.rgb[3 * sm.ray + 2];
+        d_prev = fr.depth[sm.ray];
+    }
+    const float c_new[3] = {c_prev[0] + tot[1], c_prev[1] + tot[2], c_prev[2] + tot[3]};
+    const float d_new = d_prev + tot[4];
+    const float o_new = opac0 + tot[0];
+    // ---- variance against the post-round running means (utils.py:984-999) ----
+    if (fr.probabilistic) {
+        const float e0 = rgb[0] - c_new[0], e1 = rgb[1] - c_new[1], e2 = rgb[2] - c_new[2], ed = tmid - d_new;
+        float var4[4] = {wk * (e0 * e0), wk * (e1 * e1), wk * (e2 * e2), wk * (ed * ed)};
+        seg_scan64(var4, head, lane, maxlen);
+        float vt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vt[k] = __shfl(var4[k], tail_lane, 64);
+        if (owner) {
+            fr.rgb_var[3 * sm.ray] += vt[0]; fr.rgb_var[3 * sm.ray + 1] += vt[1]; fr.rgb_var[3 * sm.ray + 2] += vt[2];
+            fr.depth_var[sm.ray] += vt[3];
+        }
+    }
+    // ---- semantic logits: weights into MFMA layout (column c of tile ct <-> sample lane 32 ct + c) ----
+    f32x16 x0;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int src = 32 * ct + c;
+        const float wm = __shfl(wk, src, 64);
+        const bool hm = __shfl((int)head, src, 64) != 0;
+        const int raym = __shfl(sm.ray, src, 64);
+        const bool tm = __shfl((int)tail, src, 64) != 0;
+        f32x16 x;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = sem[ct][k] * wm;
+        if (ct == 1) {
+            // a run that started in columns 0..31 continues into column 32: carry its partial sums across
+            const bool cont = __shfl((int)head, 32, 64) == 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float cv = __shfl(x0[k], 31 + 32 * h, 64);
+                if (cont && c == 0) x[k] += cv;
+            }
+        }
+        seg_scan32(x, hm, c, maxlen);
+        if (ct == 0) x0 = x;
+        if (tm) {                                            // the run's last column owns the totals
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
+                if (row < C) fr.sem[(int64_t)raym * C + row] += x[k];
+            }
+        }
+    }
+    // ---- per-ray bookkeeping by the owner lane ----
+    bool still_alive = false;
+    int view = -1;
+    if (owner) {
+        view = sm.ray / fr.rays_per_view;
+        fr.rgb[3 * sm.ray] = c_new[0]; fr.rgb[3 * sm.ray + 1] = c_new[1]; fr.rgb[3 * sm.ray + 2] = c_new[2];
+        fr.acc[sm.ray] = o_new; fr.depth[sm.ray] = d_new;
+        still_alive = (o_new <= fr.opc_thre) && (cnt == fr.n_samples[view]);   // utils.py:751-756
+        fr.alive[sm.ray] = still_alive;
+    }
+    // survivors per view and sample totals: accumulated per wave, flushed when the view changes / after the last tile
+    const unsigned long long m_owner = __ballot(owner);
+    if (m_owner) {
+        const int first = __ffsll((unsigned long long)m_owner) - 1;
+        const int view0 = __shfl(view, first, 64);
+        const bool uniform = __ballot(owner && view != view0) == 0;
+        const unsigned long long m_alive = __ballot(still_alive);
+        if (uniform) {
+            if (wc.view != view0) { flush_alive(fr, wc, lane); wc.view = view0; }
+            wc.alive += __popcll(m_alive);
+        } else if (still_alive) {
+            atomicAdd(&fr.alive_count[view], 1);
+        }
+        float kept = owner ? tot[5] : 0.0f, marched = owner ? tot[6] : 0.0f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { kept += __shfl_xor(kept, d, 64); marched += __shfl_xor(marched, d, 64); }
+        wc.kept += kept; wc.marched += marched;
+    }
+}
+
+}  // namespace mnf

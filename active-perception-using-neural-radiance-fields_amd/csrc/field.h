@@ -38,6 +38,19 @@ struct mnf_field_s {
 
 namespace mnf {
 
+// Per-round volumetric compositing fused into the field kernel's epilogue (mode 2): the renderer's tiles hold
+// `nslots` rays x `stride` columns (a ray never straddles a 64-column tile), described by one header word per tile.
+struct FusedRender {
+    const int32_t *tile_hdr;      // [tiles]: columns per ray slot (upper bound of a run length)
+    uint8_t *alive;               // [rays]
+    int32_t *alive_count;         // [views] survivors of this round
+    const int32_t *n_samples;     // [views] this round's per-ray sample budget
+    float *rgb, *acc, *depth, *sem, *rgb_var, *depth_var;   // running accumulators (the call's outputs)
+    unsigned long long *totals;   // [2]: kept samples, evaluated samples
+    int32_t rays_per_view, probabilistic;
+    float alpha_thre, opc_thre;
+};
+
 // What the fused kernel reads / writes.  mode 0: explicit positions+directions; mode 1: packed samples
 // with int64 ray indices; mode 2: renderer columns (int32 ray id, -1 = unused column).
 struct FieldIO {
@@ -51,8 +64,8 @@ struct FieldIO {
     const int32_t *n_dev;                    // mode 2: number of columns (device)
     // outputs: user layout (modes 0,1) ...
     float *rgb, *density, *sem;
-    // ... or the renderer's padded per-column layout (mode 2): float4 {sigma,r,g,b}, sem[32]
-    float *col_srgb, *col_sem;
+    // ... or, in mode 2, composites straight into the renderer's per-ray accumulators
+    FusedRender fr;
 };
 
 struct TrainBuf;

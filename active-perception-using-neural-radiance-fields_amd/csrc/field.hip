@@ -22,7 +22,7 @@
 //
 // Precision: fp16 parameters, fp16 features/activations at every matrix-product input, fp32
 // accumulation, fp32 outputs (oracle/field.py states the same model).
-#include "field_dev.h"
+#include "composite_dev.h"
 
 #include <cmath>
 #include <cstring>
@@ -49,11 +49,13 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     for (int i = threadIdx.x; i < kBlocks * 64; i += kThreads) s_w[i] = args.frags[i];
     __syncthreads();
 
+    WaveCounters wc;
     for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWavesPerBlock) {
         // ---- this lane's sample ----
         const int64_t col = tile * kWaveSamples + lane;
         bool valid = col < n;
         float pos[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 1.f};
+        TileSample tsm = {-1, 64, false, 0.f, 0.f, 0.f};
         if (MODE == 0) {
             if (valid) {
 #pragma unroll
@@ -62,9 +64,9 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
                     for (int d = 0; d < 3; ++d) dir[d] = args.io.directions[3 * col + d];
             }
-        } else {
+        } else if (MODE == 1) {
             int64_t ray = -1;
-            if (valid) ray = (MODE == 1) ? args.io.ray_idx64[col] : (int64_t)args.io.col_ray[col];
+            if (valid) ray = args.io.ray_idx64[col];
             valid = ray >= 0;
             if (valid) {
                 const float tsum = args.io.t_starts[col] + args.io.t_ends[col];
@@ -73,6 +75,22 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                     dir[d] = args.io.rays_d[3 * ray + d];
                     // utils.py:92 / :614: origins + dirs * (t_starts + t_ends) / 2.0
                     pos[d] = args.io.rays_o[3 * ray + d] + (dir[d] * tsum) / 2.0f;
+                }
+            }
+        } else {
+            // renderer tile: column -> ray id (-1: unused); the runs of equal ids are the rays of this tile
+            tsm.stride = args.io.fr.tile_hdr[tile];
+            tsm.ray = args.io.col_ray[col];
+            tsm.ts = args.io.t_starts[col]; tsm.te = args.io.t_ends[col];
+            valid = tsm.ray >= 0;
+            tsm.valid = valid;
+            if (valid) {
+                tsm.opac0 = args.io.fr.acc[tsm.ray];
+                const float tsum = tsm.ts + tsm.te;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    dir[d] = args.io.rays_d[3 * (int64_t)tsm.ray + d];
+                    pos[d] = args.io.rays_o[3 * (int64_t)tsm.ray + d] + (dir[d] * tsum) / 2.0f;   // utils.py:614
                 }
             }
         }
@@ -223,11 +241,10 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             rgb[k] = 1.0f / (1.0f + expf(-(h ? t1 : t0)));   // ngp.py:211-212
         }
         if (MODE == 2) {
-            if (valid) {
-                float4 v = {sigma, rgb[0], rgb[1], rgb[2]};
-                reinterpret_cast<float4 *>(args.io.col_srgb)[col] = v;
-            }
-        } else if (col < n) {
+            fused_composite(args.io.fr, args.C, lane, tsm, sigma, rgb, out_sem, wc);
+            continue;
+        }
+        if (col < n) {
             if (args.io.density) args.io.density[col] = sigma;
             if (args.io.rgb) { args.io.rgb[3 * col] = rgb[0]; args.io.rgb[3 * col + 1] = rgb[1]; args.io.rgb[3 * col + 2] = rgb[2]; }
         }
@@ -235,17 +252,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int64_t scol = tile * kWaveSamples + ct * 32 + (lane & 31);
-            // validity of that column = validity of the lane that owns it
-            const bool svalid = __shfl((int)valid, ct * 32 + (lane & 31), 64) != 0;
-            if (MODE == 2) {
-                if (!svalid) continue;
-                float4 *dst = reinterpret_cast<float4 *>(args.io.col_sem + scol * 32);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 v = {out_sem[ct][4 * g], out_sem[ct][4 * g + 1], out_sem[ct][4 * g + 2], out_sem[ct][4 * g + 3]};
-                    dst[2 * g + h] = v;
-                }
-            } else if (args.io.sem && scol < n) {
+            if (args.io.sem && scol < n) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -256,6 +263,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             }
         }
     }
+    if (MODE == 2) flush_counters(args.io.fr, wc, lane);
 }
 
 // ------------------------------------------------------------------ parameter preparation kernels

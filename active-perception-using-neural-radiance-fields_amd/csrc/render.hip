@@ -27,7 +27,7 @@ struct RenderWs {
     // per ray
     float *near_plane, *t_min, *t_max;
     int32_t *col0, *cnt;
-    uint8_t *alive, *hit, *marched;
+    uint8_t *alive, *hit;
     // per view
     int32_t *alive_count, *n_samples, *iter_samples, *active;
     // global
@@ -35,7 +35,8 @@ struct RenderWs {
     uint32_t *bitgrid;   // bit-packed copy of the occupancy grid (built once per call)
     // per column
     int32_t *col_ray;
-    float *col_ts, *col_te, *col_srgb, *col_sem;
+    float *col_ts, *col_te;
+    int32_t *tile_hdr;   // per 64-column tile: stride | nslots << 8
     int64_t col_cap;
 };
 
@@ -43,7 +44,9 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_view) {
     const int64_t n_views = n_rays / rays_per_view;
-    const int64_t col_cap = 4 * n_rays;
+    // columns of one round: a tile of 64 holds floor(64/stride) rays of `stride` columns, so it is at least half
+    // used; n_alive*stride <= max(R, 4*n_alive) <= 4R (utils.py:670) -> <= 8R, plus one partial tile per workgroup
+    const int64_t col_cap = 8 * n_rays + 64 * (n_rays / kMarchThreads + 2);
     size_t off = 0;
     auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += align_up(bytes); return p; };
     char *p;
@@ -54,7 +57,6 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     p = take(n_rays * 4); if (ws) ws->cnt = (int32_t *)p;
     p = take(n_rays); if (ws) ws->alive = (uint8_t *)p;
     p = take(n_rays); if (ws) ws->hit = (uint8_t *)p;
-    p = take(n_rays); if (ws) ws->marched = (uint8_t *)p;
     p = take(n_views * 4); if (ws) ws->alive_count = (int32_t *)p;
     p = take(n_views * 4); if (ws) ws->n_samples = (int32_t *)p;
     p = take(n_views * 4); if (ws) ws->iter_samples = (int32_t *)p;
@@ -64,8 +66,7 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     p = take(col_cap * 4); if (ws) ws->col_ray = (int32_t *)p;
     p = take(col_cap * 4); if (ws) ws->col_ts = (float *)p;
     p = take(col_cap * 4); if (ws) ws->col_te = (float *)p;
-    p = take(col_cap * 16); if (ws) ws->col_srgb = (float *)p;
-    p = take(col_cap * 128); if (ws) ws->col_sem = (float *)p;
+    p = take(col_cap / 64 * 4); if (ws) ws->tile_hdr = (int32_t *)p;
     if (ws) ws->col_cap = col_cap;
     return (int64_t)off;
 }
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(256) round_prep_kernel(int32_t n_views, int32_
             act = 1;
         }
         ws.active[v] = act;
-        ws.alive_count[v] = 0;   // re-counted by composite_kernel; rays of inactive views are never marched again
+        ws.alive_count[v] = 0;   // re-counted by the fused compositing epilogue; rays of inactive views are never marched again
         any |= act;
     }
     if (any) atomicOr(&s_any, 1);
@@ -128,10 +129,10 @@ __global__ void __launch_bounds__(256) round_prep_kernel(int32_t n_views, int32_
 }
 
 struct RoundSink {
-    int32_t *col_ray; float *col_ts, *col_te;
-    int32_t col0, ray;
+    float *col_ts, *col_te;
+    int32_t col0;
     __device__ __forceinline__ void sample(float t_last, float t_next, bool, int32_t k) {
-        col_ray[col0 + k] = ray; col_ts[col0 + k] = t_last; col_te[col0 + k] = t_next;
+        col_ts[col0 + k] = t_last; col_te[col0 + k] = t_next;
     }
 };
 
@@ -164,8 +165,8 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
                                                                     const uint8_t *__restrict__ binaries, I3 res, int n_words,
                                                                     float a0, float a1, float a2, float a3, float a4, float a5,
                                                                     float far_plane, float step_size, float cone_angle, RenderWs ws) {
-    __shared__ int s_wave_tot[kMarchThreads / 64];
-    __shared__ int s_base;
+    __shared__ int s_wave_tot[kMarchThreads / 64], s_wave_max[kMarchThreads / 64];
+    __shared__ int s_base, s_stride, s_total;
     __shared__ uint32_t s_bits[LDS_GRID ? kMaxGridWords : 1];
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,15 +176,28 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
         const int v = (int)(r / rays_per_view);
         go = ws.alive[r] && ws.active[v];
         ns = go ? ws.n_samples[v] : 0;
-        ws.marched[r] = go;
     }
-    const int incl = wave_inclusive_scan(ns, lane);
-    if (lane == 63) s_wave_tot[wave] = incl;
+    // Column allocation.  All marching rays of the workgroup get `stride` = the largest per-ray budget in the
+    // workgroup (budgets are per view, so almost always uniform); a 64-column tile holds cap = 64/stride rays, so no
+    // ray straddles a tile and the field kernel can composite a ray inside one wave.  Ray with rank k among the
+    // workgroup's marching rays -> tile k / cap, columns (k % cap) * stride ...
+    int wmax = ns;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    const int incl = wave_inclusive_scan(go ? 1 : 0, lane);
+    if (lane == 63) { s_wave_tot[wave] = incl; s_wave_max[wave] = wmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < kMarchThreads / 64; ++w) tot += s_wave_tot[w];
-        s_base = tot ? atomicAdd(ws.n_cols, tot) : -1;
+        int tot = 0, smax = 0;
+        for (int w = 0; w < kMarchThreads / 64; ++w) { tot += s_wave_tot[w]; smax = max(smax, s_wave_max[w]); }
+        s_stride = smax;
+        if (tot) {
+            const int cap = 64 / smax;
+            s_base = atomicAdd(ws.n_cols, ((tot + cap - 1) / cap) * 64);
+        } else {
+            s_base = -1;
+        }
+        s_total = tot;
     }
     __syncthreads();
     if (s_base < 0) return;   // uniform: no ray of this workgroup marches this round
@@ -192,8 +206,16 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
         __syncthreads();
     }
     if (!go) return;
-    int col0 = s_base + incl - ns;
-    for (int w = 0; w < wave; ++w) col0 += s_wave_tot[w];
+    const int stride = s_stride, cap = 64 / stride;
+    int k = incl - 1;
+    for (int w = 0; w < wave; ++w) k += s_wave_tot[w];
+    const int tile_local = k / cap, slot = k - tile_local * cap;
+    const int col0 = s_base + tile_local * 64 + slot * stride;
+    if (slot == 0) {   // the first ray of a tile also describes the tile and blanks the columns no ray owns
+        const int nslots = min(cap, s_total - tile_local * cap);
+        ws.tile_hdr[(s_base >> 6) + tile_local] = stride;
+        for (int k = nslots * stride; k < 64; ++k) ws.col_ray[s_base + tile_local * 64 + k] = -1;
+    }
 
     const float ab[6] = {a0, a1, a2, a3, a4, a5};
     const F3 org = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
@@ -201,7 +223,7 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
     const F3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
     const float near_plane = ws.near_plane[r];
     MarchState st = {near_plane, false, 0};
-    RoundSink sink = {ws.col_ray, ws.col_ts, ws.col_te, col0, (int32_t)r};
+    RoundSink sink = {ws.col_ts, ws.col_te, col0};
     if (ws.hit[r]) {   // single grid level: the only interval is [t_min, t_max] (grid.cu:125-151 with n_grids == 1)
         const float this_tmin = fmaxf(ws.t_min[r], near_plane);
         const float this_tmax = fminf(ws.t_max[r], far_plane);
@@ -210,103 +232,12 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
             else march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, ByteGrid{binaries}, step_size, cone_angle, ns, st, sink);
         }
     }
-    for (int k = st.n_samples; k < ns; ++k) ws.col_ray[col0 + k] = -1;   // unused columns of this ray's allocation
+    // per-column ray id: the run of this ray's valid samples, -1 for the rest of its slot
+    for (int k = 0; k < stride; ++k) ws.col_ray[col0 + k] = k < st.n_samples ? (int32_t)r : -1;
+    if (st.n_samples == 0) ws.alive[r] = 0;   // left the grid: retired here, the compositing pass never sees it (utils.py:751-756)
     ws.col0[r] = col0;
     ws.cnt[r] = st.n_samples;
     ws.near_plane[r] = st.t_last;   // utils.py:749 near_planes = termination_planes
-}
-
-// utils.py:704-757 (+ :984-999 for the probabilistic variant): composite this round's samples of one ray
-__global__ void __launch_bounds__(kRayThreads) composite_kernel(int64_t n_rays, int32_t rays_per_view, int32_t C,
-                                                                float alpha_thre, float opc_thre, int probabilistic,
-                                                                RenderWs ws, RenderOut out) {
-    __shared__ int s_alive;
-    __shared__ int s_kept;
-    __shared__ int s_marched;
-    if (threadIdx.x == 0) { s_alive = 0; s_kept = 0; s_marched = 0; }
-    __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t r_first = (int64_t)blockIdx.x * blockDim.x;
-    const int64_t r_last = min(r_first + (int64_t)blockDim.x, n_rays) - 1;
-    const bool one_view = (r_first / rays_per_view) == (r_last / rays_per_view);
-    int kept = 0, marched = 0;
-    bool still_alive = false;
-    if (r < n_rays && ws.marched[r]) {
-        const int v = (int)(r / rays_per_view);
-        const int cnt = ws.cnt[r], col0 = ws.col0[r];
-        marched = cnt;
-        float opacity = out.acc[r];
-        const float prefix = 1.0f - opacity;                         // utils.py:712
-        float c0 = out.rgb[3 * r], c1 = out.rgb[3 * r + 1], c2 = out.rgb[3 * r + 2];
-        float depth = out.depth[r];
-        float sem[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) sem[k] = (k < C) ? out.sem[r * C + k] : 0.f;
-        float acc_sdt = 0.f;
-        for (int j = 0; j < cnt; ++j) {
-            const int col = col0 + j;
-            const float ts = ws.col_ts[col], te = ws.col_te[col];
-            const float4 s = reinterpret_cast<const float4 *>(ws.col_srgb)[col];
-            const float sdt = s.x * (te - ts);
-            const float alpha = 1.0f - expf(-sdt);
-            const float w = expf(-acc_sdt) * prefix * alpha;          // volrend.py:258-267, :361-365
-            acc_sdt += sdt;
-            if (alpha_thre > 0.f && !(alpha >= alpha_thre)) continue; // utils.py:714-725
-            ++kept;
-            c0 += w * s.y; c1 += w * s.z; c2 += w * s.w;
-            opacity += w;
-            depth += w * ((ts + te) / 2.0f);
-            const float4 *sp = reinterpret_cast<const float4 *>(ws.col_sem + (int64_t)col * 32);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 t = sp[q];
-                sem[4 * q] += w * t.x; sem[4 * q + 1] += w * t.y; sem[4 * q + 2] += w * t.z; sem[4 * q + 3] += w * t.w;
-            }
-        }
-        if (probabilistic) {
-            // variance terms use the accumulators AFTER this round (running, un-normalised means)
-            float v0 = out.rgb_var[3 * r], v1 = out.rgb_var[3 * r + 1], v2 = out.rgb_var[3 * r + 2], dv = out.depth_var[r];
-            acc_sdt = 0.f;
-            for (int j = 0; j < cnt; ++j) {
-                const int col = col0 + j;
-                const float ts = ws.col_ts[col], te = ws.col_te[col];
-                const float4 s = reinterpret_cast<const float4 *>(ws.col_srgb)[col];
-                const float sdt = s.x * (te - ts);
-                const float alpha = 1.0f - expf(-sdt);
-                const float w = expf(-acc_sdt) * prefix * alpha;
-                acc_sdt += sdt;
-                if (alpha_thre > 0.f && !(alpha >= alpha_thre)) continue;
-                const float d0 = s.y - c0, d1 = s.z - c1, d2 = s.w - c2;
-                v0 += w * (d0 * d0); v1 += w * (d1 * d1); v2 += w * (d2 * d2);
-                const float dd = (ts + te) / 2.0f - depth;
-                dv += w * (dd * dd);
-            }
-            out.rgb_var[3 * r] = v0; out.rgb_var[3 * r + 1] = v1; out.rgb_var[3 * r + 2] = v2; out.depth_var[r] = dv;
-        }
-        out.rgb[3 * r] = c0; out.rgb[3 * r + 1] = c1; out.rgb[3 * r + 2] = c2;
-        out.acc[r] = opacity; out.depth[r] = depth;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) if (k < C) out.sem[r * C + k] = sem[k];
-        still_alive = (opacity <= opc_thre) && (cnt == ws.n_samples[v]);   // utils.py:751-756
-        ws.alive[r] = still_alive;
-        if (!one_view && still_alive) atomicAdd(&ws.alive_count[v], 1);
-    }
-    // block-aggregated counters
-    const unsigned long long m_alive = __ballot(still_alive);
-    int wave_kept = kept, wave_marched = marched;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { wave_kept += __shfl_xor(wave_kept, d, 64); wave_marched += __shfl_xor(wave_marched, d, 64); }
-    if ((threadIdx.x & 63) == 0) {
-        if (one_view && m_alive) atomicAdd(&s_alive, __popcll(m_alive));
-        if (wave_kept) atomicAdd(&s_kept, wave_kept);
-        if (wave_marched) atomicAdd(&s_marched, wave_marched);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (one_view && s_alive) atomicAdd(&ws.alive_count[r_first / rays_per_view], s_alive);
-        if (s_kept) atomicAdd((unsigned long long *)out.total_samples, (unsigned long long)s_kept);
-        if (s_marched) atomicAdd((unsigned long long *)out.total_samples + 1, (unsigned long long)s_marched);
-    }
 }
 
 // utils.py:759-760
@@ -498,7 +429,13 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
 
     FieldIO io = {};
     io.mode = 2; io.rays_o = rays_o; io.rays_d = rays_d; io.col_ray = ws.col_ray; io.t_starts = ws.col_ts; io.t_ends = ws.col_te;
-    io.n_dev = ws.n_cols; io.col_srgb = ws.col_srgb; io.col_sem = ws.col_sem;
+    io.n_dev = ws.n_cols;
+    io.fr.tile_hdr = ws.tile_hdr; io.fr.alive = ws.alive; io.fr.alive_count = ws.alive_count;
+    io.fr.n_samples = ws.n_samples; io.fr.rgb = rgb; io.fr.acc = acc; io.fr.depth = depth; io.fr.sem = sem;
+    io.fr.rgb_var = out.rgb_var; io.fr.depth_var = out.depth_var;
+    io.fr.totals = reinterpret_cast<unsigned long long *>(total_samples);
+    io.fr.rays_per_view = opts->rays_per_view; io.fr.probabilistic = opts->probabilistic;
+    io.fr.alpha_thre = opts->alpha_thre; io.fr.opc_thre = opc_thre;
 
     const int max_rounds = (int)ceil_div(opts->max_samples, min_samples);
     for (int round = 0; round < max_rounds; ++round) {
@@ -519,12 +456,8 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
                                opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
                                opts->far_plane, opts->render_step_size, opts->cone_angle, ws);
         profile_mark(s, true);
-        rc = launch_field(f, io, false, s);
+        rc = launch_field(f, io, false, s);   // field evaluation + compositing + ray retirement of this round
         profile_mark(s, false);
-        if (rc) return rc;
-        hipLaunchKernelGGL(composite_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,
-                           opts->rays_per_view, C, opts->alpha_thre, opc_thre, opts->probabilistic, ws, out);
-        rc = launch_status("render round");
         if (rc) return rc;
     }
     hipLaunchKernelGGL(finalize_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,

@@ -284,8 +284,9 @@ def test_render_test_matches_oracle(scene, fields, prob):
 
 
 def test_render_batched_views_equal_single_calls(scene, fields):
-    """Each group of rays_per_view rays must behave as its own reference call (own round schedule);
-    sync_every must not change results."""
+    """Each group of rays_per_view rays must behave as its own reference call (own round schedule); sync_every must
+    not change results.  Batched and single calls pack rays into different 64-column tiles, so per-ray sums are
+    associated differently: equality is to fp32 rounding (1e-6 relative), not bitwise."""
     from apnrf_amd import render as RD
     hip, _ = fields
     est = H.hip_estimator(scene)
@@ -297,7 +298,9 @@ def test_render_batched_views_equal_single_calls(scene, fields):
         single = RD.render_views(hip, est, o[k * 256:(k + 1) * 256], d[k * 256:(k + 1) * 256], 256, 1024, render_bkgd=bk,
                                  probabilistic=True, sync_every=3, **H.RENDER_KW)
         for key in ("rgb", "acc", "depth", "sem", "rgb_var", "depth_var"):
-            np.testing.assert_array_equal(batched[key][k * 256:(k + 1) * 256].cpu().numpy(), single[key].cpu().numpy(), err_msg=key)
+            np.testing.assert_allclose(batched[key][k * 256:(k + 1) * 256].cpu().numpy(), single[key].cpu().numpy(),
+                                       rtol=2e-6, atol=1e-7, err_msg=key)
+        assert int(batched["total"][0]) > 0
     # rays that miss the grid entirely: zero opacity, background colour, no samples
     far_o = torch.full((64, 3), 100.0, device=DEV)
     far_d = torch.tensor([[0.0, 1.0, 0.0]], device=DEV).repeat(64, 1)
