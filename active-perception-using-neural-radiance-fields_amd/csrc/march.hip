@@ -167,6 +167,23 @@ __global__ void __launch_bounds__(256) raygen_kernel(const float *__restrict__ c
     }
 }
 
+// ------------------------------------------------------------------ planner hand-off
+// scripts/pipeline.py:1043-1049 + planning/planning_funcs.py:243-261: slice the occupancy grids of the ensemble at
+// height index `y_slice`, merge (any member occupied), dilate with a 3x3 box ("symm" boundary == clamped neighbours)
+__global__ void __launch_bounds__(256) planner_map_kernel(const uint8_t *__restrict__ binaries, int n_members, int X, int Y, int Z,
+                                                          int y_slice, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= X * Z) return;
+    const int x = i / Z, z = i % Z;
+    int hit = 0;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dz = -1; dz <= 1; ++dz) {
+            const int xx = min(max(x + dx, 0), X - 1), zz = min(max(z + dz, 0), Z - 1);
+            for (int m = 0; m < n_members; ++m) hit |= binaries[(((int64_t)m * X + xx) * Y + y_slice) * Z + zz];
+        }
+    out[i] = hit ? 1 : 0;
+}
+
 static inline int grid_for(int64_t n, int threads) {
     int64_t b = ceil_div(n, threads);
     return (int)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
@@ -246,4 +263,13 @@ extern "C" int mnf_generate_rays(const float *c2w, int32_t n_views, int32_t widt
     hipLaunchKernelGGL(raygen_kernel, dim3(grid_for((int64_t)n_views * n_pix, 256)), dim3(256), 0, as_stream(stream), c2w,
                        n_views, width, height, focal, pix_idx, n_pix, origins, viewdirs);
     return launch_status("raygen_kernel");
+}
+
+extern "C" int mnf_planner_map(const uint8_t *binaries, int32_t n_members, int32_t res_x, int32_t res_y, int32_t res_z,
+                               int32_t y_slice, int32_t *out_map, mnf_stream_t stream) {
+    MNF_REQUIRE(binaries && out_map, "planner_map: null pointer");
+    MNF_REQUIRE(n_members > 0 && res_x > 0 && res_y > 0 && res_z > 0 && y_slice >= 0 && y_slice < res_y, "planner_map: bad sizes");
+    hipLaunchKernelGGL(planner_map_kernel, dim3(grid_for((int64_t)res_x * res_z, 256)), dim3(256), 0, as_stream(stream), binaries,
+                       n_members, res_x, res_y, res_z, y_slice, out_map);
+    return launch_status("planner_map_kernel");
 }

@@ -188,6 +188,14 @@ int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32
                     float *rgb, float *acc, float *depth, float *sem, float *rgb_var, float *depth_var,
                     int64_t *total_samples, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
 
+/* ---------------------------------------------------------------- planner hand-off
+ * The only perception artefact the planner reads (scripts/pipeline.py:1043-1049, planning/planning_funcs.py:243-261):
+ * binaries [n_members,X,Y,Z] u8 (the ensemble's `estimator.binaries[0]`), sliced at height index y_slice (8 in the
+ * reference), merged over members and dilated by the 3x3 box with symmetric boundary -> out_map [X,Z] int32 (1 = blocked).
+ * The caller clears the cells around the vehicle (planning_funcs.py:262-266) on the host. */
+int mnf_planner_map(const uint8_t *binaries, int32_t n_members, int32_t res_x, int32_t res_y, int32_t res_z,
+                    int32_t y_slice, int32_t *out_map, mnf_stream_t stream);
+
 /* Optional in-library timing of the dominant kernel (the fused field kernel) for bench.py's roofline line:
  * between begin and end every field-kernel launch made by mnf_render_test on this thread is bracketed by a
  * hipEvent pair on the launch stream.  mnf_profile_end synchronises those events and returns the summed

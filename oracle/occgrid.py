@@ -54,3 +54,18 @@ def binarize(occs, occ_thre):
     occs = np.asarray(occs, np.float32)
     thre = min(np.float32(occs[occs >= 0].mean(dtype=np.float32)), np.float32(occ_thre))
     return occs > thre, thre
+
+
+def planner_path_finding_map(binaries_list, current_state_xzy=None, aabb_xzy=None, voxel_grid_size=0.2):
+    """scripts/pipeline.py:1043-1049 + planning/planning_funcs.py:243-266 restated with numpy/scipy:
+    swap axes 2,3 of every estimator's [1,X,Y,Z] grid, stack, squeeze, slice [:, :, 8], merge, 3x3 'symm' dilation."""
+    from scipy import signal
+    vg = np.squeeze(np.array([np.swapaxes(np.asarray(b), 2, 3) for b in binaries_list]))      # [M, X, Z, Y]
+    v_merge = sum(vg[m, :, :, 8].astype(np.int32) for m in range(vg.shape[0]))
+    path = (v_merge > 1e-4).astype(np.int32)
+    path = np.array(signal.convolve2d(path, np.ones((3, 3), int), boundary="symm", mode="same") > 1e-4).astype(np.int32)
+    if current_state_xzy is not None:
+        v = np.array((np.asarray(current_state_xzy)[:3] - np.asarray(aabb_xzy)[:3]) // voxel_grid_size, dtype=int)
+        path[v[1], v[0]] = 0; path[v[1] + 1, v[0]] = 0; path[v[1] - 1, v[0]] = 0
+        path[v[1], v[0] + 1] = 0; path[v[1], v[0] - 1] = 0
+    return path

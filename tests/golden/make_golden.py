@@ -18,17 +18,12 @@ What is captured (all from the reference's own, CPU-runnable code; nothing is re
   vanilla.npz   radiance_fields.mlp.VanillaNeRFRadianceField(2, 64, None, 1, 64) + nerfacc.rendering
                 on BASELINE config 1 (64x64 rays x 32 samples): state_dict, outputs, loss, grads
                 (perception/models/radiance_fields/mlp.py:168-245)
+  dataset.npz   Dataset.update_data + evaluation-mode fetch_data/preprocess on a tiny synthetic set
+                (perception/data_proc/habitat_to_data.py:89-272), same placeholder-module note as raygen.npz
   raygen.npz    Dataset.generate_image_rays + the linspace sub-sampler
                 (perception/data_proc/habitat_to_data.py:274-301, :462-467).  The module imports
                 imageio / cv2 / skimage at top level (unused by this function, absent here); empty
                 placeholder modules are registered for those three names so the import succeeds.
-  orchestration.npz  perception/models/utils.py `render_probablistic_image_with_occgrid_test`,
-                `render_image_with_occgrid_test`, `render_image_with_occgrid_with_depth_guide`
-                executed from the reference's source with the CUDA-only primitives it calls
-                (`_C.ray_aabb_intersect`, `_C.traverse_grids`, `_C.exclusive_sum`, `pack_info`) and
-                the tcnn field bound to the ORACLE's CPU restatements.  This pins ONLY the
-                orchestration logic (round structure, prefix transmittance, alpha threshold,
-                running-mean variance, background, depth normalisation), not the primitives.
 """
 import os
 import sys
@@ -229,8 +224,46 @@ def gen_raygen():
     np.savez_compressed(os.path.join(OUT, "raygen.npz"), **rec)
 
 
+def _stub_modules():
+    for name in ("imageio", "cv2", "skimage", "skimage.io", "skimage.color"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    sk = sys.modules["skimage"]
+    if not hasattr(sk, "io"):
+        sk.io = sys.modules["skimage.io"]; sk.color = sys.modules["skimage.color"]
+
+
+def gen_dataset():
+    """Dataset.update_data / fetch_data (evaluation branch) / preprocess of the reference on a tiny synthetic set
+    (perception/data_proc/habitat_to_data.py:89-272), CPU device."""
+    _stub_modules()
+    import habitat_to_data as h2d
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(5)
+    N, H, W = 3, 6, 8
+    images = rng.integers(0, 256, size=(N, H, W, 3)).astype(np.uint8)
+    depths = rng.random((N, H, W)).astype(np.float32) * 5
+    sems = rng.integers(0, 29, size=(N, H, W))
+    c2w = np.stack([np.eye(4) for _ in range(N)])
+    for i in range(N):
+        c2w[i, :3, :3] = R.from_euler("xyz", rng.random(3) * 2).as_matrix()
+        c2w[i, :3, 3] = rng.random(3) * 4
+    ds = h2d.Dataset(training=False, save_fp="/tmp/_golden_ds", num_rays=None, num_models=2, device="cpu")
+    np.random.seed(0)
+    ds.update_data(images[:2], depths[:2], sems[:2], c2w[:2])
+    ds.update_data(images[2:], depths[2:], sems[2:], c2w[2:])
+    d = ds[2]
+    np.savez_compressed(os.path.join(OUT, "dataset.npz"), images=images, depths=depths, sems=sems, c2w=c2w,
+                        K=ds.K.numpy(), size=np.int64(ds.size), pixels=d["pixels"].numpy(), dep=d["dep"].numpy(),
+                        sem=d["sem"].numpy(), origins=d["rays"].origins.numpy(), viewdirs=d["rays"].viewdirs.numpy(),
+                        color_bkgd=d["color_bkgd"].numpy(), boot0=np.asarray(ds.bootstrap(0)), boot1=np.asarray(ds.bootstrap(1)))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["aabb", "volrend", "occgrid", "query", "vanilla", "raygen"]
+    which = sys.argv[1:] or ["aabb", "volrend", "occgrid", "query", "vanilla", "raygen", "dataset"]
     _enter_reference()
     for w in which:
         globals()["gen_" + w]()

@@ -460,3 +460,68 @@ def test_train_step_matches_oracle(scene):
     with torch.no_grad():                                          # the updated parameters are picked up by the kernels
         rgb2, *_ = RD.render_image_with_occgrid_with_depth_guide(hip, est, RD.Rays(o.to(DEV), d.to(DEV)), render_bkgd=bk.to(DEV), **H.RENDER_KW)
     assert (rgb2 - rgb.detach()).abs().max() > 0
+
+
+# ------------------------------------------------------------------ §8(f) rows: dataset ingest, checkpoints, planner map
+def test_dataset_matches_reference(golden, tmp_path):
+    from apnrf_amd.dataset import Dataset
+    g = golden("dataset")
+    ds = Dataset(training=False, save_fp=str(tmp_path), num_models=2, device=DEV)
+    np.random.seed(0)
+    ds.update_data(g["images"][:2], g["depths"][:2], g["sems"][:2], g["c2w"][:2])
+    ds.update_data(g["images"][2:], g["depths"][2:], g["sems"][2:], g["c2w"][2:])
+    assert len(ds) == int(g["size"])
+    np.testing.assert_array_equal(ds.K.cpu().numpy(), g["K"])
+    np.testing.assert_array_equal(ds.bootstrap(0), g["boot0"])
+    np.testing.assert_array_equal(ds.bootstrap(1), g["boot1"])         # same np.random stream as the reference
+    d = ds[2]                                                           # evaluation branch: image 2, all pixels
+    # uint8 / 255.0 is a torch op on the storage device: the GPU kernel multiplies by the reciprocal (1 ulp from the
+    # CPU golden's true division); the reference itself runs this on its CUDA device
+    np.testing.assert_allclose(d["pixels"].cpu().numpy(), g["pixels"], rtol=2e-7, atol=0)
+    np.testing.assert_array_equal(d["dep"].cpu().numpy(), g["dep"])
+    np.testing.assert_array_equal(d["sem"].cpu().numpy(), g["sem"])
+    np.testing.assert_array_equal(d["rays"].origins.cpu().numpy(), g["origins"])
+    np.testing.assert_array_equal(d["rays"].viewdirs.cpu().numpy(), g["viewdirs"])     # bit-exact rays
+    np.testing.assert_array_equal(d["color_bkgd"].cpu().numpy(), g["color_bkgd"])
+    # training branch: one random image, num_rays random pixels; values must be the gathered pixels of that image
+    ds.training = True
+    ds.update_num_rays(500)
+    t = ds[0]
+    iid, x, y = int(t["image_id"].item()), t["x"].cpu().numpy(), t["y"].cpu().numpy()
+    assert t["pixels"].shape == (500, 3) and t["rays"].origins.shape == (500, 3) and t["color_bkgd"].shape == (3,)
+    np.testing.assert_allclose(t["pixels"].cpu().numpy(), g["images"][iid, y, x].astype(np.float32) / 255.0, rtol=2e-7, atol=0)
+    np.testing.assert_array_equal(t["dep"].cpu().numpy(), g["depths"][iid, y, x])
+    np.testing.assert_array_equal(t["sem"].cpu().numpy(), g["sems"][iid, y, x])
+    ds.training = False
+    full = ds[iid]
+    np.testing.assert_array_equal(t["rays"].viewdirs.cpu().numpy(), full["rays"].viewdirs.cpu().numpy()[y, x])
+
+
+def test_checkpoint_roundtrip_and_planner_map(scene, tmp_path):
+    from apnrf_amd import dataset as DS
+    from oracle import occgrid as OG
+    hip = H.hip_field(scene)
+    est = H.hip_estimator(scene)
+    opt = torch.optim.Adam(hip.parameters(), lr=1e-3, eps=1e-15)
+    path = str(tmp_path / "model.pth")
+    DS.save_checkpoint(path, est, hip, opt)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"occ_grid", "model", "optimizer_state_dict"}                    # pipeline.py:630-635
+    assert ck["occ_grid"].dtype == torch.bool and tuple(ck["occ_grid"].shape) == (1, *scene["res"])
+    assert set(ck["model"]) == {"aabb", "direction_encoding.params", "mlp_base.params", "mlp_head.params", "mlp_sem.params"}
+    sc2 = dict(scene); sc2["params"] = H.S.make_field_params(seed=5)
+    hip2, est2 = H.hip_field(sc2), H.hip_estimator(scene)
+    est2.binaries = torch.zeros_like(est2.binaries)
+    DS.load_checkpoint(path, est2, hip2, map_location=DEV)
+    assert torch.equal(est2.binaries, est.binaries)
+    pos = torch.rand(1000, 3, device=DEV) * 3
+    np.testing.assert_array_equal(hip2.query_density(pos).cpu().numpy(), hip.query_density(pos).cpu().numpy())
+    # planner map of a two-member ensemble
+    rng = np.random.default_rng(2)
+    est2.binaries = torch.from_numpy(rng.random(scene["occ"].shape) > 0.9).to(DEV)
+    a = scene["aabb"]
+    state = np.array([-14.79, -10.60, 1.5]); aabb_xzy = np.array([a[0], a[2], a[1], a[3], a[5], a[4]])
+    got = DS.planner_path_finding_map([est, est2], state, aabb_xzy, 0.2)
+    ref = OG.planner_path_finding_map([est.binaries.cpu().numpy(), est2.binaries.cpu().numpy()], state, aabb_xzy, 0.2)
+    np.testing.assert_array_equal(got, ref)
+    assert got.shape == (scene["res"][0], scene["res"][2]) and 0 < got.mean() < 1
