@@ -44,13 +44,30 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     int64_t n = args.io.n;
     if (MODE == 2) n = *args.io.n_dev;
     const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
-    if ((int64_t)blockIdx.x * kWavesPerBlock >= n_tiles) return;  // uniform per block: nothing to do
+    if (n_tiles == 0) return;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an L2), and
+    // neighbouring tiles hold neighbouring rays that touch the same hash-table lines, so each XCD walks one contiguous
+    // eighth of the tile groups (a group = the 8 tiles of one workgroup pass).  A speed choice only: any placement is
+    // correct.  Grids that are not a multiple of 8 use the plain grid-stride order.
+    const int64_t n_groups = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    int64_t g_first, g_end, g_step;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7;
+        g_first = n_groups * xcd / 8 + (blockIdx.x >> 3);
+        g_end = n_groups * (xcd + 1) / 8;
+        g_step = gridDim.x >> 3;
+    } else {
+        g_first = blockIdx.x; g_end = n_groups; g_step = gridDim.x;
+    }
+    if (g_first >= g_end) return;   // uniform per block: nothing to do
 
     for (int i = threadIdx.x; i < kBlocks * 64; i += kThreads) s_w[i] = args.frags[i];
     __syncthreads();
 
     WaveCounters wc;
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWavesPerBlock) {
+    for (int64_t grp = g_first; grp < g_end; grp += g_step) {
+        const int64_t tile = grp * kWavesPerBlock + wave;
+        if (tile >= n_tiles) break;
         // ---- this lane's sample ----
         const int64_t col = tile * kWaveSamples + lane;
         bool valid = col < n;
