@@ -76,7 +76,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    if world > 1:
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
@@ -85,7 +86,7 @@ def main():
     import __graft_entry__ as G
     if rank == 0:
         G.build()
-    if world > 1:
+    if distributed:
         dist.barrier()
     import helpers as H
     from apnrf_amd import _lib as L
@@ -147,7 +148,7 @@ def main():
     def timed_pass(with_events):
         """K steps bracketed by barrier + synchronize on both sides; returns (seconds, evaluated samples, field ms, launches)."""
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         if with_events:
@@ -159,7 +160,7 @@ def main():
             if isinstance(out, dict):
                 evaluated += out["total"][1]
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -182,9 +183,9 @@ def main():
     field_ms = launches = 0
     if not args.no_kernel_timing:
         _, samples, field_ms, launches = timed_pass(True)
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # the slowest rank defines the step time
         dt = float(t.item())
 
     if rank == 0:
@@ -214,7 +215,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "render800":
             line["cpu_baseline"] = cpu_baseline(scene, scene["poses"], width, height, focal, args.cpu_sample)
         print(json.dumps(line))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 
