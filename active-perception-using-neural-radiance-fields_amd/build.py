@@ -19,6 +19,7 @@ SOURCES = {
     "render.hip": ["-ffp-contract=off"],
     "field.hip": [],
     "train.hip": [],
+    "composite_train.hip": [],
 }
 
 

@@ -1,0 +1,218 @@
+// Train-mode semantic volume rendering on packed samples, forward and backward, one wave per ray.
+//
+// Replaces the chain the reference builds out of torch ops for every training iteration
+// (perception/models/utils.py:362-461 `sem_rendering`): render_weight_from_density (volrend.py:213-267: exclusive_sum,
+// exp, 1-exp), four accumulate_along_rays index_adds (volrend.py:27-66) and, in backward, their autograd twins.
+//
+//   s_i = sigma_i (te_i - ts_i)     T_i = exp(-sum_{j<i} s_j)     alpha_i = 1 - exp(-s_i)     w_i = T_i alpha_i
+//   C = sum w_i c_i + bkgd (1 - A)   A = sum w_i   D = sum w_i (ts_i+te_i)/2 / max(A, eps)   S = sum w_i sem_i
+//
+// Backward, with g_i = dL/dw_i = gC.c_i + gA' + gDn m_i + gS.sem_i:
+//   dL/ds_i = g_i T_i (1 - alpha_i) - sum_{k>i} g_k w_k          (one reverse sweep with a running suffix sum)
+//
+// A wave walks its ray in blocks of 64 samples (lane = sample); the [64 x C] semantic block is staged through LDS with
+// coalesced row-major loads/stores so that neither the per-sample dot product nor the per-class sum strides global memory.
+#include "common.h"
+
+namespace mnf {
+namespace {
+
+constexpr int kMaxClasses = 64;
+constexpr float kEps = 1.1920928955078125e-07f;     // torch.finfo(float32).eps, utils.py:447
+
+__device__ __forceinline__ float wave_inclusive_scan(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Copy n_rows x C floats between row-major global memory and LDS rows of `stride` words (stride odd: conflict-free
+// when lanes later walk one row each).
+template <bool TO_LDS>
+__device__ __forceinline__ void stage_rows(float *__restrict__ lds, float *g, int n_rows, int C, int stride, int lane) {
+    const int n = n_rows * C;
+    int row = lane / C, col = lane - row * C;
+    const int drow = 64 / C, dcol = 64 - drow * C;
+    for (int e = lane; e < n; e += 64) {
+        if (TO_LDS) lds[row * stride + col] = g[e];
+        else g[e] = lds[row * stride + col];
+        row += drow; col += dcol;
+        if (col >= C) { col -= C; ++row; }
+    }
+}
+
+__global__ void __launch_bounds__(64) composite_fwd_kernel(const int64_t *__restrict__ starts, const int64_t *__restrict__ cnts,
+                                                           const float *__restrict__ ts, const float *__restrict__ te,
+                                                           const float *__restrict__ sig, const float *__restrict__ rgb,
+                                                           const float *__restrict__ sem, int C, const float *__restrict__ bkgd,
+                                                           float *__restrict__ o_rgb, float *__restrict__ o_acc,
+                                                           float *__restrict__ o_dep, float *__restrict__ o_sem,
+                                                           float *__restrict__ w_out, float *__restrict__ t_out,
+                                                           float *__restrict__ a_out) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x;
+    const int stride = C | 1;
+    float *w_lds = lds + 64 * stride;
+    const int64_t r = blockIdx.x;
+    const int64_t s0 = starts[r];
+    const int cnt = (int)cnts[r];
+
+    float carry = 0.f, aR = 0.f, aG = 0.f, aB = 0.f, aA = 0.f, aD = 0.f, aS = 0.f;
+    for (int base = 0; base < cnt; base += 64) {
+        const int nv = min(64, cnt - base);
+        const bool valid = lane < nv;
+        const int64_t k = s0 + base + lane;
+        float a = 0.f, b = 0.f, sg = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (valid) {
+            a = ts[k]; b = te[k]; sg = sig[k];
+            c0 = rgb[3 * k]; c1 = rgb[3 * k + 1]; c2 = rgb[3 * k + 2];
+        }
+        if (C > 0) stage_rows<true>(lds, const_cast<float *>(sem) + (s0 + base) * C, nv, C, stride, lane);
+        const float s = sg * (b - a);
+        const float incl = wave_inclusive_scan(s, lane);
+        const float T = __expf(-((incl - s) + carry));
+        const float alpha = 1.f - __expf(-s);
+        const float w = valid ? T * alpha : 0.f;
+        carry += __shfl(incl, 63, 64);
+        if (valid) {
+            w_out[k] = w;
+            if (t_out) t_out[k] = T;
+            if (a_out) a_out[k] = alpha;
+        }
+        aR += w * c0; aG += w * c1; aB += w * c2; aA += w; aD += w * ((a + b) * 0.5f);
+        w_lds[lane] = w;
+        __syncthreads();
+        if (lane < C) {
+            for (int i = 0; i < nv; ++i) aS += w_lds[i] * lds[i * stride + lane];
+        }
+        __syncthreads();
+    }
+    aR = wave_sum(aR); aG = wave_sum(aG); aB = wave_sum(aB); aA = wave_sum(aA); aD = wave_sum(aD);
+    if (lane == 0) {
+        const float bk0 = bkgd ? bkgd[0] : 0.f, bk1 = bkgd ? bkgd[1] : 0.f, bk2 = bkgd ? bkgd[2] : 0.f;
+        o_rgb[3 * r] = aR + bk0 * (1.f - aA);
+        o_rgb[3 * r + 1] = aG + bk1 * (1.f - aA);
+        o_rgb[3 * r + 2] = aB + bk2 * (1.f - aA);
+        o_acc[r] = aA;
+        o_dep[r] = aD / fmaxf(aA, kEps);
+    }
+    if (lane < C) o_sem[r * C + lane] = aS;
+}
+
+__global__ void __launch_bounds__(64) composite_bwd_kernel(const int64_t *__restrict__ starts, const int64_t *__restrict__ cnts,
+                                                           const float *__restrict__ ts, const float *__restrict__ te,
+                                                           const float *__restrict__ sig, const float *__restrict__ rgb,
+                                                           const float *__restrict__ sem, int C, const float *__restrict__ bkgd,
+                                                           const float *__restrict__ w_in, const float *__restrict__ t_in,
+                                                           const float *__restrict__ o_acc,
+                                                           const float *__restrict__ o_dep, const float *__restrict__ g_rgb,
+                                                           const float *__restrict__ g_acc, const float *__restrict__ g_dep,
+                                                           const float *__restrict__ g_sem, float *__restrict__ d_sig,
+                                                           float *__restrict__ d_rgb, float *__restrict__ d_sem) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x;
+    const int stride = C | 1;
+    float *gs_lds = lds + 64 * stride;
+    const int64_t r = blockIdx.x;
+    const int64_t s0 = starts[r];
+    const int cnt = (int)cnts[r];
+    if (cnt == 0) return;
+
+    const float gc0 = g_rgb ? g_rgb[3 * r] : 0.f, gc1 = g_rgb ? g_rgb[3 * r + 1] : 0.f, gc2 = g_rgb ? g_rgb[3 * r + 2] : 0.f;
+    const float A = o_acc[r];
+    const float gD = g_dep ? g_dep[r] : 0.f;
+    const float gDn = gD / fmaxf(A, kEps);
+    float gA = g_acc ? g_acc[r] : 0.f;
+    if (bkgd) gA -= gc0 * bkgd[0] + gc1 * bkgd[1] + gc2 * bkgd[2];
+    if (A >= kEps) gA -= gD * o_dep[r] / A;
+    if (lane < C) gs_lds[lane] = g_sem ? g_sem[r * C + lane] : 0.f;
+    __syncthreads();
+
+    float suffix = 0.f;
+    const int n_blocks = (cnt + 63) / 64;
+    for (int b = n_blocks - 1; b >= 0; --b) {
+        const int base = b * 64;
+        const int nv = min(64, cnt - base);
+        const bool valid = lane < nv;
+        const int64_t k = s0 + base + lane;
+        float a = 0.f, e = 0.f, sg = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, w = 0.f, T = 0.f;
+        if (valid) {
+            a = ts[k]; e = te[k]; sg = sig[k]; w = w_in[k]; T = t_in[k];
+            c0 = rgb[3 * k]; c1 = rgb[3 * k + 1]; c2 = rgb[3 * k + 2];
+        }
+        if (C > 0) stage_rows<true>(lds, const_cast<float *>(sem) + (s0 + base) * C, nv, C, stride, lane);
+        __syncthreads();
+        const float dt = e - a;
+        const float s = sg * dt;
+        const float one_minus_alpha = __expf(-s);
+        float g = gc0 * c0 + gc1 * c1 + gc2 * c2 + gA + gDn * ((a + e) * 0.5f);
+        for (int c = 0; c < C; ++c) g += gs_lds[c] * lds[lane * stride + c];
+        const float gw = valid ? g * w : 0.f;
+        const float gincl = wave_inclusive_scan(gw, lane);
+        const float total = __shfl(gincl, 63, 64);
+        const float ds = g * T * one_minus_alpha - ((total - gincl) + suffix);
+        suffix += total;
+        if (valid) {
+            d_sig[k] = ds * dt;
+            d_rgb[3 * k] = w * gc0; d_rgb[3 * k + 1] = w * gc1; d_rgb[3 * k + 2] = w * gc2;
+        }
+        __syncthreads();
+        for (int c = 0; c < C; ++c) lds[lane * stride + c] = w * gs_lds[c];
+        __syncthreads();
+        if (C > 0) stage_rows<false>(lds, d_sem + (s0 + base) * C, nv, C, stride, lane);
+        __syncthreads();
+    }
+}
+
+size_t lds_bytes(int C) { return (size_t)(64 * (C | 1) + kMaxClasses) * sizeof(float); }
+
+}  // namespace
+}  // namespace mnf
+
+using namespace mnf;
+
+extern "C" int mnf_composite_train_forward(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                           const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                                           const float *sems, int32_t n_classes, int64_t n_samples, const float *bkgd,
+                                           float *out_rgb, float *out_acc, float *out_depth, float *out_sem, float *weights,
+                                           float *trans, float *alphas, mnf_stream_t stream) {
+    if (n_rays == 0) return MNF_OK;
+    MNF_REQUIRE(n_classes >= 0 && n_classes <= kMaxClasses, "composite_train_forward: n_classes %d not in [0, %d]", n_classes,
+                kMaxClasses);
+    MNF_REQUIRE(chunk_starts && chunk_cnts && out_rgb && out_acc && out_depth && (out_sem || n_classes == 0),
+                "composite_train_forward: null pointer");
+    MNF_REQUIRE(n_samples == 0 || (t_starts && t_ends && sigmas && rgbs && weights && (sems || n_classes == 0)),
+                "composite_train_forward: null sample pointer");
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_rays), dim3(64), lds_bytes(n_classes), as_stream(stream), chunk_starts,
+                       chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, n_classes, bkgd, out_rgb, out_acc, out_depth, out_sem,
+                       weights, trans, alphas);
+    return launch_status("composite_fwd_kernel");
+}
+
+extern "C" int mnf_composite_train_backward(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                            const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                                            const float *sems, int32_t n_classes, int64_t n_samples, const float *bkgd,
+                                            const float *weights, const float *trans, const float *out_acc,
+                                            const float *out_depth,
+                                            const float *g_rgb, const float *g_acc, const float *g_depth, const float *g_sem,
+                                            float *d_sigmas, float *d_rgbs, float *d_sems, mnf_stream_t stream) {
+    if (n_rays == 0 || n_samples == 0) return MNF_OK;
+    MNF_REQUIRE(n_classes >= 0 && n_classes <= kMaxClasses, "composite_train_backward: n_classes %d not in [0, %d]", n_classes,
+                kMaxClasses);
+    MNF_REQUIRE(chunk_starts && chunk_cnts && t_starts && t_ends && sigmas && rgbs && weights && trans && out_acc && out_depth &&
+                    d_sigmas && d_rgbs && ((sems && d_sems) || n_classes == 0),
+                "composite_train_backward: null pointer");
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_rays), dim3(64), lds_bytes(n_classes), as_stream(stream), chunk_starts,
+                       chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, n_classes, bkgd, weights, trans, out_acc, out_depth, g_rgb, g_acc,
+                       g_depth, g_sem, d_sigmas, d_rgbs, d_sems);
+    return launch_status("composite_bwd_kernel");
+}

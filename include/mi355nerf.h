@@ -80,6 +80,25 @@ int mnf_render_weight_from_density(const int64_t *chunk_starts, const int64_t *c
                                    const float *prefix_trans, int64_t n_samples,
                                    float *weights, float *trans, float *alphas, mnf_stream_t stream);
 
+/* Train-mode semantic volume rendering on packed samples (perception/models/utils.py:362-461 `sem_rendering`):
+ * render_weight_from_density (volrend.py:213-267) + the four accumulate_along_rays (volrend.py:27-66) + background
+ * blend + depth normalisation in one launch.  Outputs: rgb [R,3], acc [R], depth [R], sem [R,C]; per-sample weights and
+ * trans [N] are saved for backward, alphas is optional.  bkgd (3 floats, device) may be NULL.  n_classes <= 64. */
+int mnf_composite_train_forward(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                                const float *sems, int32_t n_classes, int64_t n_samples, const float *bkgd,
+                                float *out_rgb, float *out_acc, float *out_depth, float *out_sem, float *weights,
+                                float *trans, float *alphas, mnf_stream_t stream);
+
+/* Its adjoint (what torch autograd derives for the reference's op chain): gradients of the four per-ray outputs
+ * (any of g_* may be NULL = zero) -> d_sigmas [N], d_rgbs [N,3], d_sems [N,C]. */
+int mnf_composite_train_backward(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                 const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                                 const float *sems, int32_t n_classes, int64_t n_samples, const float *bkgd,
+                                 const float *weights, const float *trans, const float *out_acc,
+                                 const float *out_depth, const float *g_rgb, const float *g_acc, const float *g_depth,
+                                 const float *g_sem, float *d_sigmas, float *d_rgbs, float *d_sems, mnf_stream_t stream);
+
 /* ---------------------------------------------------------------- ray generation */
 
 /* Dataset.generate_image_rays (perception/data_proc/habitat_to_data.py:274-301) for n_views poses,

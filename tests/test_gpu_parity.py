@@ -187,6 +187,48 @@ def test_exclusive_sum_and_weights(golden):
     np.testing.assert_allclose(sig.grad.cpu().numpy(), [0.6703, 0.1653, 0.1653, 0.1653, 0.1653], atol=1e-4)
 
 
+@pytest.mark.parametrize("C,bkgd", [(29, True), (13, False), (64, True), (0, True)])
+def test_composite_train_forward_backward_matches_oracle(C, bkgd):
+    """csrc/composite_train.hip against the op chain of utils.py:362-461 under CPU autograd (oracle/render.py):
+    ragged rays (empty, 1, 63..65, 200 samples), all four heads contributing to the loss."""
+    from apnrf_amd.render import _CompositeTrain
+    from oracle import marcher as M
+    from oracle import render as R
+    rng = np.random.default_rng(C + 1)
+    cnts = rng.integers(0, 90, 300)
+    cnts[::7] = 0
+    cnts[1:6] = [1, 63, 64, 65, 200]
+    n_rays, ri = len(cnts), np.repeat(np.arange(len(cnts)), cnts)
+    N = len(ri)
+    ts = (rng.random(N) * 3).astype(np.float32)
+    te = ts + (0.01 + rng.random(N) * 0.05).astype(np.float32)
+    sig, rgb, sem = (rng.random(N) * 4).astype(np.float32), rng.random((N, 3)).astype(np.float32), rng.normal(size=(N, C)).astype(np.float32)
+    bk = np.array([0.2, 0.5, 0.9], np.float32) if bkgd else None
+    g = [rng.normal(size=s).astype(np.float32) for s in ((n_rays, 3), (n_rays, 1), (n_rays, 1), (n_rays, C))]
+    pk = M.pack_info(ri, n_rays)
+
+    # oracle: CPU autograd over the reference's op chain
+    o_sig, o_rgb, o_sem = (torch.from_numpy(a).requires_grad_(True) for a in (sig, rgb, sem))
+    t_ts, t_te, t_ri = torch.from_numpy(ts), torch.from_numpy(te), torch.from_numpy(ri)
+    w, tr, al = R.render_weight_from_density(t_ts, t_te, o_sig, pk)
+    colors = R.accumulate_along_rays(w, o_rgb, t_ri, n_rays)
+    opac = R.accumulate_along_rays(w, None, t_ri, n_rays)
+    depth = R.accumulate_along_rays(w, (t_ts + t_te)[:, None] / 2.0, t_ri, n_rays) / opac.clamp_min(torch.finfo(torch.float32).eps)
+    semo = R.accumulate_along_rays(w, o_sem, t_ri, n_rays)
+    if bkgd:
+        colors = colors + torch.from_numpy(bk) * (1.0 - opac)
+    sum((o * torch.from_numpy(gi)).sum() for o, gi in zip((colors, opac, depth, semo), g)).backward()
+
+    h_sig, h_rgb, h_sem = (_cu(a).requires_grad_(True) for a in (sig, rgb, sem))
+    outs = _CompositeTrain.apply(_cu(pk[:, 0]), _cu(pk[:, 1]), _cu(ts), _cu(te), h_sig, h_rgb, h_sem, _cu(bk) if bkgd else None)
+    sum((o * _cu(gi)).sum() for o, gi in zip(outs[:4], g)).backward()
+    for got, want, name in zip(outs, (colors, opac, depth, semo, w, tr, al), "rgb acc depth sem weights trans alphas".split()):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-6, err_msg=name)
+    for got, want, name in ((h_sig, o_sig, "d_sigma"), (h_rgb, o_rgb, "d_rgb"), (h_sem, o_sem, "d_sem")):
+        scale = float(want.grad.abs().max()) if want.grad.numel() else 1.0
+        np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), rtol=1e-4, atol=2e-5 * max(scale, 1.0), err_msg=name)
+
+
 # ------------------------------------------------------------------ field (fp: tolerance)
 def test_grid_meta_matches_oracle(fields):
     from oracle.field import grid_levels
