@@ -43,6 +43,7 @@ SIGNATURES = {
     "mnf_exclusive_sum": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "mnf_render_weight_from_density": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_run_bounds": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mnf_composite_train_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p]),

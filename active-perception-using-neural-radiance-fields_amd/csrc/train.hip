@@ -40,7 +40,7 @@ struct BwdArgs {
     const half8 *fragsT;
     const float *d_rgb, *d_sigma, *d_sem;   // [N,3], [N], [N,C]
     const float *rgb, *sigma;               // forward outputs [N,3], [N]
-    float *dX;                              // [Np][16][4] fp32, un-scaled
+    float *dX;                              // [16 levels][Np][4] fp32, un-scaled (level-major for hash_bwd)
     int64_t n;
     int C;
     float loss_scale;
@@ -175,11 +175,11 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
             dense_tile<L::KSW>(s_w + (L::o_b1 + rt * L::KSW) * 64, lane, dz, acc);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                float4 *dst = reinterpret_cast<float4 *>(args.dX + (fcol0 + 32 * ct) * 64);
+                float4 *dst = reinterpret_cast<float4 *>(args.dX) + fcol0 + 32 * ct;   // 32 lanes x 16 B contiguous per level
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float4 v = {acc[ct][4 * g] * inv, acc[ct][4 * g + 1] * inv, acc[ct][4 * g + 2] * inv, acc[ct][4 * g + 3] * inv};
-                    dst[8 * rt + 2 * g + h] = v;
+                    dst[(int64_t)(8 * rt + 2 * g + h) * args.train.Np] = v;
                 }
             }
         }
@@ -235,7 +235,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__
 // ------------------------------------------------------------------ hash-grid gradient scatter
 struct HashBwdArgs {
     const float *positions;
-    const float *dX;      // [Np][16][4]
+    const float *dX;      // [16][Np][4]
+    int64_t Np;
     float *g_table;       // fp32 [entries][4]
     int64_t n;
     float aabb[6];
@@ -258,13 +259,15 @@ __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) xn[d] = (args.positions[3 * i + d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);
     }
-#pragma unroll 1
-    for (int l = 0; l < 16; ++l) {
+    // One level per blockIdx.y, and the level is the slow grid dimension: at any time the chip scatters into one or two
+    // levels' slice of the gradient table (<= 8 MB) instead of all 200 MB, so the memory-side atomics stay cache hits.
+    {
+        const int l = blockIdx.y;
         const LevelMeta m = args.levels[l];
         LevelPrep p;
         hash_prep(m, xn, p);
         float4 g = {0.f, 0.f, 0.f, 0.f};
-        if (valid) g = reinterpret_cast<const float4 *>(args.dX + i * 64)[l];
+        if (valid) g = reinterpret_cast<const float4 *>(args.dX)[(int64_t)l * args.Np + i];
         // cell identity: the three integer cell coordinates (recomputed exactly as hash_prep does)
         int cell[3];
 #pragma unroll
@@ -306,14 +309,13 @@ __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
                         if (v[4 * corner + k] != 0.f) atomicAdd(dst + k, v[4 * corner + k]);
                 }
             }
-            continue;
+            return;
         }
         // Transpose through LDS so that one atomic wave-instruction covers 16 (sample, corner) pairs x 4 consecutive
         // floats: the four floats of a table entry share one 64-byte memory-side atomic request, so a wave issues 16
         // requests per instruction instead of 64 scattered dwords.
         float *w_val = s_val[threadIdx.x >> 6];
         uint32_t *w_off = s_off[threadIdx.x >> 6];
-        __syncthreads();   // previous level's readers are done
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) {
             float4 q = {v[4 * corner], v[4 * corner + 1], v[4 * corner + 2], v[4 * corner + 3]};
@@ -600,11 +602,11 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     if (rc) return rc;
     // hash-table gradient
     HashBwdArgs hb;
-    hb.positions = positions; hb.dX = v.dX; hb.g_table = g_base + f->n_base_mlp; hb.n = n;
+    hb.positions = positions; hb.dX = v.dX; hb.Np = v.Np; hb.g_table = g_base + f->n_base_mlp; hb.n = n;
     std::memcpy(hb.aabb, f->cfg.aabb, sizeof(hb.aabb));
     std::memcpy(hb.levels, f->levels, sizeof(hb.levels));
     static const bool simple = getenv("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane and corner
-    if (simple) hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, hb);
-    else hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, hb);
+    if (simple) hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((unsigned)ceil_div(n, 256), 16), dim3(256), 0, s, hb);
+    else hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((unsigned)ceil_div(n, 256), 16), dim3(256), 0, s, hb);
     return launch_status("hash_bwd_kernel");
 }

@@ -164,6 +164,16 @@ def pack_info(ray_indices: Tensor, n_rays: Optional[int] = None) -> Tensor:
     return torch.stack([starts, cnts], dim=-1)
 
 
+def pack_info_grouped(ray_indices: Tensor, n_rays: int) -> Tensor:
+    """`pack_info` for ray indices grouped by ray (every output of `traverse_grids` / `sampling`, masked or not): same
+    [n_rays, 2] result, from run boundaries instead of an index_add over all samples."""
+    ray_indices = ray_indices.contiguous()
+    bounds = torch.zeros((2, n_rays), device=ray_indices.device, dtype=torch.int64)
+    L.check(L.load_library().mnf_run_bounds(L.ptr(ray_indices), ray_indices.shape[0], L.ptr(bounds[0]), L.ptr(bounds[1]), L.stream()))
+    cnts = bounds[1] - bounds[0]
+    return torch.stack([cnts.cumsum(0) - cnts, cnts], dim=-1)
+
+
 class _ExclusiveSum(torch.autograd.Function):
     """scan.py:206-229: forward packed exclusive sum; backward = reverse-direction scan of the grad."""
 

@@ -184,7 +184,7 @@ def sem_rendering(radiance_field, rays: Rays, t_starts, t_ends, ray_indices, n_r
         rgbs, sigmas, sems = radiance_field.forward_samples(rays.origins, rays.viewdirs, ray_indices, t_starts, t_ends)
     else:
         rgbs, sigmas, sems = torch.empty((0, 3), device=dev), torch.empty((0,), device=dev), torch.empty((0, C), device=dev)
-    packed = NA.pack_info(ray_indices, n_rays)
+    packed = NA.pack_info_grouped(ray_indices, n_rays)
     bk = None if render_bkgd is None else render_bkgd.to(device=dev, dtype=torch.float32).reshape(3).contiguous()
     colors, opacities, depths, semantics, weights, trans, alphas = _CompositeTrain.apply(
         packed[:, 0].contiguous(), packed[:, 1].contiguous(), t_starts, t_ends, sigmas, rgbs, sems, bk)

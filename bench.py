@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="render800", choices=["render800", "score256", "train"])
+    ap.add_argument("--views", type=int, default=4, choices=[1, 2, 4, 8],
+                    help="render800: 800x800 views per step, rendered in one batched call (the reference renders pose lists, "
+                         "habitat_to_data.py:304-549); every view keeps its own per-round sample budget")
     ap.add_argument("--train-rays", type=int, default=8192, help="rays per train step (BASELINE config 5: 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket field-kernel launches with hipEvents")
@@ -102,14 +105,18 @@ def main():
         c2w = np.stack([RD.pose_to_c2w(p) for p in my_poses]).astype(np.float32)
         K = np.array([[focal, 0, width / 2], [0, focal, height / 2], [0, 0, 1.0]])
         rays = RD.generate_image_rays(torch.from_numpy(c2w), width, height, K, dev)
-        n_per_step = width * height
+        V = args.views
+        n_per_view = width * height
         bk = torch.zeros(3)
+        view_batches = [(rays.origins[k:k + V].reshape(-1, 3).contiguous(), rays.viewdirs[k:k + V].reshape(-1, 3).contiguous())
+                        for k in range(0, 8, V)]
 
         def step(i):
-            k = i % rays.origins.shape[0]
-            return RD.render_views(field, est, rays.origins[k], rays.viewdirs[k], n_per_step, 1024, render_bkgd=bk, **H.RENDER_KW)
-        units_per_step = n_per_step
-        workload = "scene 102344529 (synthetic stand-in), 800x800 RGB+depth+29-class semantic render, hash-grid 16x4 T=2^19 + MLP 128x2 + 64x2 heads"
+            o, d = view_batches[i % len(view_batches)]
+            return RD.render_views(field, est, o, d, n_per_view, 1024, render_bkgd=bk, **H.RENDER_KW)
+        units_per_step = n_per_view * V
+        workload = (f"scene 102344529 (synthetic stand-in), 800x800 RGB+depth+29-class semantic render, {V} view(s) per step in one "
+                    "batched call, hash-grid 16x4 T=2^19 + MLP 128x2 + 64x2 heads")
     elif args.workload == "train":
         # BASELINE config 5 shape: scene 102344280, 8192-ray train batches; targets are synthetic (no Habitat data offline)
         scene = H.make_scene("102344280", n_poses=8)
@@ -198,6 +205,9 @@ def main():
                        "render_step_size": 1e-3, "cone_angle": 0.004, "alpha_thre": 0.01,
                        "weights": "random-init (hash U(-0.5,0.5), xavier MLPs, |density row| x 8), procedural occupancy"},
         }
+        if args.workload == "render800":
+            line["config"]["views_per_step"] = args.views
+            line["config"]["ms_per_view"] = 1e3 * dt / args.steps / args.views
         if launches and samples:
             achieved = ALGO_BYTES_PER_SAMPLE * samples / (field_ms * 1e-3) / 1e9
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

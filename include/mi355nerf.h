@@ -80,6 +80,11 @@ int mnf_render_weight_from_density(const int64_t *chunk_starts, const int64_t *c
                                    const float *prefix_trans, int64_t n_samples,
                                    float *weights, float *trans, float *alphas, mnf_stream_t stream);
 
+/* Run boundaries of ray indices that are grouped by ray (the marcher's output order): first[r] = index of the
+ * first sample of ray r, last[r] = one past its last sample; both must be zero-filled by the caller, rays without
+ * samples stay (0, 0).  cnts = last - first is `pack_info`'s second column (nerfacc/pack.py:10-38). */
+int mnf_run_bounds(const int64_t *ray_indices, int64_t n_samples, int64_t *first, int64_t *last, mnf_stream_t stream);
+
 /* Train-mode semantic volume rendering on packed samples (perception/models/utils.py:362-461 `sem_rendering`):
  * render_weight_from_density (volrend.py:213-267) + the four accumulate_along_rays (volrend.py:27-66) + background
  * blend + depth normalisation in one launch.  Outputs: rgb [R,3], acc [R], depth [R], sem [R,C]; per-sample weights and

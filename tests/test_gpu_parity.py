@@ -161,6 +161,7 @@ def test_exclusive_sum_and_weights(golden):
     x = rng.random(len(ri)).astype(np.float32)
     pk = M.pack_info(ri, 500)
     np.testing.assert_array_equal(NA.pack_info(_cu(ri), 500).cpu().numpy(), pk)
+    np.testing.assert_array_equal(NA.pack_info_grouped(_cu(ri), 500).cpu().numpy(), pk)
     np.testing.assert_array_equal(NA.pack_info(_cu(np.array([0, 2, 2, 2, 2])), 3).cpu().numpy(), [[0, 1], [1, 0], [1, 4]])
     xs = _cu(x).requires_grad_(True)
     y = NA.exclusive_sum(xs, _cu(pk))
