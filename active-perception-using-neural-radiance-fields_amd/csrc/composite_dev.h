@@ -88,6 +88,38 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
     const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
     const int tail_lane = above ? lane + (__ffsll(above) - 1) : 63;
     const int maxlen = sm.stride;
+    // ---- every load of the epilogue is issued here, before any arithmetic or store: they depend only on the run
+    //      structure, and issued one read-modify-write at a time they cost four to five serial memory round trips
+    //      per tile at two waves per SIMD ----
+    float c_prev[3] = {0.f, 0.f, 0.f}, d_prev = 0.f, v_prev[4] = {0.f, 0.f, 0.f, 0.f};
+    int view = -1, budget = 0;
+    if (sm.ray >= 0 && (owner || fr.probabilistic)) {
+        c_prev[0] = fr.rgb[3 * sm.ray]; c_prev[1] = fr.rgb[3 * sm.ray + 1]; c_prev[2] = fr.rgb[3 * sm.ray + 2];
+        d_prev = fr.depth[sm.ray];
+    }
+    if (owner) {
+        view = sm.ray / fr.rays_per_view;
+        budget = fr.n_samples[view];
+        if (fr.probabilistic) {
+            v_prev[0] = fr.rgb_var[3 * sm.ray]; v_prev[1] = fr.rgb_var[3 * sm.ray + 1]; v_prev[2] = fr.rgb_var[3 * sm.ray + 2];
+            v_prev[3] = fr.depth_var[sm.ray];
+        }
+    }
+    f32x16 s_prev[CT];
+    int raym[CT];
+    bool hm[CT], tm[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int src = 32 * ct + c;
+        raym[ct] = __shfl(sm.ray, src, 64);
+        hm[ct] = __shfl((int)head, src, 64) != 0;
+        tm[ct] = __shfl((int)tail, src, 64) != 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
+            s_prev[ct][k] = (tm[ct] && row < C) ? fr.sem[(int64_t)raym[ct] * C + row] : 0.f;
+        }
+    }
     // ---- weights: w = exp(-excl_sum(sigma*dt)) * (1 - opacity_before) * alpha ----
     const float sdt = sm.valid ? sigma * (sm.te - sm.ts) : 0.0f;
     float sc[1] = {sdt};
@@ -106,36 +138,23 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
 #pragma unroll
     for (int k = 0; k < 7; ++k) tot[k] = __shfl(acc5[k], tail_lane, 64);
     const int cnt = (int)(tot[6] + 0.5f);                              // samples of this ray in this round
-    float c_prev[3] = {0.f, 0.f, 0.f}, d_prev = 0.f;
-    if (sm.ray >= 0 && (owner || fr.probabilistic)) {
-        c_prev[0] = fr.rgb[3 * sm.ray]; c_prev[1] = fr.rgb[3 * sm.ray + 1]; c_prev[2] = fr.rgb[3 * sm.ray + 2];
-        d_prev = fr.depth[sm.ray];
-    }
     const float c_new[3] = {c_prev[0] + tot[1], c_prev[1] + tot[2], c_prev[2] + tot[3]};
     const float d_new = d_prev + tot[4];
     const float o_new = opac0 + tot[0];
     // ---- variance against the post-round running means (utils.py:984-999) ----
+    float vt[4] = {0.f, 0.f, 0.f, 0.f};
     if (fr.probabilistic) {
         const float e0 = rgb[0] - c_new[0], e1 = rgb[1] - c_new[1], e2 = rgb[2] - c_new[2], ed = tmid - d_new;
         float var4[4] = {wk * (e0 * e0), wk * (e1 * e1), wk * (e2 * e2), wk * (ed * ed)};
         seg_scan64(var4, head, lane, maxlen);
-        float vt[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) vt[k] = __shfl(var4[k], tail_lane, 64);
-        if (owner) {
-            fr.rgb_var[3 * sm.ray] += vt[0]; fr.rgb_var[3 * sm.ray + 1] += vt[1]; fr.rgb_var[3 * sm.ray + 2] += vt[2];
-            fr.depth_var[sm.ray] += vt[3];
-        }
     }
     // ---- semantic logits: weights into MFMA layout (column c of tile ct <-> sample lane 32 ct + c) ----
     f32x16 x0;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const int src = 32 * ct + c;
-        const float wm = __shfl(wk, src, 64);
-        const bool hm = __shfl((int)head, src, 64) != 0;
-        const int raym = __shfl(sm.ray, src, 64);
-        const bool tm = __shfl((int)tail, src, 64) != 0;
+        const float wm = __shfl(wk, 32 * ct + c, 64);
         f32x16 x;
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = sem[ct][k] * wm;
@@ -148,24 +167,27 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
                 if (cont && c == 0) x[k] += cv;
             }
         }
-        seg_scan32(x, hm, c, maxlen);
+        seg_scan32(x, hm[ct], c, maxlen);
         if (ct == 0) x0 = x;
-        if (tm) {                                            // the run's last column owns the totals
+        if (tm[ct]) {                                        // the run's last column owns the totals
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
-                if (row < C) fr.sem[(int64_t)raym * C + row] += x[k];
+                if (row < C) fr.sem[(int64_t)raym[ct] * C + row] = s_prev[ct][k] + x[k];
             }
         }
     }
     // ---- per-ray bookkeeping by the owner lane ----
     bool still_alive = false;
-    int view = -1;
     if (owner) {
-        view = sm.ray / fr.rays_per_view;
+        if (fr.probabilistic) {
+            fr.rgb_var[3 * sm.ray] = v_prev[0] + vt[0]; fr.rgb_var[3 * sm.ray + 1] = v_prev[1] + vt[1];
+            fr.rgb_var[3 * sm.ray + 2] = v_prev[2] + vt[2];
+            fr.depth_var[sm.ray] = v_prev[3] + vt[3];
+        }
         fr.rgb[3 * sm.ray] = c_new[0]; fr.rgb[3 * sm.ray + 1] = c_new[1]; fr.rgb[3 * sm.ray + 2] = c_new[2];
         fr.acc[sm.ray] = o_new; fr.depth[sm.ray] = d_new;
-        still_alive = (o_new <= fr.opc_thre) && (cnt == fr.n_samples[view]);   // utils.py:751-756
+        still_alive = (o_new <= fr.opc_thre) && (cnt == budget);       // utils.py:751-756
         fr.alive[sm.ray] = still_alive;
     }
     // survivors per view and sample totals: accumulated per wave, flushed when the view changes / after the last tile

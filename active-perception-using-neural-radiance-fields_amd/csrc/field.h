@@ -62,6 +62,8 @@ struct FieldIO {
     const float *t_starts, *t_ends;          // mode 1, 2
     int64_t n;                               // modes 0, 1
     const int32_t *n_dev;                    // mode 2: number of columns (device)
+    const void *enc;                         // optional [ceil(n/64)][8][64] x 16 B feature scratch: non-null selects the
+                                             // two-launch path (encode_kernel, then the MLP kernel on its output)
     // outputs: user layout (modes 0,1) ...
     float *rgb, *density, *sem;
     // ... or, in mode 2, composites straight into the renderer's per-ray accumulators

@@ -29,8 +29,152 @@
 
 namespace mnf {
 
+// ------------------------------------------------------------------ sample fetch (shared by the kernels below)
+// Position / direction of column `col`: mode 0 explicit arrays, mode 1 packed samples with int64 ray ids, mode 2 renderer
+// columns.  xn = position normalised to the aabb (ngp.py:177-178), selector = inside the open unit box (ngp.py:179).
+// Renderer columns of one tile (mode 2).  (Loading them one tile ahead was measured: slower, the four extra live
+// registers cost more than the hidden round trip.)
+struct ColData {
+    int ray, stride;
+    float ts, te;
+};
+
+__device__ __forceinline__ ColData load_cols(const KernelArgs &args, int64_t tile, int lane) {
+    const int64_t col = tile * kWaveSamples + lane;
+    ColData c;
+    c.stride = args.io.fr.tile_hdr[tile];
+    c.ray = args.io.col_ray[col];
+    c.ts = args.io.t_starts[col]; c.te = args.io.t_ends[col];
+    return c;
+}
+
+template <int MODE, bool WANT_DIR>
+__device__ __forceinline__ void fetch_sample(const KernelArgs &args, const ColData &cd, int64_t col, int64_t n, float (&xn)[3],
+                                             float (&dir)[3], TileSample &tsm, bool &valid, bool &selector) {
+    valid = col < n;
+    float pos[3] = {0.f, 0.f, 0.f};
+    dir[0] = 0.f; dir[1] = 0.f; dir[2] = 1.f;
+    tsm = {-1, 64, false, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+        if (valid) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) pos[d] = args.io.positions[3 * col + d];
+            if (WANT_DIR)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) dir[d] = args.io.directions[3 * col + d];
+        }
+    } else if (MODE == 1) {
+        int64_t ray = -1;
+        if (valid) ray = args.io.ray_idx64[col];
+        valid = ray >= 0;
+        if (valid) {
+            const float tsum = args.io.t_starts[col] + args.io.t_ends[col];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                dir[d] = args.io.rays_d[3 * ray + d];
+                // utils.py:92 / :614: origins + dirs * (t_starts + t_ends) / 2.0
+                pos[d] = args.io.rays_o[3 * ray + d] + (dir[d] * tsum) / 2.0f;
+            }
+        }
+    } else {
+        // renderer tile: column -> ray id (-1: unused); the runs of equal ids are the rays of this tile
+        tsm.stride = cd.stride; tsm.ray = cd.ray; tsm.ts = cd.ts; tsm.te = cd.te;
+        valid = tsm.ray >= 0;
+        tsm.valid = valid;
+        if (valid) {
+            if (WANT_DIR) tsm.opac0 = args.io.fr.acc[tsm.ray];
+            const float tsum = tsm.ts + tsm.te;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                dir[d] = args.io.rays_d[3 * (int64_t)tsm.ray + d];
+                pos[d] = args.io.rays_o[3 * (int64_t)tsm.ray + d] + (dir[d] * tsum) / 2.0f;   // utils.py:614
+            }
+        }
+    }
+    selector = valid;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        xn[d] = (pos[d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);   // ngp.py:177-178
+        selector = selector && (xn[d] > 0.0f) && (xn[d] < 1.0f);               // ngp.py:179
+    }
+    if (!valid) { xn[0] = 0.5f; xn[1] = 0.5f; xn[2] = 0.5f; }
+}
+
+// XCD-aware tile-group order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an L2), and
+// neighbouring tiles hold neighbouring rays that touch the same hash-table lines, so each XCD walks one contiguous
+// eighth of the tile groups.  A speed choice only: any placement is correct.  Grids that are not a multiple of 8 use
+// the plain grid-stride order.
+__device__ __forceinline__ void group_range(int64_t n_groups, int64_t &g_first, int64_t &g_end, int64_t &g_step) {
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7;
+        g_first = n_groups * xcd / 8 + (blockIdx.x >> 3);
+        g_end = n_groups * (xcd + 1) / 8;
+        g_step = gridDim.x >> 3;
+    } else {
+        g_first = blockIdx.x; g_end = n_groups; g_step = gridDim.x;
+    }
+}
+
+// ------------------------------------------------------------------ hash-grid encode as its own launch (diagnostic path)
+// MNF_FIELD_SPLIT=1 runs the multiresolution gather and the MLP chain as two launches, which separates their costs:
+// on the 800x800 workload the gather alone takes 64 % of the fused kernel's time and is insensitive to occupancy
+// (3..8 waves per SIMD) and to halving the L1 tag lookups (paired 16-byte loads), i.e. it is bound by the miss path
+// (random 64-byte fetches), while the MLP + compositing launch alone takes 38 %.  The fused kernel overlaps the two
+// and stays the default: split is ~7 % slower end to end and needs 128 B of scratch per column.
+// Features leave in the B-fragment order the MLP kernel consumes: half8 block ((tile*4 + ks)*2 + ct)*64 + (h*32 + c)
+// holds levels 4ks+2h, 4ks+2h+1 of sample 32ct + c  (k = 16ks + 8h + j), so the consumer's load is one coalesced b128.
+constexpr int kEncodeThreads = 256;
+
+template <int MODE>
+__global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelArgs args, half8 *__restrict__ enc) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    constexpr int kWaves = kEncodeThreads / 64;
+    constexpr int LPB = 2;   // levels per batch of gathers (16 loads in flight per wave, <= 80 VGPRs, 6 waves per SIMD)
+    int64_t n = args.io.n;
+    if (MODE == 2) n = *args.io.n_dev;
+    const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
+    const int64_t n_groups = (n_tiles + kWaves - 1) / kWaves;
+    int64_t g_first, g_end, g_step;
+    group_range(n_groups, g_first, g_end, g_step);
+    for (int64_t grp = g_first; grp < g_end; grp += g_step) {
+        const int64_t tile = grp * kWaves + wave;
+        if (tile >= n_tiles) break;
+        const int64_t col = tile * kWaveSamples + lane;
+        ColData cd = {-1, 64, 0.f, 0.f};
+        if (MODE == 2) cd = load_cols(args, tile, lane);
+        float xn[3], dir[3];
+        TileSample tsm;
+        bool valid, selector;
+        fetch_sample<MODE, false>(args, cd, col, n, xn, dir, tsm, valid, selector);
+        half8 *dst = enc + (tile * 8 + (lane >> 5)) * 64 + (lane & 31);
+#pragma unroll
+        for (int l0 = 0; l0 < 16; l0 += LPB) {
+            LevelPrep prep[LPB];
+            half4 v[LPB][8];
+#pragma unroll
+            for (int q = 0; q < LPB; ++q) {
+                hash_prep(args.levels[l0 + q], xn, prep[q]);
+                hash_load(args.table, prep[q], v[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < LPB; q += 2) {
+                float f[8];
+                hash_blend(prep[q], v[q], f);
+                hash_blend(prep[q + 1], v[q + 1], f + 4);
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)f[j];
+                const int p = (l0 + q) >> 1;                      // level pair: ks = p >> 1, h = p & 1
+                dst[((p >> 1) * 2) * 64 + (p & 1) * 32] = o;      // block (tile*4 + ks)*2 + ct, slot h*32 + c
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the fused kernel
-template <int W, int NH, int MODE, bool DENSITY_ONLY, bool SAVE = false>
+template <int W, int NH, int MODE, bool DENSITY_ONLY, bool SAVE = false, bool ENC = false>
 __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs args) {
     using L = Layout<W, NH>;
     using T = TrainLayout<W, NH>;
@@ -45,102 +189,59 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     if (MODE == 2) n = *args.io.n_dev;
     const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
     if (n_tiles == 0) return;
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an L2), and
-    // neighbouring tiles hold neighbouring rays that touch the same hash-table lines, so each XCD walks one contiguous
-    // eighth of the tile groups (a group = the 8 tiles of one workgroup pass).  A speed choice only: any placement is
-    // correct.  Grids that are not a multiple of 8 use the plain grid-stride order.
-    const int64_t n_groups = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int wpb = args.active_waves;
+    const int64_t n_groups = (n_tiles + wpb - 1) / wpb;
     int64_t g_first, g_end, g_step;
-    if ((gridDim.x & 7) == 0) {
-        const int xcd = blockIdx.x & 7;
-        g_first = n_groups * xcd / 8 + (blockIdx.x >> 3);
-        g_end = n_groups * (xcd + 1) / 8;
-        g_step = gridDim.x >> 3;
-    } else {
-        g_first = blockIdx.x; g_end = n_groups; g_step = gridDim.x;
-    }
+    group_range(n_groups, g_first, g_end, g_step);
     if (g_first >= g_end) return;   // uniform per block: nothing to do
 
     for (int i = threadIdx.x; i < kBlocks * 64; i += kThreads) s_w[i] = args.frags[i];
     __syncthreads();
+    if (wave >= wpb) return;
 
     WaveCounters wc;
     for (int64_t grp = g_first; grp < g_end; grp += g_step) {
-        const int64_t tile = grp * kWavesPerBlock + wave;
+        const int64_t tile = grp * wpb + wave;
         if (tile >= n_tiles) break;
         // ---- this lane's sample ----
         const int64_t col = tile * kWaveSamples + lane;
-        bool valid = col < n;
-        float pos[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 1.f};
-        TileSample tsm = {-1, 64, false, 0.f, 0.f, 0.f};
-        if (MODE == 0) {
-            if (valid) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) pos[d] = args.io.positions[3 * col + d];
-                if (!DENSITY_ONLY)
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) dir[d] = args.io.directions[3 * col + d];
-            }
-        } else if (MODE == 1) {
-            int64_t ray = -1;
-            if (valid) ray = args.io.ray_idx64[col];
-            valid = ray >= 0;
-            if (valid) {
-                const float tsum = args.io.t_starts[col] + args.io.t_ends[col];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    dir[d] = args.io.rays_d[3 * ray + d];
-                    // utils.py:92 / :614: origins + dirs * (t_starts + t_ends) / 2.0
-                    pos[d] = args.io.rays_o[3 * ray + d] + (dir[d] * tsum) / 2.0f;
-                }
-            }
-        } else {
-            // renderer tile: column -> ray id (-1: unused); the runs of equal ids are the rays of this tile
-            tsm.stride = args.io.fr.tile_hdr[tile];
-            tsm.ray = args.io.col_ray[col];
-            tsm.ts = args.io.t_starts[col]; tsm.te = args.io.t_ends[col];
-            valid = tsm.ray >= 0;
-            tsm.valid = valid;
-            if (valid) {
-                tsm.opac0 = args.io.fr.acc[tsm.ray];
-                const float tsum = tsm.ts + tsm.te;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    dir[d] = args.io.rays_d[3 * (int64_t)tsm.ray + d];
-                    pos[d] = args.io.rays_o[3 * (int64_t)tsm.ray + d] + (dir[d] * tsum) / 2.0f;   // utils.py:614
-                }
-            }
-        }
-        float xn[3];
-        bool selector = valid;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            xn[d] = (pos[d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);   // ngp.py:177-178
-            selector = selector && (xn[d] > 0.0f) && (xn[d] < 1.0f);               // ngp.py:179
-        }
-        if (!valid) { xn[0] = 0.5f; xn[1] = 0.5f; xn[2] = 0.5f; }
+        ColData cd = {-1, 64, 0.f, 0.f};
+        if (MODE == 2) cd = load_cols(args, tile, lane);
+        float xn[3], dir[3];
+        TileSample tsm;
+        bool valid, selector;
+        fetch_sample<MODE, !DENSITY_ONLY>(args, cd, col, n, xn, dir, tsm, valid, selector);
 
         // ---- hash encode: all 16 levels of this lane's sample (one k-step = 4 levels = 32 gathers in flight),
         //      then trade halves with lane^32 ----
         half8 bfeat[CT][4];
+        if (ENC) {
+            // features were produced by encode_kernel, already in fragment order
+            const half8 *src = reinterpret_cast<const half8 *>(args.io.enc) + tile * 512 + lane;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            LevelPrep prep[4];
-            half4 v[4][8];
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                hash_prep(args.levels[4 * ks + q], xn, prep[q]);
-                hash_load(args.table, prep[q], v[q]);
+                for (int ct = 0; ct < CT; ++ct) bfeat[ct][ks] = src[(ks * 2 + ct) * 64];
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                LevelPrep prep[4];
+                half4 v[4][8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    hash_prep(args.levels[4 * ks + q], xn, prep[q]);
+                    hash_load(args.table, prep[q], v[q]);
+                }
+                float f[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hash_blend(prep[q], v[q], f + 4 * q);
+                half8 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
+                exchange_halves(lo, hi);
+                bfeat[0][ks] = lo; bfeat[1][ks] = hi;
+                __builtin_amdgcn_sched_barrier(0);
             }
-            float f[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hash_blend(prep[q], v[q], f + 4 * q);
-            half8 lo, hi;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
-            exchange_halves(lo, hi);
-            bfeat[0][ks] = lo; bfeat[1][ks] = hi;
-            __builtin_amdgcn_sched_barrier(0);
         }
 
         // column of tile ct held by this lane in MFMA layout, and the mask-dump base of this tile
@@ -390,11 +491,29 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     a.frags = reinterpret_cast<const half8 *>(f->d_frags);
     std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));
     a.C = f->cfg.num_semantic_classes;
+    static const int active_waves = getenv("MNF_FIELD_ACTIVE_WAVES") ? atoi(getenv("MNF_FIELD_ACTIVE_WAVES")) : kWavesPerBlock;
+    a.active_waves = active_waves >= 1 && active_waves <= kWavesPerBlock ? active_waves : kWavesPerBlock;
     std::memcpy(a.levels, f->levels, sizeof(a.levels));
     a.io = io;
 #define MNF_LAUNCH(MODE, DO) hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO>), dim3(grid), dim3(kThreads), 0, stream, a)
     if (train) {
         hipLaunchKernelGGL((field_kernel<W, NH, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    } else if (io.enc) {
+        // two launches: gather at high occupancy, then the register-heavy MLP chain on ready-made fragments
+        half8 *enc = reinterpret_cast<half8 *>(const_cast<void *>(io.enc));
+        const int egrid = 2048;
+        if (io.mode == 0) hipLaunchKernelGGL((encode_kernel<0>), dim3(egrid), dim3(kEncodeThreads), 0, stream, a, enc);
+        else if (io.mode == 1) hipLaunchKernelGGL((encode_kernel<1>), dim3(egrid), dim3(kEncodeThreads), 0, stream, a, enc);
+        else hipLaunchKernelGGL((encode_kernel<2>), dim3(egrid), dim3(kEncodeThreads), 0, stream, a, enc);
+        if (density_only) {
+            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, true, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, true, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else hipLaunchKernelGGL((field_kernel<W, NH, 2, true, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+        } else {
+            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, false, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else hipLaunchKernelGGL((field_kernel<W, NH, 2, false, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+        }
     } else if (density_only) {
         if (io.mode == 0) MNF_LAUNCH(0, true); else if (io.mode == 1) MNF_LAUNCH(1, true); else MNF_LAUNCH(2, true);
     } else {
@@ -451,7 +570,7 @@ extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
     f->shape = {W, NH, Wh, cfg->num_semantic_classes, (int)(table.size() / 512)};
     f->d_table = nullptr; f->d_frags = nullptr; f->d_frag_src = nullptr; f->params_loaded = false;
     f->master[0] = f->master[1] = f->master[2] = nullptr; f->train_state = nullptr;
-    hipError_t e = hipMalloc(&f->d_table, (size_t)f->table_entries * 4 * sizeof(uint16_t));
+    hipError_t e = hipMalloc(&f->d_table, (size_t)f->table_entries * 4 * sizeof(uint16_t) );
     if (e == hipSuccess) e = hipMalloc(&f->d_frags, table.size() * sizeof(uint16_t) + sizeof(LevelMeta) * 16);
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_frag_src, table.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(f->d_frag_src, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice);

@@ -81,6 +81,7 @@ struct KernelArgs {
     const half8 *frags;
     float aabb[6];
     int C;
+    int active_waves;       // experiment knob (MNF_FIELD_ACTIVE_WAVES): waves per workgroup that take tiles, default 8
     LevelMeta levels[16];   // wave-uniform: read with scalar loads
     FieldIO io;
     TrainBuf train;

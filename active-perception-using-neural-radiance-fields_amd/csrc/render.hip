@@ -37,8 +37,14 @@ struct RenderWs {
     int32_t *col_ray;
     float *col_ts, *col_te;
     int32_t *tile_hdr;   // per 64-column tile: stride | nslots << 8
+    void *enc;           // hash features of the round's columns in MLP fragment order (two-launch field path)
     int64_t col_cap;
 };
+
+static bool split_field() {
+    static const bool on = getenv("MNF_FIELD_SPLIT") != nullptr;
+    return on;
+}
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -67,6 +73,8 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     p = take(col_cap * 4); if (ws) ws->col_ts = (float *)p;
     p = take(col_cap * 4); if (ws) ws->col_te = (float *)p;
     p = take(col_cap / 64 * 4); if (ws) ws->tile_hdr = (int32_t *)p;
+    if (split_field()) { p = take((col_cap / 64 + 1) * 8192); if (ws) ws->enc = p; }   // diagnostic two-launch path: 128 B per column
+    else if (ws) ws->enc = nullptr;
     if (ws) ws->col_cap = col_cap;
     return (int64_t)off;
 }
@@ -430,6 +438,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     FieldIO io = {};
     io.mode = 2; io.rays_o = rays_o; io.rays_d = rays_d; io.col_ray = ws.col_ray; io.t_starts = ws.col_ts; io.t_ends = ws.col_te;
     io.n_dev = ws.n_cols;
+    io.enc = ws.enc;   // non-null only under MNF_FIELD_SPLIT (diagnostic: gather and MLP as two launches)
     io.fr.tile_hdr = ws.tile_hdr; io.fr.alive = ws.alive; io.fr.alive_count = ws.alive_count;
     io.fr.n_samples = ws.n_samples; io.fr.rgb = rgb; io.fr.acc = acc; io.fr.depth = depth; io.fr.sem = sem;
     io.fr.rgb_var = out.rgb_var; io.fr.depth_var = out.depth_var;

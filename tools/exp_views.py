@@ -10,7 +10,7 @@ c2w = np.stack([RD.pose_to_c2w(p) for p in scene["poses"]]).astype(np.float32)
 K = np.array([[400.0, 0, 400], [0, 400.0, 400], [0, 0, 1.0]])
 rays = RD.generate_image_rays(torch.from_numpy(c2w), 800, 800, K, dev)
 bk = torch.zeros(3)
-for V in (1, 2, 4, 8):
+for V in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 8)):
     o = rays.origins[:V].reshape(-1, 3).contiguous(); d = rays.viewdirs[:V].reshape(-1, 3).contiguous()
     for i in range(3):
         RD.render_views(field, est, o, d, 640000, 1024, render_bkgd=bk, **H.RENDER_KW)
