@@ -27,6 +27,10 @@
 #include <cmath>
 #include <cstring>
 
+#ifndef MNF_KSB
+#define MNF_KSB 1
+#endif
+
 namespace mnf {
 
 // ------------------------------------------------------------------ sample fetch (shared by the kernels below)
@@ -179,6 +183,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     using L = Layout<W, NH>;
     using T = TrainLayout<W, NH>;
     constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
+    constexpr int KSB = MNF_KSB;   // k-steps (4 levels each) gathered per batch
     __shared__ half8 s_w[kBlocks * 64];
 
     const int lane = threadIdx.x & 63;
@@ -224,22 +229,25 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 for (int ct = 0; ct < CT; ++ct) bfeat[ct][ks] = src[(ks * 2 + ct) * 64];
         } else {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                LevelPrep prep[4];
-                half4 v[4][8];
+            for (int kb = 0; kb < 4 / KSB; ++kb) {
+                LevelPrep prep[4 * KSB];
+                half4 v[4 * KSB][8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    hash_prep(args.levels[4 * ks + q], xn, prep[q]);
+                for (int q = 0; q < 4 * KSB; ++q) {
+                    hash_prep(args.levels[4 * KSB * kb + q], xn, prep[q]);
                     hash_load(args.table, prep[q], v[q]);
                 }
-                float f[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hash_blend(prep[q], v[q], f + 4 * q);
-                half8 lo, hi;
+                for (int k2 = 0; k2 < KSB; ++k2) {
+                    float f[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
-                exchange_halves(lo, hi);
-                bfeat[0][ks] = lo; bfeat[1][ks] = hi;
+                    for (int q = 0; q < 4; ++q) hash_blend(prep[4 * k2 + q], v[4 * k2 + q], f + 4 * q);
+                    half8 lo, hi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
+                    exchange_halves(lo, hi);
+                    bfeat[0][KSB * kb + k2] = lo; bfeat[1][KSB * kb + k2] = hi;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -395,6 +395,30 @@ class OccGridEstimator(torch.nn.Module):
         return out
 
     @torch.no_grad()
+    def mark_invisible_cells(self, K: Tensor, c2w: Tensor, width: int, height: int, near_plane: float = 0.0,
+                             chunk: int = 32 ** 3) -> None:
+        """occ_grid.py:279-342: cells no camera sees (or that sit closer than near_plane to one) get occupancy -1 and are
+        never sampled again.  Known answer: tests/test_grid.py:207-233 (77 660 / 53 412 cells)."""
+        assert K.dim() == 3 and K.shape[1:] == (3, 3)
+        assert c2w.dim() == 3 and (c2w.shape[1:] == (3, 4) or c2w.shape[1:] == (4, 4))
+        assert K.shape[0] == c2w.shape[0] or K.shape[0] == 1
+        rot = c2w[:, :3, :3].transpose(2, 1)                      # world -> camera rotation, one per camera
+        shift = -rot @ c2w[:, :3, 3:]
+        for lvl, cells in enumerate(self._get_all_cells()):
+            lo, hi = self.aabbs[lvl, :3], self.aabbs[lvl, 3:]
+            for begin in range(0, len(cells), chunk):
+                ids = cells[begin:begin + chunk]
+                unit = self.grid_coords[ids] / (self.resolution - 1)          # cell corner in [0, 1]^3
+                world = (lo + unit * (hi - lo)).T                             # [3, n]
+                pix = K @ (rot @ world + shift)                                # [cams, 3, n]: (u*d, v*d, d)
+                depth = pix[:, 2]
+                u, v = pix[:, 0] / depth, pix[:, 1] / depth
+                inside = (depth >= 0) & (u >= 0) & (u < width) & (v >= 0) & (v < height)
+                seen = ((depth >= near_plane) & inside).any(0)
+                too_close = ((depth < near_plane) & inside).any(0)
+                self.occs[lvl * self.cells_per_lvl + ids] = torch.where(seen & ~too_close, 0.0, -1.0)
+
+    @torch.no_grad()
     def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
                 warmup_steps: int = 256) -> None:
         """occ_grid.py:377-437 (EMA-max update with the fork's NaN roll-back)."""

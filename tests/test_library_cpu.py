@@ -69,3 +69,17 @@ def test_estimator_state_matches_oracle(golden):
     est.eval()
     with pytest.raises(RuntimeError):
         est.update_every_n_steps(step=0, occ_eval_fn=lambda x: x[:, :1])
+
+
+def test_mark_invisible_cells_known_answer(golden):
+    """The reference's own known-answer test (perception/nerfacc/tests/test_grid.py:207-233) on the mirror estimator
+    (pure torch: runs on CPU); the counts are also held by tests/golden/occgrid.npz, captured from the reference."""
+    import torch
+    from apnrf_amd.nerfacc import OccGridEstimator
+    g = OccGridEstimator(roi_aabb=torch.tensor([-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]), resolution=32, levels=4)
+    K = torch.tensor([[[100.0, 0, 50.0], [0, 100.0, 50.0], [0, 0, 1]]])
+    pose = torch.tensor([[[-1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, -1.0, 2.5]]])
+    g.mark_invisible_cells(K, pose, 100, 100)
+    gold = golden("occgrid")
+    assert int((g.occs == -1).sum()) == 77660 == int(gold["mark_invisible_neg1"])
+    assert int((g.occs == 0).sum()) == 53412 == int(gold["mark_invisible_zero"])
