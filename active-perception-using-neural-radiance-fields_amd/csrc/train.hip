@@ -237,6 +237,10 @@ struct HashBwdArgs {
     const float *positions;
     const float *dX;      // [16][Np][4]
     int64_t Np;
+    int level0;           // first level of this launch (experiments; 0 in production)
+    float *repl;          // [kReplicas][repl_floats]: private copies of the coarsest levels' gradient (see below)
+    uint32_t repl_floats;
+    int repl_levels;
     float *g_table;       // fp32 [entries][4]
     int64_t n;
     float aabb[6];
@@ -247,6 +251,21 @@ struct HashBwdArgs {
 // of a level (always at the coarse levels, often at the fine ones).  A scattered float atomic is the slow operation
 // here (MI355X: ~17x below the contiguous rate), so each wave first sums the 8 corners x 4 features of runs of lanes
 // that share a cell (segmented inclusive scan over the lanes) and only the last lane of every run issues atomics.
+// The coarsest dense levels have a few thousand entries that every ray of a camera crosses near its origin: their
+// atomics pile up on the same addresses (level 0 alone cost as much as the finest level).  Workgroups therefore add
+// into one of kReplicas private copies of those levels, which a small kernel folds into the gradient afterwards.
+constexpr int kReplicas = 16;
+constexpr uint32_t kReplMaxEntries = 131072;
+
+__global__ void __launch_bounds__(256) fold_replicas_kernel(const float *__restrict__ repl, uint32_t repl_floats, float *__restrict__ g_table) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= repl_floats) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < kReplicas; ++r) acc += repl[(size_t)r * repl_floats + i];
+    if (acc != 0.f) g_table[i] += acc;
+}
+
 template <bool PRE>
 __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
     __shared__ float s_val[4][64 * 32];
@@ -262,8 +281,9 @@ __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
     // One level per blockIdx.y, and the level is the slow grid dimension: at any time the chip scatters into one or two
     // levels' slice of the gradient table (<= 8 MB) instead of all 200 MB, so the memory-side atomics stay cache hits.
     {
-        const int l = blockIdx.y;
+        const int l = blockIdx.y + args.level0;
         const LevelMeta m = args.levels[l];
+        float *const g_dst = l < args.repl_levels ? args.repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.g_table;
         LevelPrep p;
         hash_prep(m, xn, p);
         float4 g = {0.f, 0.f, 0.f, 0.f};
@@ -284,10 +304,15 @@ __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
             const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
             v[4 * corner + 0] = w * g.x; v[4 * corner + 1] = w * g.y; v[4 * corner + 2] = w * g.z; v[4 * corner + 3] = w * g.w;
         }
-        // segmented inclusive scan (Hillis-Steele) over the wave
+        // segmented inclusive scan (Hillis-Steele) over the wave, only as many doubling steps as the longest run of this
+        // level needs (fine levels: runs of one or two samples; coarse levels: the whole wave in one cell)
+        int maxlen = 1;
+        if (PRE) {
+            unsigned long long cont = ~__ballot(head || !valid);   // lanes that continue the run of the lane below
+            while (cont) { cont &= cont << 1; ++maxlen; }
+        }
         bool f = head;
-#pragma unroll
-        for (int d = 1; PRE && d < 64; d <<= 1) {
+        for (int d = 1; PRE && d < maxlen; d <<= 1) {
             const int fu = __shfl_up((int)f, d, 64);
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
@@ -303,7 +328,7 @@ __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
             if (tail) {
 #pragma unroll
                 for (int corner = 0; corner < 8; ++corner) {
-                    float *dst = args.g_table + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
+                    float *dst = g_dst + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (v[4 * corner + k] != 0.f) atomicAdd(dst + k, v[4 * corner + k]);
@@ -327,8 +352,9 @@ __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
         for (int sidx = 0; sidx < 32; ++sidx) {
             const int pi = 16 * sidx + (lane >> 2);          // (sample, corner) pair handled by this lane quad
             const uint32_t off = w_off[pi];
+            if (__ballot(off != 0xFFFFFFFFu) == 0ull) continue;   // none of these 16 pairs closes a run (common at coarse levels)
             const float val = w_val[pi * 4 + (lane & 3)];
-            if (off != 0xFFFFFFFFu && val != 0.f) atomicAdd(args.g_table + (off >> 1) + (lane & 3), val);
+            if (off != 0xFFFFFFFFu && val != 0.f) atomicAdd(g_dst + (off >> 1) + (lane & 3), val);
         }
     }
 }
@@ -605,8 +631,29 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     hb.positions = positions; hb.dX = v.dX; hb.Np = v.Np; hb.g_table = g_base + f->n_base_mlp; hb.n = n;
     std::memcpy(hb.aabb, f->cfg.aabb, sizeof(hb.aabb));
     std::memcpy(hb.levels, f->levels, sizeof(hb.levels));
+    int n_levels = 16;
+    hb.level0 = 0;
+    if (const char *e = getenv("MNF_HASH_BWD_LEVELS")) { int lo = 0, hi = 16; if (sscanf(e, "%d,%d", &lo, &hi) == 2) { hb.level0 = lo; n_levels = hi - lo; } }
+    // replicated coarse levels: the leading dense levels while they stay small; the copies live in the activation
+    // buffer, which the weight-gradient kernel above was the last to read
+    uint32_t repl_entries = 0;
+    hb.repl_levels = 0;
+    for (int l = 0; l < 16; ++l) {
+        if (f->levels[l].hashed || f->levels[l].offset != repl_entries || repl_entries + f->levels[l].size > kReplMaxEntries) break;
+        repl_entries += f->levels[l].size;
+        hb.repl_levels = l + 1;
+    }
+    hb.repl_floats = repl_entries * 4;
+    hb.repl = reinterpret_cast<float *>(v.act);
+    const size_t repl_bytes = (size_t)kReplicas * hb.repl_floats * sizeof(float);
+    if ((size_t)ts->tt.rows * v.Np * 2 < repl_bytes) { hb.repl_levels = 0; hb.repl_floats = 0; }
+    if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.repl, 0, repl_bytes, s));
     static const bool simple = getenv("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane and corner
-    if (simple) hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((unsigned)ceil_div(n, 256), 16), dim3(256), 0, s, hb);
-    else hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((unsigned)ceil_div(n, 256), 16), dim3(256), 0, s, hb);
-    return launch_status("hash_bwd_kernel");
+    if (simple) hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, s, hb);
+    else hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, s, hb);
+    rc = launch_status("hash_bwd_kernel");
+    if (rc) return rc;
+    if (hb.repl_levels)
+        hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, s, hb.repl, hb.repl_floats, hb.g_table);
+    return launch_status("fold_replicas_kernel");
 }
