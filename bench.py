@@ -206,6 +206,8 @@ def main():
                        "weights": "random-init (hash U(-0.5,0.5), xavier MLPs, |density row| x 8), procedural occupancy"},
         }
         if args.workload == "render800":
+            # evaluated samples of the timed steps and of the warm-up (PMC sums cover both): tools/reduce_pmc.py
+            line["samples"] = {"timed": int(samples), "warmup": int(warm.item())}
             line["config"]["views_per_step"] = args.views
             line["config"]["ms_per_view"] = 1e3 * dt / args.steps / args.views
         if launches and samples:
