@@ -196,40 +196,78 @@ struct WgradJob {
     int32_t colmap[32];           // parameter column of in-row k of this tile, -1 = none
 };
 
-// one wave = one (job, chunk of 64-sample tiles): D[32][32] += dOut^T[32][16 samples] * In^T[16 samples][32], four MFMA
-// steps per tile; the 32 rows of each operand are one contiguous 4 KB block of the tile-major activation matrix
-__global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__ jobs, int n_jobs, int split, const half_t *__restrict__ act,
-                                                    int64_t n_tiles, int rows, float inv_scale, float *g0, float *g1, float *g2) {
+// A group = up to 2 x 2 jobs of one matrix that share their dOut row tiles and their In row tiles.
+struct WgradGroup {
+    int32_t no, ni;       // dOut tiles and In tiles in the group (1 or 2 each)
+    int32_t job[2][2];    // job[o][i]
+};
+
+// one wave = one (group, chunk of 64-sample tiles): D[o][i][32][32] += dOut_o^T[32][16 samples] * In_i^T[16 samples][32],
+// four MFMA steps per tile and (o, i); the 32 rows of each operand are one contiguous 4 KB block of the tile-major
+// activation matrix.  Register blocking 2 x 2 reads each activation row once per two output tiles: the kernel is bound
+// by re-reading the activations (44 jobs x 64 rows -> 14 groups, -43 % bytes), not by the MFMAs.
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__ jobs, const WgradGroup *__restrict__ groups, int n_groups,
+                                                    int split, const half_t *__restrict__ act, int64_t n_tiles, int rows, float inv_scale,
+                                                    float *g0, float *g1, float *g2) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= n_jobs * split) return;
-    const WgradJob &jb = jobs[wid / split];
+    if (wid >= n_groups * split) return;
+    const WgradGroup gp = groups[wid / split];
     const int part = wid % split;
     const int64_t t0 = n_tiles * part / split, t1 = n_tiles * (part + 1) / split;
     const int r = lane & 31, h = lane >> 5;
-    f32x16 acc;
+    const bool o2 = gp.no > 1, i2 = gp.ni > 1;   // wave-uniform
+    const int dout0 = jobs[gp.job[0][0]].dout_row0, dout1 = o2 ? jobs[gp.job[1][0]].dout_row0 : dout0;
+    const int in0 = jobs[gp.job[0][0]].in_row0, in1 = i2 ? jobs[gp.job[0][1]].in_row0 : in0;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[o][i][k] = 0.0f;
     for (int64_t t = t0; t < t1; ++t) {
-        const half_t *pa = act + ((t * rows + jb.dout_row0 + r) * 64) + 8 * h;
-        const half_t *pb = act + ((t * rows + jb.in_row0 + r) * 64) + 8 * h;
-        half8 a[4], b[4];
+        const half_t *base = act + (t * rows + r) * 64 + 8 * h;
+        half8 a[2][4], b[2][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            a[q] = *reinterpret_cast<const half8 *>(pa + 16 * q);
-            b[q] = *reinterpret_cast<const half8 *>(pb + 16 * q);
+            a[0][q] = *reinterpret_cast<const half8 *>(base + dout0 * 64 + 16 * q);
+            b[0][q] = *reinterpret_cast<const half8 *>(base + in0 * 64 + 16 * q);
         }
+        if (o2)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = mfma(a[q], b[q], acc);
-    }
-    float *g = jb.buf == 0 ? g0 : (jb.buf == 1 ? g1 : g2);
-    const int col = jb.colmap[r];
-    if (col < 0) return;
+            for (int q = 0; q < 4; ++q) a[1][q] = *reinterpret_cast<const half8 *>(base + dout1 * 64 + 16 * q);
+        if (i2)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (row < jb.n_valid) atomicAdd(g + jb.param_off + (int64_t)(jb.n0 + row) * jb.stride + col, acc[i] * inv_scale);
+            for (int q = 0; q < 4; ++q) b[1][q] = *reinterpret_cast<const half8 *>(base + in1 * 64 + 16 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[0][0] = mfma(a[0][q], b[0][q], acc[0][0]);
+        if (i2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[0][1] = mfma(a[0][q], b[1][q], acc[0][1]);
+        if (o2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[1][0] = mfma(a[1][q], b[0][q], acc[1][0]);
+            if (i2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[1][1] = mfma(a[1][q], b[1][q], acc[1][1]);
+        }
     }
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (o >= gp.no || i >= gp.ni) continue;
+            const WgradJob &jb = jobs[gp.job[o][i]];
+            float *g = jb.buf == 0 ? g0 : (jb.buf == 1 ? g1 : g2);
+            const int col = jb.colmap[r];
+            if (col < 0) continue;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
+                if (row < jb.n_valid) atomicAdd(g + jb.param_off + (int64_t)(jb.n0 + row) * jb.stride + col, acc[o][i][k] * inv_scale);
+            }
+        }
 }
 
 // ------------------------------------------------------------------ hash-grid gradient scatter
@@ -389,6 +427,7 @@ static void append_matrix_T(std::vector<int32_t> &t, int buf, int64_t off, int n
 struct TrainTables {
     std::vector<int32_t> fragT;
     std::vector<WgradJob> jobs;
+    std::vector<WgradGroup> groups;
     int rows, mask_blocks;
 };
 
@@ -403,6 +442,19 @@ static void add_jobs(std::vector<WgradJob> &jobs, int buf, int64_t off, int n_ou
             if (j.n_valid < 0) j.n_valid = 0;
             for (int k = 0; k < 32; ++k) j.colmap[k] = colmap(cm, 32 * it + k, n_in_real);
             jobs.push_back(j);
+        }
+}
+
+// 2 x 2 groups over the (n_out_tiles x n_in_tiles) jobs of one matrix, which add_jobs appended row-major at `first`
+static void add_groups(std::vector<WgradGroup> &groups, int first, int n_out_tiles, int n_in_tiles) {
+    for (int ot = 0; ot < n_out_tiles; ot += 2)
+        for (int it = 0; it < n_in_tiles; it += 2) {
+            WgradGroup g;
+            g.no = n_out_tiles - ot < 2 ? 1 : 2; g.ni = n_in_tiles - it < 2 ? 1 : 2;
+            for (int o = 0; o < 2; ++o)
+                for (int i = 0; i < 2; ++i)
+                    g.job[o][i] = first + (ot + (o < g.no ? o : 0)) * n_in_tiles + it + (i < g.ni ? i : 0);
+            groups.push_back(g);
         }
 }
 
@@ -427,23 +479,30 @@ static TrainTables build_tables(int C) {
     append_matrix_T(t, 0, b_out, 16, W, W, W / 32, C_IDENT, T_ACC, 1);                  // o_bo
     for (int l = 0; l < NH - 1; ++l) append_matrix_T(t, 0, b_hid + (int64_t)l * W * W, W, W, W, W / 32, C_IDENT, T_ACC, W / 16);   // o_bh
     append_matrix_T(t, 0, b_in, W, 64, 64, 2, C_IDENT, T_ACC, W / 16);                  // o_b1
-    // weight-gradient jobs: (dOut rows, In rows)
+    // weight-gradient jobs: (dOut rows, In rows), grouped 2 x 2 per matrix
     auto &j = tt.jobs;
-    add_jobs(j, 0, b_in, W, 64, 64, T::rdZ0, W / 32, T::rX, 2, C_IDENT);
+    auto matrix = [&](int buf, int64_t off, int n_out_real, int stride, int n_in_real, int dout_row0, int n_out_tiles, int in_row0,
+                      int n_in_tiles, ColMap cm) {
+        const int first = (int)j.size();
+        add_jobs(j, buf, off, n_out_real, stride, n_in_real, dout_row0, n_out_tiles, in_row0, n_in_tiles, cm);
+        add_groups(tt.groups, first, n_out_tiles, n_in_tiles);
+        return first;
+    };
+    matrix(0, b_in, W, 64, 64, T::rdZ0, W / 32, T::rX, 2, C_IDENT);
     for (int l = 0; l < NH - 1; ++l)
-        add_jobs(j, 0, b_hid + (int64_t)l * W * W, W, W, W, T::rdZ0 + (l + 1) * W, W / 32, T::rH0 + l * W, W / 32, C_IDENT);
-    add_jobs(j, 0, b_out, 16, W, W, T::rdBO, 1, T::rH0 + (NH - 1) * W, W / 32, C_IDENT);
+        matrix(0, b_hid + (int64_t)l * W * W, W, W, W, T::rdZ0 + (l + 1) * W, W / 32, T::rH0 + l * W, W / 32, C_IDENT);
+    matrix(0, b_out, 16, W, W, T::rdBO, 1, T::rH0 + (NH - 1) * W, W / 32, C_IDENT);
     // rgb head: in = [SH(16) | geo fragment(16)] (contiguous rows rS..rS+31): SH rows map to columns 0..15
     {
-        std::vector<WgradJob> tmp;
-        add_jobs(tmp, 1, h_in, Wh, 32, 32, T::rdZr1, Wh / 32, T::rS, 1, C_IDENT);
-        for (auto &jb : tmp) { for (int k = 0; k < 16; ++k) { jb.colmap[k] = k; jb.colmap[16 + k] = colmap(C_GEO_RGB, k, 32); } j.push_back(jb); }
+        const int first = matrix(1, h_in, Wh, 32, 32, T::rdZr1, Wh / 32, T::rS, 1, C_IDENT);
+        for (size_t q = first; q < j.size(); ++q)
+            for (int k = 0; k < 16; ++k) { j[q].colmap[k] = k; j[q].colmap[16 + k] = colmap(C_GEO_RGB, k, 32); }
     }
-    add_jobs(j, 1, h_hid, Wh, Wh, Wh, T::rdZr2, Wh / 32, T::rHH1, Wh / 32, C_IDENT);
-    add_jobs(j, 1, h_out, 16, Wh, Wh, T::rdYr, 1, T::rHH2, Wh / 32, C_IDENT);
-    add_jobs(j, 2, s_in, Wh, 16, 16, T::rdZs1, Wh / 32, T::rG, 1, C_GEO_SEM);
-    add_jobs(j, 2, s_hid, Wh, Wh, Wh, T::rdZs2, Wh / 32, T::rHS1, Wh / 32, C_IDENT);
-    add_jobs(j, 2, s_out, sem_pad, Wh, Wh, T::rdYs, 1, T::rHS2, Wh / 32, C_IDENT);
+    matrix(1, h_hid, Wh, Wh, Wh, T::rdZr2, Wh / 32, T::rHH1, Wh / 32, C_IDENT);
+    matrix(1, h_out, 16, Wh, Wh, T::rdYr, 1, T::rHH2, Wh / 32, C_IDENT);
+    matrix(2, s_in, Wh, 16, 16, T::rdZs1, Wh / 32, T::rG, 1, C_GEO_SEM);
+    matrix(2, s_hid, Wh, Wh, Wh, T::rdZs2, Wh / 32, T::rHS1, Wh / 32, C_IDENT);
+    matrix(2, s_out, sem_pad, Wh, Wh, T::rdYs, 1, T::rHS2, Wh / 32, C_IDENT);
     return tt;
 }
 
@@ -478,6 +537,7 @@ struct TrainState {
     int32_t *d_fragT_src = nullptr;
     half_t *d_fragT = nullptr;
     WgradJob *d_jobs = nullptr;
+    WgradGroup *d_groups = nullptr;
 };
 
 static int ensure_train_state(mnf_field_t f) {
@@ -491,6 +551,8 @@ static int ensure_train_state(mnf_field_t f) {
     hipError_t e = hipMalloc((void **)&ts->d_fragT_src, ts->tt.fragT.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ts->d_fragT, ts->tt.fragT.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ts->d_jobs, ts->tt.jobs.size() * sizeof(WgradJob));
+    if (e == hipSuccess) e = hipMalloc((void **)&ts->d_groups, ts->tt.groups.size() * sizeof(WgradGroup));
+    if (e == hipSuccess) e = hipMemcpy(ts->d_groups, ts->tt.groups.data(), ts->tt.groups.size() * sizeof(WgradGroup), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_fragT_src, ts->tt.fragT.data(), ts->tt.fragT.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_jobs, ts->tt.jobs.data(), ts->tt.jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -508,6 +570,7 @@ void free_train_state(mnf_field_t f) {
     if (ts->d_fragT_src) (void)hipFree(ts->d_fragT_src);
     if (ts->d_fragT) (void)hipFree(ts->d_fragT);
     if (ts->d_jobs) (void)hipFree(ts->d_jobs);
+    if (ts->d_groups) (void)hipFree(ts->d_groups);
     delete ts;
     f->train_state = nullptr;
 }
@@ -615,15 +678,15 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     rc = launch_status("dgrad_kernel");
     if (rc) return rc;
     // weight gradients
-    const int n_jobs = (int)ts->tt.jobs.size();
-    // enough sample chunks to fill the chip with waves (the loop is load-latency bound: ~32 waves per CU), but
-    // at least 16 MFMA steps per wave so the final atomics stay negligible
+    const int n_groups = (int)ts->tt.groups.size();
+    // enough sample chunks to fill the chip with waves (the loop is load-latency bound; 2 x 2 blocking leaves room for
+    // ~3 waves per SIMD), but at least 16 tiles per wave so the final atomics stay negligible
     const int64_t n_tiles = v.Np / 64;
-    int split = (int)(256 * 32 / n_jobs);
-    if (split > n_tiles / 4) split = (int)(n_tiles / 4);
+    int split = (int)(256 * 12 / n_groups);
+    if (split > n_tiles / 16) split = (int)(n_tiles / 16);
     if (split < 1) split = 1;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_jobs * split, 4)), dim3(256), 0, s, ts->d_jobs, n_jobs, split,
-                       v.act, n_tiles, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * split, 4)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
+                       split, v.act, n_tiles, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem);
     rc = launch_status("wgrad_kernel");
     if (rc) return rc;
     // hash-table gradient
