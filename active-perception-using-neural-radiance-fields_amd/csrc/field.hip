@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(h, (lane & 31) + 32 * ct);
         }
-        half8 *mdump = SAVE ? args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
+        uint8_t *mdump = SAVE ? args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
         if (SAVE) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
                 for (int k = 0; k < L::KSW; ++k) {
                     save_rows<true>(args.train, tile, T::rH0 + 16 * k, so[ct], hb[ct][k]);
-                    mdump[((T::mH0 + k) * CT + ct) * 64] = hb[ct][k];
+                    mdump[((T::mH0 + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
                 }
         }
 #pragma unroll
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
                     for (int k = 0; k < L::KSW; ++k) {
                         save_rows<true>(args.train, tile, T::rH0 + (l + 1) * W + 16 * k, so[ct], hb[ct][k]);
-                        mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = hb[ct][k];
+                        mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
                     }
             }
         }
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
                 for (int k = 0; k < L::KSh; ++k) {
                     save_rows<true>(args.train, tile, row0 + 16 * k, so[ct], a[ct][k]);
-                    mdump[((mblk + k) * CT + ct) * 64] = a[ct][k];
+                    mdump[((mblk + k) * CT + ct) * 64] = frag_mask(a[ct][k]);
                 }
         };
         // rgb head (ngp.py:143-156, :202-213)

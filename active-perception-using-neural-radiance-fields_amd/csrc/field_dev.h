@@ -42,8 +42,8 @@ struct Layout {
 //  * `act`: feature-major fp16 tiles ACT[tile][row][64 samples] (Np = samples rounded up to 64) — every row is one
 //    feature over the 64 samples of a tile, so the weight-gradient GEMM reads its MFMA operands (8 consecutive
 //    samples of one feature) as plain 16-byte loads, and the 32 rows of an operand tile are one contiguous 4 KB block;
-//  * `masks`: the post-ReLU hidden activations dumped as the half8 B fragments they already are
-//    ([tile][block][ct][lane]), which line up register-for-register with the accumulators of the backward chain.
+//  * `masks`: one byte per post-ReLU hidden B fragment and lane ([tile][block][ct][lane]): bit frag_mask_bit(j) says
+//    whether element j is non-zero; fragments line up register-for-register with the accumulators of the backward chain.
 template <int W, int NH>
 struct TrainLayout {
     static constexpr int Wh = W / 2;
@@ -71,10 +71,24 @@ struct TrainLayout {
 
 struct TrainBuf {
     half_t *act;      // [tiles][rows][64]
-    half8 *masks;     // [tiles][mask_blocks][CT][64]
+    uint8_t *masks;   // [tiles][mask_blocks][CT][64]
     int64_t Np;
     int32_t rows;
 };
+
+// ReLU mask of a post-ReLU fp16 fragment as one byte: element j -> bit frag_mask_bit(j).  For non-negative halves
+// "non-zero" is "integer value >= 1": adding 0x7FFF carries into bit 15 of each half without crossing into the other.
+__device__ __forceinline__ constexpr int frag_mask_bit(int j) { return (j & 1) * 4 + (j >> 1); }
+__device__ __forceinline__ uint8_t frag_mask(const half8 &f) {
+    const u32x4 d = __builtin_bit_cast(u32x4, f);
+    uint32_t u = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t t = ((d[i] & 0x7FFF7FFFu) + 0x7FFF7FFFu) & 0x80008000u;   // bit 15: element 2i, bit 31: element 2i+1
+        u |= t >> (15 - i);
+    }
+    return (uint8_t)((u & 0xFu) | ((u >> 12) & 0xF0u));
+}
 
 struct KernelArgs {
     const half4 *table;

@@ -66,7 +66,7 @@ __device__ __forceinline__ void dense_tile(const half8 *__restrict__ w_lds, int 
 // stored feature-major at row0 for the weight gradient.
 template <int RT_OUT, int KS>
 __device__ __forceinline__ void dense_mask(const half8 *__restrict__ w_lds, int lane, int h, const half8 (&b)[CT][KS],
-                                           const half8 *__restrict__ masks, const TrainBuf &tb, int64_t tile, int row0,
+                                           const uint8_t *__restrict__ masks, const TrainBuf &tb, int64_t tile, int row0,
                                            const SaveOff (&so)[CT], half8 (&o)[CT][RT_OUT * 2]) {
 #pragma unroll
     for (int rt = 0; rt < RT_OUT; ++rt) {
@@ -76,10 +76,10 @@ __device__ __forceinline__ void dense_mask(const half8 *__restrict__ w_lds, int 
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const half8 m = masks[((rt * 2 + s) * CT + ct) * 64];
+                const uint32_t m = masks[((rt * 2 + s) * CT + ct) * 64];
                 half8 v;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (m[j] != (half_t)0.0f) ? (half_t)acc[ct][8 * s + j] : (half_t)0.0f;
+                for (int j = 0; j < 8; ++j) v[j] = ((m >> frag_mask_bit(j)) & 1u) ? (half_t)acc[ct][8 * s + j] : (half_t)0.0f;
                 o[ct][rt * 2 + s] = v;
                 save_rows<true>(tb, tile, row0 + 16 * (rt * 2 + s), so[ct], v);
             }
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
         SaveOff so[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(h, c + 32 * ct);
-        const half8 *mdump = args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane;
+        const uint8_t *mdump = args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane;
         // ---- output-layer gradients, built directly as natural-order B fragments ----
         half8 dyr[CT][1], dys[CT][2];
         float dlogit[CT];
@@ -576,7 +576,7 @@ void free_train_state(mnf_field_t f) {
 }
 
 struct WsView {
-    half_t *act; half8 *masks; float *dX;
+    half_t *act; uint8_t *masks; float *dX;
     int64_t Np, bytes;
 };
 
@@ -586,7 +586,7 @@ static WsView carve_train(const TrainTables &tt, void *base, int64_t n) {
     size_t off = 0;
     auto take = [&](size_t b) { char *p = base ? (char *)base + off : nullptr; off += (b + 255) & ~(size_t)255; return p; };
     v.act = (half_t *)take((size_t)tt.rows * v.Np * 2);
-    v.masks = (half8 *)take((size_t)(v.Np / 64) * tt.mask_blocks * CT * 64 * 16);
+    v.masks = (uint8_t *)take((size_t)(v.Np / 64) * tt.mask_blocks * CT * 64);
     v.dX = (float *)take((size_t)v.Np * 64 * 4);
     v.bytes = (int64_t)off;
     return v;
