@@ -107,6 +107,78 @@ __global__ void __launch_bounds__(256) traverse_kernel(int32_t n_rays, const flo
     }
 }
 
+// ------------------------------------------------------------------ single-pass sampler (one grid level)
+// `OccGridEstimator.sampling` (occ_grid.py:80-238) only needs (t_start, t_end, ray) per sample, and a ray is one long
+// sequential chain (~1 ms for the longest training ray), so marching every ray twice (count pass, fill pass:
+// grid.cu:320-474) doubles the latency.  Here every ray is marched once into its own row of a caller-provided scratch
+// [n_rays][cap]; rows are then packed by `compact_samples_kernel`.  A ray with more than `cap` samples only counts
+// (the host mirror then falls back to the two-pass traversal).  The occupancy grid is bit-packed into LDS by each
+// workgroup (a dependent global load per visited cell otherwise).  Same t values as traverse_kernel, bit for bit.
+constexpr int kSamplerGridWords = 16384;   // 64 KB of LDS = 524 288 cells
+
+struct ScratchSink {
+    float *ts, *te;
+    int32_t cap;
+    __device__ __forceinline__ void sample(float t_last, float t_next, bool, int32_t k) {
+        if (k < cap) { ts[k] = t_last; te[k] = t_next; }
+    }
+};
+
+template <bool LDS_GRID>
+__global__ void __launch_bounds__(256) sample_rays_kernel(int32_t n_rays, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                          I3 res, const uint8_t *__restrict__ binaries, float a0, float a1, float a2,
+                                                          float a3, float a4, float a5, const float *__restrict__ near_planes,
+                                                          const float *__restrict__ far_planes, float step_size, float cone_angle,
+                                                          int32_t cap, float *__restrict__ scratch_ts, float *__restrict__ scratch_te,
+                                                          int64_t *__restrict__ counts) {
+    __shared__ uint32_t s_bits[LDS_GRID ? kSamplerGridWords : 1];
+    const int64_t cells = (int64_t)res.x * res.y * res.z;
+    if (LDS_GRID) {
+        const int n_words = (int)((cells + 31) / 32);
+        for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
+            uint32_t v = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int64_t c = (int64_t)w * 32 + b;
+                if (c < cells && binaries[c]) v |= 1u << b;
+            }
+            s_bits[w] = v;
+        }
+        __syncthreads();
+    }
+    const float ab[6] = {a0, a1, a2, a3, a4, a5};
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += blockDim.x * gridDim.x) {
+        const F3 org = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+        const F3 dir = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+        const F3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+        const float near_plane = near_planes[r], far_plane = far_planes[r];
+        MarchState st = {near_plane, false, 0};
+        ScratchSink sink = {scratch_ts + (int64_t)r * cap, scratch_te + (int64_t)r * cap, cap};
+        float t0, t1;
+        if (ray_aabb(org, inv, -INFINITY, INFINITY, ab, t0, t1)) {   // grid.py:150-160 default planes, then grid.cu:125-151
+            const float this_tmin = fmaxf(t0, near_plane), this_tmax = fminf(t1, far_plane);
+            if (this_tmin < this_tmax) {
+                if (LDS_GRID) march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, BitGrid{s_bits}, step_size, cone_angle, 0, st, sink);
+                else march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, ByteGrid{binaries}, step_size, cone_angle, 0, st, sink);
+            }
+        }
+        counts[r] = st.n_samples;
+    }
+}
+
+// one wave per ray: scratch row -> packed position
+__global__ void __launch_bounds__(64) compact_samples_kernel(const float *__restrict__ scratch_ts, const float *__restrict__ scratch_te,
+                                                             int32_t cap, const int64_t *__restrict__ chunk_starts,
+                                                             const int64_t *__restrict__ counts, int32_t n_rays,
+                                                             float *__restrict__ t_starts, float *__restrict__ t_ends,
+                                                             int64_t *__restrict__ ray_indices) {
+    for (int32_t r = blockIdx.x; r < n_rays; r += gridDim.x) {
+        const int64_t s = chunk_starts[r];
+        const int c = (int)counts[r];
+        const float *ts = scratch_ts + (int64_t)r * cap, *te = scratch_te + (int64_t)r * cap;
+        for (int k = threadIdx.x; k < c; k += 64) { t_starts[s + k] = ts[k]; t_ends[s + k] = te[k]; ray_indices[s + k] = r; }
+    }
+}
+
 // ------------------------------------------------------------------ packed scans
 // One lane per ray: chunks are short (<= a few hundred samples) and consecutive lanes own
 // consecutive chunks, so the wave streams a contiguous window.  Sequential fp32 order == oracle.
@@ -257,6 +329,37 @@ extern "C" int mnf_traverse_grids(const float *rays_o, const float *rays_d, cons
                        rays_mask, n_grids, res, binaries, aabbs, hits, t_sorted, t_indices, near_planes, far_planes,
                        step_size, cone_angle, traverse_steps_limit, first_pass != 0, iv, sm, terminate_planes);
     return launch_status("traverse_kernel");
+}
+
+extern "C" int mnf_sample_rays(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries, int32_t res_x,
+                               int32_t res_y, int32_t res_z, const float *aabb_host, const float *near_planes, const float *far_planes,
+                               float step_size, float cone_angle, int32_t cap, float *scratch_ts, float *scratch_te, int64_t *counts,
+                               mnf_stream_t stream) {
+    if (n_rays == 0) return MNF_OK;
+    MNF_REQUIRE(rays_o && rays_d && binaries && aabb_host && near_planes && far_planes && scratch_ts && scratch_te && counts,
+                "sample_rays: null pointer");
+    MNF_REQUIRE(res_x > 0 && res_y > 0 && res_z > 0 && cap > 0 && step_size > 0.f, "sample_rays: bad sizes");
+    const I3 res = {res_x, res_y, res_z};
+    const float *ab = aabb_host;
+    const bool lds = (int64_t)res_x * res_y * res_z <= (int64_t)kSamplerGridWords * 32;
+    const int grid = grid_for(n_rays, 256);
+    if (lds)
+        hipLaunchKernelGGL(sample_rays_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, ab[0],
+                           ab[1], ab[2], ab[3], ab[4], ab[5], near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts);
+    else
+        hipLaunchKernelGGL(sample_rays_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, ab[0],
+                           ab[1], ab[2], ab[3], ab[4], ab[5], near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts);
+    return launch_status("sample_rays_kernel");
+}
+
+extern "C" int mnf_compact_samples(const float *scratch_ts, const float *scratch_te, int32_t cap, const int64_t *chunk_starts,
+                                   const int64_t *counts, int32_t n_rays, float *t_starts, float *t_ends, int64_t *ray_indices,
+                                   mnf_stream_t stream) {
+    if (n_rays == 0) return MNF_OK;
+    MNF_REQUIRE(scratch_ts && scratch_te && chunk_starts && counts && cap > 0, "compact_samples: null pointer");
+    hipLaunchKernelGGL(compact_samples_kernel, dim3(n_rays < 65535 ? n_rays : 65535), dim3(64), 0, as_stream(stream), scratch_ts, scratch_te,
+                       cap, chunk_starts, counts, n_rays, t_starts, t_ends, ray_indices);
+    return launch_status("compact_samples_kernel");
 }
 
 extern "C" int mnf_exclusive_sum(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,

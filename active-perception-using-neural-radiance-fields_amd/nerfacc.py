@@ -340,12 +340,16 @@ class OccGridEstimator(torch.nn.Module):
             far_planes = torch.clamp(far_planes, max=t_max)
         if stratified:
             near_planes += torch.rand_like(near_planes) * render_step_size
-        intervals, samples, _ = traverse_grids(rays_o, rays_d, self.binaries, self.aabbs, near_planes=near_planes,
-                                               far_planes=far_planes, step_size=render_step_size, cone_angle=cone_angle)
-        t_starts = intervals.vals[intervals.is_left]
-        t_ends = intervals.vals[intervals.is_right]
-        ray_indices = samples.ray_indices
-        packed_info = samples.packed_info
+        packed = self._sample_single_pass(rays_o, rays_d, near_planes, far_planes, render_step_size, cone_angle)
+        if packed is not None:
+            ray_indices, t_starts, t_ends, packed_info = packed
+        else:
+            intervals, samples, _ = traverse_grids(rays_o, rays_d, self.binaries, self.aabbs, near_planes=near_planes,
+                                                   far_planes=far_planes, step_size=render_step_size, cone_angle=cone_angle)
+            t_starts = intervals.vals[intervals.is_left]
+            t_ends = intervals.vals[intervals.is_right]
+            ray_indices = samples.ray_indices
+            packed_info = samples.packed_info
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             alpha_thre = min(alpha_thre, self.occs.mean().item())
             if sigma_fn is not None:
@@ -362,6 +366,49 @@ class OccGridEstimator(torch.nn.Module):
                     masks = masks & (alphas >= alpha_thre)
             ray_indices, t_starts, t_ends = ray_indices[masks], t_starts[masks], t_ends[masks]
         return ray_indices, t_starts, t_ends
+
+    @torch.no_grad()
+    def _sample_single_pass(self, rays_o, rays_d, near_planes, far_planes, step_size, cone_angle, cap=None):
+        """One traversal instead of the count + fill pair of `traverse_grids` (csrc/march.hip, sample_rays_kernel): rays
+        are marched once into a bounded scratch and the rows are packed afterwards; the result is the one `traverse_grids`
+        gives, bit for bit.  Returns None (caller uses the two-pass path) for multi-level grids, step_size <= 0 or when a ray
+        overflows its scratch row."""
+        if self.levels != 1 or step_size <= 0.0 or rays_o.dim() != 2 or not rays_o.is_cuda:
+            return None
+        n = rays_o.shape[0]
+        dev = rays_o.device
+        if n == 0:
+            return None
+        if cap is None:
+            cap = int(max(64, min(2048, (1 << 27) // n)))   # scratch <= 1 GiB; longest reference-config ray: ~1400 samples
+        b = self.binaries
+        b = b.contiguous().view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8).contiguous()
+        key = (self.aabbs.data_ptr(), self.aabbs._version)
+        if getattr(self, "_aabb_host_key", None) != key:
+            self._aabb_host = [float(x) for x in self.aabbs[0].detach().cpu().tolist()]
+            self._aabb_host_key = key
+        import ctypes
+        aabb_host = (ctypes.c_float * 6)(*self._aabb_host)
+        rays_o, rays_d = L.contig(rays_o, torch.float32), L.contig(rays_d, torch.float32)
+        near_planes, far_planes = L.contig(near_planes, torch.float32), L.contig(far_planes, torch.float32)
+        scratch = torch.empty((2, n, cap), device=dev, dtype=torch.float32)
+        counts = torch.empty((n,), device=dev, dtype=torch.int64)
+        res = [int(x) for x in b.shape[1:]]
+        lib = L.load_library()
+        L.check(lib.mnf_sample_rays(L.ptr(rays_o), L.ptr(rays_d), n, L.ptr(b), res[0], res[1], res[2], aabb_host, L.ptr(near_planes),
+                                    L.ptr(far_planes), float(step_size), float(cone_angle), cap, L.ptr(scratch[0]), L.ptr(scratch[1]),
+                                    L.ptr(counts), L.stream()))
+        cum = counts.cumsum(0)
+        total, longest = (int(x) for x in torch.stack([cum[-1], counts.max()]).tolist())   # the one sync (data_spec.hpp:91 has it too)
+        if longest > cap:
+            return None
+        starts = cum - counts
+        t_starts, t_ends = torch.empty((total,), device=dev), torch.empty((total,), device=dev)
+        ray_indices = torch.empty((total,), device=dev, dtype=torch.int64)
+        if total:
+            L.check(lib.mnf_compact_samples(L.ptr(scratch[0]), L.ptr(scratch[1]), cap, L.ptr(starts), L.ptr(counts), n, L.ptr(t_starts),
+                                            L.ptr(t_ends), L.ptr(ray_indices), L.stream()))
+        return ray_indices, t_starts, t_ends, torch.stack([starts, counts], dim=-1)
 
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,

@@ -67,6 +67,22 @@ int mnf_traverse_grids(const float *rays_o, const float *rays_d, const uint8_t *
                        const int64_t *sm_chunk_starts, int64_t *sm_chunk_cnts,
                        float *terminate_planes, mnf_stream_t stream);
 
+/* Single-pass form of the sampling traversal for one grid level (what `OccGridEstimator.sampling`,
+ * occ_grid.py:80-238, needs from `traverse_grids`): every ray is marched ONCE; its samples (t_start, t_end) go to row r of
+ * the caller's scratch [n_rays][cap] and counts[r] receives the ray's full sample count (rows are truncated at cap:
+ * if any count exceeds cap the caller falls back to mnf_traverse_grids).  aabb_host: 6 host floats.  The t values are
+ * those of mnf_traverse_grids, bit for bit. */
+int mnf_sample_rays(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries, int32_t res_x,
+                    int32_t res_y, int32_t res_z, const float *aabb_host, const float *near_planes, const float *far_planes,
+                    float step_size, float cone_angle, int32_t cap, float *scratch_ts, float *scratch_te, int64_t *counts,
+                    mnf_stream_t stream);
+
+/* Pack the scratch rows: samples of ray r go to [chunk_starts[r], chunk_starts[r] + counts[r]) of t_starts / t_ends /
+ * ray_indices (chunk_starts = exclusive prefix of counts, `RaySegmentsSpec::memalloc_data_from_chunk`, data_spec.hpp:86-96). */
+int mnf_compact_samples(const float *scratch_ts, const float *scratch_te, int32_t cap, const int64_t *chunk_starts,
+                        const int64_t *counts, int32_t n_rays, float *t_starts, float *t_ends, int64_t *ray_indices,
+                        mnf_stream_t stream);
+
 /* nerfacc.cpp:104 `exclusive_sum` (scan.cu:68-125); backward=1 is the reverse-direction scan
  * used by the autograd rule (scan.py:226-228). */
 int mnf_exclusive_sum(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,

@@ -130,6 +130,39 @@ def test_traverse_grids_chunked_bit_exact(scene):
 
 
 # ------------------------------------------------------------------ ray generation (bit-exact vs the reference golden)
+@pytest.mark.parametrize("cone,stratified", [(0.004, False), (0.0, False), (0.004, True)])
+def test_single_pass_sampler_bit_exact(scene, cone, stratified):
+    """csrc/march.hip sample_rays_kernel + compact_samples_kernel (what OccGridEstimator.sampling runs) against the
+    two-pass traverse_grids of the same library and against the oracle marcher: identical samples, bit for bit."""
+    from apnrf_amd import nerfacc as NA
+    from oracle import marcher as M
+    est = H.hip_estimator(scene)
+    o, d = H.view_rays(scene, 2, h=24, w=24)
+    o, d = o.to(DEV), d.to(DEV)
+    step = 1e-3 if cone > 0 else 2e-2
+    near = torch.full((o.shape[0],), 0.1, device=DEV)
+    if stratified:
+        near = near + torch.rand(o.shape[0], generator=torch.Generator().manual_seed(5)).to(DEV) * step
+    far = torch.full_like(near, 1e10)
+    got = est._sample_single_pass(o, d, near, far, step, cone)
+    assert got is not None
+    ri, ts, te, packed = got
+    iv, sm, _ = NA.traverse_grids(o, d, est.binaries, est.aabbs, near_planes=near, far_planes=far, step_size=step, cone_angle=cone)
+    np.testing.assert_array_equal(ts.cpu().numpy(), iv.vals[iv.is_left].cpu().numpy())
+    np.testing.assert_array_equal(te.cpu().numpy(), iv.vals[iv.is_right].cpu().numpy())
+    np.testing.assert_array_equal(ri.cpu().numpy(), sm.ray_indices.cpu().numpy())
+    np.testing.assert_array_equal(packed.cpu().numpy(), sm.packed_info.cpu().numpy())
+    assert ts.shape[0] > 1000
+    ref = M.traverse_grids(o.cpu().numpy(), d.cpu().numpy(), scene["occ"], scene["aabb"][None], near_planes=near.cpu().numpy(),
+                           far_planes=far.cpu().numpy(), step_size=step, cone_angle=cone)
+    np.testing.assert_array_equal(ts.cpu().numpy(), ref[0].vals[ref[0].is_left])
+    # a scratch row that is too short is reported, not truncated silently: the mirror falls back to two passes
+    assert int(packed[:, 1].max()) > 16 and est._sample_single_pass(o, d, near, far, step, cone, cap=16) is None
+    ri2, ts2, te2 = est.sampling(o, d, near_plane=0.1, render_step_size=step, cone_angle=cone)
+    if not stratified:
+        np.testing.assert_array_equal(ts2.cpu().numpy(), ts.cpu().numpy())
+
+
 def test_generate_image_rays_bit_exact(golden):
     from apnrf_amd import render as RD
     g = golden("raygen")
