@@ -223,11 +223,29 @@ def render_image_with_occgrid_with_depth_guide(radiance_field, estimator, rays: 
     return colors.view(*shp, -1), opacities.view(*shp, -1), depths.view(*shp, -1), semantics.view(*shp, -1), sum(r[4] for r in results)
 
 
+def allreduce_gradients(parameters, group=None):
+    """Ray-data-parallel training: every rank renders its own slice of the ray batch, then the gradients of
+    the three flat parameter vectors are averaged with one all-reduce each (RCCL over xGMI on GPUs; the hash-table vector
+    is 100 MB, the two heads a few KB).  No-op without an initialised process group of more than one rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(group)
+    if world < 2:
+        return
+    for p_ in parameters:
+        if p_.grad is not None:
+            dist.all_reduce(p_.grad, op=dist.ReduceOp.SUM, group=group)
+            p_.grad.div_(world)
+
+
 def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, sem, render_bkgd, step: int,
-               near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-3, scheduler=None):
+               near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-3, scheduler=None,
+               data_parallel_group=None, data_parallel=False):
     """One model's training iteration exactly as scripts/pipeline.py:447-532 sequences it: occupancy refresh every 16th
     step (:447-470), train render (:472-489), loss 10*smoothL1(rgb) + smoothL1(depth)/5 + CE(sem)/2 (:506-511),
-    backward (:518), NaN-gradient guard (:520-529), optimizer and scheduler step (:531-532).
+    backward (:518), NaN-gradient guard (:520-529), optimizer and scheduler step (:531-532).  `data_parallel=True`
+    averages the gradients over the ranks of `data_parallel_group` before the guard (each rank holds a slice of the rays).
     Returns dict(loss, loss_rgb, loss_dep, loss_sem as device tensors, n_rendering_samples, skipped)."""
     import torch.nn.functional as F
     radiance_field.train()
@@ -248,6 +266,8 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     loss = loss_rgb * 10 + loss_dep / 5 + loss_sem / 2
     optimizer.zero_grad()
     loss.backward()
+    if data_parallel:
+        allreduce_gradients(radiance_field.parameters(), data_parallel_group)
     bad = torch.zeros((), device=rgb.device)
     for p_ in radiance_field.parameters():
         if p_.grad is not None:

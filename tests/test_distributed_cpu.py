@@ -70,3 +70,36 @@ def test_shard_views_covers_all_views():
                 assert hi - lo <= per
                 seen += list(range(lo, hi))
             assert seen == list(range(V))
+
+
+def _grad_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import apnrf_amd  # noqa: F401
+    from apnrf_amd import render as RD
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (1000, 37, 5)]
+    for p in params[:2]:
+        p.grad = torch.randn(p.shape, generator=g)          # the third parameter has no gradient on any rank
+    RD.allreduce_gradients(params)
+    np.save(os.path.join(out_dir, f"grads_{rank}.npy"), torch.cat([p.grad for p in params[:2]]).numpy())
+    assert params[2].grad is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ray_data_parallel_gradient_average_two_ranks_gloo(tmp_path):
+    """`render.allreduce_gradients` (what `train_step(data_parallel=True)` runs between backward and the NaN guard):
+    both ranks end with the mean of the per-rank gradients."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    per_rank = []
+    for r in range(2):
+        g = torch.Generator().manual_seed(100 + r)
+        per_rank.append(torch.cat([torch.randn(1000, generator=g), torch.randn(37, generator=g)]))
+    mean = ((per_rank[0] + per_rank[1]) / 2).numpy()
+    g0, g1 = np.load(tmp_path / "grads_0.npy"), np.load(tmp_path / "grads_1.npy")
+    np.testing.assert_array_equal(g0, g1)
+    np.testing.assert_allclose(g0, mean, rtol=1e-6, atol=1e-7)
