@@ -12,6 +12,9 @@ struct LevelMeta {
     uint32_t size;    // entries in this level (tcnn params_in_level)
     uint32_t offset;  // first entry of this level in the table
     uint32_t hashed;  // 1: spatial hash, 0: dense
+    // idx / size for any uint32 idx without a branch (dense levels wrap the index as tcnn does):
+    // q = mulhi(div_magic, idx); q = (((idx - q) >> 1) + q) >> div_shift
+    uint32_t div_magic, div_shift;
 };
 
 struct FieldShape {

@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
         TileSample tsm;
         bool valid, selector;
         fetch_sample<MODE, false>(args, cd, col, n, xn, dir, tsm, valid, selector);
+        const LevelMeta *lv = levels_here(args.levels);
         half8 *dst = enc + (tile * 8 + (lane >> 5)) * 64 + (lane & 31);
 #pragma unroll
         for (int l0 = 0; l0 < 16; l0 += LPB) {
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
             half4 v[LPB][8];
 #pragma unroll
             for (int q = 0; q < LPB; ++q) {
-                hash_prep(args.levels[l0 + q], xn, prep[q]);
+                hash_prep(lv[l0 + q], xn, prep[q]);
                 hash_load(args.table, prep[q], v[q]);
             }
 #pragma unroll
@@ -216,6 +217,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         TileSample tsm;
         bool valid, selector;
         fetch_sample<MODE, !DENSITY_ONLY>(args, cd, col, n, xn, dir, tsm, valid, selector);
+        const LevelMeta *lv = levels_here(args.levels);
 
         // ---- hash encode: all 16 levels of this lane's sample (one k-step = 4 levels = 32 gathers in flight),
         //      then trade halves with lane^32 ----
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 half4 v[4 * KSB][8];
 #pragma unroll
                 for (int q = 0; q < 4 * KSB; ++q) {
-                    hash_prep(args.levels[4 * KSB * kb + q], xn, prep[q]);
+                    hash_prep(lv[4 * KSB * kb + q], xn, prep[q]);
                     hash_load(args.table, prep[q], v[q]);
                 }
 #pragma unroll
@@ -429,6 +431,20 @@ static int grid_levels(const mnf_field_config &cfg, LevelMeta *levels, int64_t *
         levels[l].size = (uint32_t)n;
         levels[l].offset = (uint32_t)offset;
         levels[l].hashed = dense > n ? 1u : 0u;
+        {   // round-up magic number for an exact, branch-free unsigned division by n (33-bit multiplier form)
+            const uint32_t d = (uint32_t)n;
+            uint32_t fl = 31; while (!((d >> fl) & 1u)) --fl;
+            if ((d & (d - 1)) == 0) { levels[l].div_magic = 0; levels[l].div_shift = fl - 1; }
+            else {
+                const uint64_t num = 1ull << (32 + fl);
+                uint32_t pm = (uint32_t)(num / d);
+                const uint64_t rem = num % d;
+                pm += pm;
+                const uint64_t twice = rem + rem;
+                if (twice >= d) pm += 1;
+                levels[l].div_magic = pm + 1; levels[l].div_shift = fl;
+            }
+        }
         offset += (int64_t)n;
     }
     *total = offset;
@@ -501,7 +517,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     a.C = f->cfg.num_semantic_classes;
     static const int active_waves = getenv("MNF_FIELD_ACTIVE_WAVES") ? atoi(getenv("MNF_FIELD_ACTIVE_WAVES")) : kWavesPerBlock;
     a.active_waves = active_waves >= 1 && active_waves <= kWavesPerBlock ? active_waves : kWavesPerBlock;
-    std::memcpy(a.levels, f->levels, sizeof(a.levels));
+    a.levels = reinterpret_cast<const LevelMeta *>(reinterpret_cast<const char *>(f->d_frags) + (size_t)f->shape.blocks_total * 1024);
     a.io = io;
 #define MNF_LAUNCH(MODE, DO) hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO>), dim3(grid), dim3(kThreads), 0, stream, a)
     if (train) {

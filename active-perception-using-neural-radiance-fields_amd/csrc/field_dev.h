@@ -96,7 +96,9 @@ struct KernelArgs {
     float aabb[6];
     int C;
     int active_waves;       // experiment knob (MNF_FIELD_ACTIVE_WAVES): waves per workgroup that take tiles, default 8
-    LevelMeta levels[16];   // wave-uniform: read with scalar loads
+    const LevelMeta *levels;   // [16] in device memory, wave-uniform: read with scalar loads where a batch needs them
+                               // (as a by-value kernarg array the 112 dwords were all loaded up front and lived in
+                               // spilled SGPRs: ~1000 v_readlane per tile)
     FieldIO io;
     TrainBuf train;
 };
@@ -202,6 +204,13 @@ __device__ __forceinline__ void exchange_halves(half8 &lo, half8 &hi) {
     lo = __builtin_bit_cast(half8, a); hi = __builtin_bit_cast(half8, b);
 }
 
+// The level table pointer made opaque once per tile, so that the scalar loads of a level's metadata stay next to their
+// use instead of being hoisted out of the tile loop (where they would occupy, and spill, a hundred SGPRs).
+__device__ __forceinline__ const LevelMeta *levels_here(const LevelMeta *p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // One hash level (wave-uniform metadata) for the lane's sample, split in two so that the gathers of several
 // levels can be in flight together: hash_prep computes the 8 byte offsets and the separable trilinear weights,
 // hash_blend consumes the 8 loaded entries.  The blend weight of corner (bx,by,bz) is ((wx*wy)*wz), the same
@@ -242,7 +251,12 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
             idx = (px ^ ty[(corner >> 1) & 1] ^ tz[corner >> 2]) & (m.size - 1u);
         } else {
             idx = px + ty[(corner >> 1) & 1] + tz[corner >> 2];
-            if (idx >= m.size) idx %= m.size;   // only out-of-box positions / the far corner
+            // idx %= m.size (only out-of-box positions / the far corner actually wrap): exact for every uint32 and
+            // branch-free -- the compiler's generic modulo put a rarely taken division loop, and a reload of the spilled
+            // level metadata, behind every corner of every dense level
+            uint32_t q = __umulhi(m.div_magic, idx);
+            q = (((idx - q) >> 1) + q) >> m.div_shift;
+            idx -= q * m.size;
         }
         o.off[corner] = (m.offset + idx) * 8u;   // 32-bit byte offset from the uniform table base (SGPR base + VGPR offset)
     }
