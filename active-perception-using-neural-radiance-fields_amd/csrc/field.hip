@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
         bool valid, selector;
         fetch_sample<MODE, false>(args, cd, col, n, xn, dir, tsm, valid, selector);
         const LevelMeta *lv = levels_here(args.levels);
+        const bool in_box = __ballot(valid && !selector) == 0ull;   // wave-uniform: the cheap dense-level wrap applies
         half8 *dst = enc + (tile * 8 + (lane >> 5)) * 64 + (lane & 31);
 #pragma unroll
         for (int l0 = 0; l0 < 16; l0 += LPB) {
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
             half4 v[LPB][8];
 #pragma unroll
             for (int q = 0; q < LPB; ++q) {
-                hash_prep(lv[l0 + q], xn, prep[q]);
+                hash_prep(lv[l0 + q], xn, prep[q], in_box);
                 hash_load(args.table, prep[q], v[q]);
             }
 #pragma unroll
@@ -218,6 +219,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         bool valid, selector;
         fetch_sample<MODE, !DENSITY_ONLY>(args, cd, col, n, xn, dir, tsm, valid, selector);
         const LevelMeta *lv = levels_here(args.levels);
+        const bool in_box = __ballot(valid && !selector) == 0ull;   // wave-uniform: the cheap dense-level wrap applies
 
         // ---- hash encode: all 16 levels of this lane's sample (one k-step = 4 levels = 32 gathers in flight),
         //      then trade halves with lane^32 ----
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 half4 v[4 * KSB][8];
 #pragma unroll
                 for (int q = 0; q < 4 * KSB; ++q) {
-                    hash_prep(lv[4 * KSB * kb + q], xn, prep[q]);
+                    hash_prep(lv[4 * KSB * kb + q], xn, prep[q], in_box);
                     hash_load(args.table, prep[q], v[q]);
                 }
 #pragma unroll

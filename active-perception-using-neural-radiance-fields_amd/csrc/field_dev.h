@@ -220,7 +220,7 @@ struct LevelPrep {
     float wxy[4], wz[2];
 };
 
-__device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], LevelPrep &o) {
+__device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], LevelPrep &o, bool all_in_box = false) {
     float frac[3];
     uint32_t cell[3];
 #pragma unroll
@@ -251,12 +251,18 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
             idx = (px ^ ty[(corner >> 1) & 1] ^ tz[corner >> 2]) & (m.size - 1u);
         } else {
             idx = px + ty[(corner >> 1) & 1] + tz[corner >> 2];
-            // idx %= m.size (only out-of-box positions / the far corner actually wrap): exact for every uint32 and
-            // branch-free -- the compiler's generic modulo put a rarely taken division loop, and a reload of the spilled
-            // level metadata, behind every corner of every dense level
-            uint32_t q = __umulhi(m.div_magic, idx);
-            q = (((idx - q) >> 1) + q) >> m.div_shift;
-            idx -= q * m.size;
+            // idx %= m.size (only out-of-box positions / the far corner actually wrap).  `all_in_box` is wave-uniform:
+            // with every position inside the unit box the corner coordinates are <= res, so idx < 2*size and one
+            // conditional subtraction is the modulo (unsigned min of idx and idx - size).  Otherwise: exact for every
+            // uint32 and branch-free -- the compiler's generic modulo put a rarely taken division loop, and a reload
+            // of the spilled level metadata, behind every corner of every dense level.
+            if (all_in_box) {
+                idx = min(idx, idx - m.size);
+            } else {
+                uint32_t q = __umulhi(m.div_magic, idx);
+                q = (((idx - q) >> 1) + q) >> m.div_shift;
+                idx -= q * m.size;
+            }
         }
         o.off[corner] = (m.offset + idx) * 8u;   // 32-bit byte offset from the uniform table base (SGPR base + VGPR offset)
     }
