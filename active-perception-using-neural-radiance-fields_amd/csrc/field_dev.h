@@ -274,13 +274,25 @@ __device__ __forceinline__ void hash_load(const half4 *__restrict__ table, const
         v[corner] = *reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + p.off[corner]);
 }
 
+// acc = fma((float)half, w, acc) in ONE instruction: v_fma_mix_f32 reads the fp16 operand straight from one half of a
+// 32-bit register (exact widening, single rounding: the same value as cvt + fma).  The compiler's own choice was two
+// v_cvt_f32_f16 per dword plus a packed fp32 fma: 6 instructions per corner instead of 4.
+template <int HI>
+__device__ __forceinline__ float fma_mix_half(uint32_t packed, float w, float acc) {
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+    else asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+    return acc;
+}
+
 __device__ __forceinline__ void hash_blend(const LevelPrep &p, const half4 (&v)[8], float *f) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
         const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
-        a0 += w * (float)v[corner][0]; a1 += w * (float)v[corner][1];
-        a2 += w * (float)v[corner][2]; a3 += w * (float)v[corner][3];
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 d = __builtin_bit_cast(u32x2, v[corner]);
+        a0 = fma_mix_half<0>(d[0], w, a0); a1 = fma_mix_half<1>(d[0], w, a1);
+        a2 = fma_mix_half<0>(d[1], w, a2); a3 = fma_mix_half<1>(d[1], w, a3);
     }
     f[0] = a0; f[1] = a1; f[2] = a2; f[3] = a3;
 }

@@ -302,6 +302,27 @@ def test_field_forward_matches_oracle(neurons, layers, C, lh):
     assert np.abs(r_sem.numpy()).max() > 0.5                                     # the comparison is not vacuous
 
 
+def test_field_forward_tcnn_init_scale_table():
+    """Hash table at tiny-cuda-nn's initialisation scale U(-1e-4, 1e-4): most entries are fp16 SUBNORMALS (< 6.1e-5).
+    The gather blend must widen them exactly (no flush to zero), as the oracle's fp16 -> fp32 conversion does."""
+    sc = H.make_scene(neurons=64, layers=1, C=13, seed=4, log2_hashmap_size=14)
+    n_mlp = 64 * 64 + 16 * 64
+    tab = sc["params"]["mlp_base"][n_mlp:]
+    tab[:] = np.random.default_rng(0).uniform(-1e-4, 1e-4, tab.shape).astype(np.float32)
+    sc["params"]["mlp_base"][:64 * 64] *= 200.0       # amplify the first layer so the tiny features matter in the outputs
+    hip, orc = H.hip_field(sc), H.oracle_field(sc)
+    rng = np.random.default_rng(1)
+    x = (sc["aabb"][:3] + rng.random((4096, 3)).astype(np.float32) * (sc["aabb"][3:] - sc["aabb"][:3])).astype(np.float32)
+    d = rng.normal(size=(4096, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    with torch.no_grad():
+        rgb, sig, sem = hip(_cu(x), _cu(d))
+        r_rgb, r_sig, r_sem = orc(torch.from_numpy(x), torch.from_numpy(d))
+    assert float(r_sem.abs().max()) > 1e-3        # the features do reach the outputs
+    np.testing.assert_allclose(sig.cpu().numpy(), r_sig.numpy(), rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(sem.cpu().numpy(), r_sem.numpy(), atol=1e-3 * float(r_sem.abs().max()), rtol=2e-3)
+    np.testing.assert_allclose(rgb.cpu().numpy(), r_rgb.numpy(), atol=1e-3)
+
+
 def test_field_forward_samples_matches_positions(scene, fields):
     hip, _ = fields
     o, d = H.view_rays(scene, 3, h=16, w=16)
