@@ -30,6 +30,61 @@ __device__ __forceinline__ void seg_scan64(float (&v)[N], bool head, int lane, i
     }
 }
 
+// The same scan on the VALU's data-parallel-primitive path instead of ds_bpermute (the LDS pipe is shared by the whole
+// CU and 192 permutes per level made the hash-gradient scatter LDS-bound): Hillis-Steele inside each 16-lane row with
+// row_shr:1/2/4/8, then the row totals are carried across the three row boundaries with row_bcast:15.  `heads` is the
+// wave's ballot of segment heads (lanes outside every segment count as heads); HALVES = true scans lanes 0..31 and
+// 32..63 independently (no carry across lane 32).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+
+template <int N, int D>
+__device__ __forceinline__ void seg_step_row(float (&v)[N], unsigned long long &window, int lane) {
+    // lane i may add lane i-D iff no head in (i-D, i]; `window` holds the OR of the head mask over (i-D', i] for the
+    // previous distance D' = D/2 and is widened here
+    if (D > 1) window |= window << (D / 2);
+    const bool add = !((window >> lane) & 1ull);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float t = dpp_f32<0x110 + D, 0xf>(v[k]);      // row_shr:D, lanes without an in-row source read 0
+        v[k] += add ? t : 0.0f;
+    }
+}
+
+template <int N, bool HALVES = false>
+__device__ __forceinline__ void seg_scan_dpp(float (&v)[N], unsigned long long heads, int lane, int maxlen) {
+    unsigned long long window = heads;
+    seg_step_row<N, 1>(v, window, lane);
+    if (maxlen > 2) seg_step_row<N, 2>(v, window, lane);
+    if (maxlen > 4) seg_step_row<N, 4>(v, window, lane);
+    if (maxlen > 8) seg_step_row<N, 8>(v, window, lane);
+    // row totals across the row boundaries, for lanes whose segment began before their row (no head in [row start, lane])
+    const int row = lane >> 4, in_row = lane & 15;
+    const unsigned long long row_heads = (heads >> (row * 16)) & 0xFFFFull;
+    const bool carries = (row_heads & ((2ull << in_row) - 1ull)) == 0ull;
+    const unsigned long long crossing = ~heads & (HALVES ? 0x0001000000010000ull : 0x0001000100010000ull);
+    if (crossing == 0ull) return;                          // wave-uniform: no segment spans a row boundary
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float t = dpp_f32<0x142, 0x2>(v[k]);          // row_bcast:15 into row 1
+        v[k] += (carries && row == 1) ? t : 0.0f;
+    }
+    if (!HALVES) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float t = dpp_f32<0x142, 0x4>(v[k]);      // row 1's (updated) total into row 2
+            v[k] += (carries && row == 2) ? t : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float t = dpp_f32<0x142, 0x8>(v[k]);          // row 2's total into row 3
+        v[k] += (carries && row == 3) ? t : 0.0f;
+    }
+}
+
 // the same over each 32-lane half independently (MFMA layout: column c = lane & 31)
 __device__ __forceinline__ void seg_scan32(f32x16 &v, bool head, int c, int maxlen) {
     bool f = head;
@@ -123,7 +178,7 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
     // ---- weights: w = exp(-excl_sum(sigma*dt)) * (1 - opacity_before) * alpha ----
     const float sdt = sm.valid ? sigma * (sm.te - sm.ts) : 0.0f;
     float sc[1] = {sdt};
-    seg_scan64(sc, head, lane, maxlen);
+    seg_scan_dpp<1>(sc, heads, lane, maxlen);
     const float excl = sc[0] - sdt;
     const float alpha = 1.0f - expf(-sdt);
     const float opac0 = sm.opac0;
@@ -133,7 +188,7 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
     const float tmid = (sm.ts + sm.te) / 2.0f;
     // ---- per-ray sums of the lane=sample quantities ----
     float acc5[7] = {wk, wk * rgb[0], wk * rgb[1], wk * rgb[2], wk * tmid, keep ? 1.0f : 0.0f, sm.valid ? 1.0f : 0.0f};
-    seg_scan64(acc5, head, lane, maxlen);
+    seg_scan_dpp<7>(acc5, heads, lane, maxlen);
     float tot[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) tot[k] = __shfl(acc5[k], tail_lane, 64);
@@ -146,7 +201,7 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
     if (fr.probabilistic) {
         const float e0 = rgb[0] - c_new[0], e1 = rgb[1] - c_new[1], e2 = rgb[2] - c_new[2], ed = tmid - d_new;
         float var4[4] = {wk * (e0 * e0), wk * (e1 * e1), wk * (e2 * e2), wk * (ed * ed)};
-        seg_scan64(var4, head, lane, maxlen);
+        seg_scan_dpp<4>(var4, heads, lane, maxlen);
 #pragma unroll
         for (int k = 0; k < 4; ++k) vt[k] = __shfl(var4[k], tail_lane, 64);
     }
@@ -167,7 +222,14 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
                 if (cont && c == 0) x[k] += cv;
             }
         }
-        seg_scan32(x, hm[ct], c, maxlen);
+        {
+            float xv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xv[k] = x[k];
+            seg_scan_dpp<16, true>(xv, __ballot(hm[ct]), lane, maxlen < 32 ? maxlen : 32);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = xv[k];
+        }
         if (ct == 0) x0 = x;
         if (tm[ct]) {                                        // the run's last column owns the totals
 #pragma unroll

@@ -106,7 +106,6 @@ __global__ void __launch_bounds__(kRayThreads) init_kernel(int64_t n_rays, int32
     ws.near_plane[r] = near_plane;
     out.rgb[3 * r] = 0.f; out.rgb[3 * r + 1] = 0.f; out.rgb[3 * r + 2] = 0.f;
     out.acc[r] = 0.f; out.depth[r] = 0.f;
-    for (int k = 0; k < C; ++k) out.sem[r * C + k] = 0.f;
     if (out.rgb_var) { out.rgb_var[3 * r] = 0.f; out.rgb_var[3 * r + 1] = 0.f; out.rgb_var[3 * r + 2] = 0.f; }
     if (out.depth_var) out.depth_var[r] = 0.f;
 }
@@ -430,6 +429,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     const bool lds_grid = n_words <= kMaxGridWords;
     if (lds_grid)
         hipLaunchKernelGGL(pack_grid_kernel, dim3((int)ceil_div(n_words, 256)), dim3(256), 0, s, binaries, cells, ws.bitgrid, n_words);
+    MNF_HIP(hipMemsetAsync(sem, 0, (size_t)n_rays * C * sizeof(float), s));   // [R,C] accumulators: one streaming fill
     hipLaunchKernelGGL(init_kernel, dim3(ray_blocks), dim3(kRayThreads), 0, s, n_rays, opts->rays_per_view, C, rays_o, rays_d,
                        ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], opts->near_plane, ws, out);
     int rc = launch_status("init_kernel");

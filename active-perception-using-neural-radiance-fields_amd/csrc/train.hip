@@ -16,7 +16,7 @@
 #include <cstring>
 #include <vector>
 
-#include "field_dev.h"
+#include "composite_dev.h"
 
 namespace mnf {
 
@@ -349,16 +349,7 @@ __global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
             unsigned long long cont = ~__ballot(head || !valid);   // lanes that continue the run of the lane below
             while (cont) { cont &= cont << 1; ++maxlen; }
         }
-        bool f = head;
-        for (int d = 1; PRE && d < maxlen; d <<= 1) {
-            const int fu = __shfl_up((int)f, d, 64);
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const float t = __shfl_up(v[k], d, 64);
-                if (lane >= d && !f) v[k] += t;
-            }
-            if (lane >= d) f = f || (fu != 0);
-        }
+        if (PRE) seg_scan_dpp<32>(v, __ballot(head || !valid), lane, maxlen);
         // the last lane of a run holds the run total
         const unsigned long long brk = __ballot(head || !valid);   // lanes that start a run (or are past the end)
         const bool tail = valid && (lane == 63 || ((brk >> (lane + 1)) & 1ull));
