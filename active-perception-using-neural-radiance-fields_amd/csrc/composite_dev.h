@@ -215,11 +215,13 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
         for (int k = 0; k < 16; ++k) x[k] = sem[ct][k] * wm;
         if (ct == 1) {
             // a run that started in columns 0..31 continues into column 32: carry its partial sums across
-            const bool cont = __shfl((int)head, 32, 64) == 0;
+            const bool cont = !((heads >> 32) & 1ull);        // wave-uniform: lane 32 continues the run of lane 31
+            if (cont) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float cv = __shfl(x0[k], 31 + 32 * h, 64);
-                if (cont && c == 0) x[k] += cv;
+                for (int k = 0; k < 16; ++k) {
+                    const float cv = __shfl(x0[k], 31 + 32 * h, 64);
+                    if (c == 0) x[k] += cv;
+                }
             }
         }
         {
