@@ -48,8 +48,15 @@ __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min
 // The extra `!(nt > t_last)` exit only triggers where the reference would spin forever
 // (dt below half an ulp of t_last, or NaN) — it protects the GPU from a hang.
 __device__ __forceinline__ void skip_to(float &t_last, float dt, float target) {
+    const float hd = dt * 0.5f;
+    if (t_last >= 0.0f && target + dt > target) {
+        // dt still moves `target`, so it moves every smaller non-negative t as well: the hang guard cannot fire inside this skip and
+        // the loop is one add, one compare and one exit per step (same t sequence, same exit test)
+        while (!(t_last + hd >= target)) t_last += dt;
+        return;
+    }
     for (;;) {
-        if (t_last + dt * 0.5f >= target) break;
+        if (t_last + hd >= target) break;
         const float nt = t_last + dt;
         if (!(nt > t_last)) break;
         t_last = nt;
