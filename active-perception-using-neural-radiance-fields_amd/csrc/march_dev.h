@@ -125,12 +125,17 @@ __device__ __forceinline__ void march_segment(const F3 org, const F3 dir, const 
     const F3 dtmp = {vox.x * inv.x * stepf.x, vox.y * inv.y * stepf.y, vox.z * inv.z * stepf.z};
     const F3 delta = {dir.x == 0.0f ? this_tmax : dtmp.x, dir.y == 0.0f ? this_tmax : dtmp.y, dir.z == 0.0f ? this_tmax : dtmp.z};
     const I3 overflow = {fin.x + step.x, fin.y + step.y, fin.z + step.z};
+    // linear cell index, updated incrementally (the grids of this path have < 2^31 cells: checked by the host wrappers)
+    const int32_t stride_x = res.y * res.z * step.x, stride_y = res.z * step.y, stride_z = step.z;
+    int32_t cell = (cur.x * res.y + cur.y) * res.z + cur.z;
+    // With dt >= step_size > 0 and t < 2*this_tmax, `t + dt > t` holds whenever step_size still moves 2*this_tmax: the hang
+    // guard of the sampling loop cannot fire and is compiled out of the common path (skip_to() makes its own check).
+    const bool guard_free = step_size > 0.0f && st.t_last >= 0.0f && (this_tmax * 2.0f + step_size > this_tmax * 2.0f);
 
     while (limit <= 0 || st.n_samples < limit) {
         float t_traverse = fminf(tdist.x, fminf(tdist.y, tdist.z));
         t_traverse = fminf(t_traverse, this_tmax);
-        const int64_t cell = (int64_t)cur.x * res.y * res.z + (int64_t)cur.y * res.z + cur.z;
-        if (!occupied(cell)) {
+        if (!occupied((int64_t)cell)) {
             if (step_size <= 0.0f) {
                 st.t_last = t_traverse;
             } else {
@@ -138,6 +143,17 @@ __device__ __forceinline__ void march_segment(const F3 org, const F3 dir, const 
                 skip_to(st.t_last, dt, t_traverse);
             }
             st.continuous = false;
+        } else if (guard_free) {
+            while (limit <= 0 || st.n_samples < limit) {
+                const float dt = calc_dt(st.t_last, cone_angle, step_size, 1e10f);
+                if (st.t_last + dt * 0.5f >= t_traverse) break;
+                const float t_next = st.t_last + dt;
+                sink.sample(st.t_last, t_next, st.continuous, st.n_samples);
+                st.n_samples++;
+                st.continuous = true;
+                st.t_last = t_next;
+                if (t_next >= t_traverse) break;
+            }
         } else {
             while (limit <= 0 || st.n_samples < limit) {
                 float t_next;
@@ -156,17 +172,16 @@ __device__ __forceinline__ void march_segment(const F3 org, const F3 dir, const 
                 if (t_next >= t_traverse) break;
             }
         }
-        // single_traversal, utils_grid.cuh:116-142
-        if (tdist.x < tdist.y && tdist.x < tdist.z) {
-            cur.x += step.x; tdist.x += delta.x;
-            if (cur.x == overflow.x) break;
-        } else if (tdist.y < tdist.z) {
-            cur.y += step.y; tdist.y += delta.y;
-            if (cur.y == overflow.y) break;
-        } else {
-            cur.z += step.z; tdist.z += delta.z;
-            if (cur.z == overflow.z) break;
-        }
+        // single_traversal, utils_grid.cuh:116-142, without divergent branches: exactly one axis advances
+        const bool ax = tdist.x < tdist.y && tdist.x < tdist.z;
+        const bool ay = !ax && tdist.y < tdist.z;
+        const bool az = !ax && !ay;
+        cur.x += ax ? step.x : 0; cur.y += ay ? step.y : 0; cur.z += az ? step.z : 0;
+        cell += ax ? stride_x : (ay ? stride_y : stride_z);
+        tdist.x = ax ? tdist.x + delta.x : tdist.x;
+        tdist.y = ay ? tdist.y + delta.y : tdist.y;
+        tdist.z = az ? tdist.z + delta.z : tdist.z;
+        if ((ax && cur.x == overflow.x) || (ay && cur.y == overflow.y) || (az && cur.z == overflow.z)) break;
     }
 }
 

@@ -139,7 +139,10 @@ struct RoundSink {
     float *col_ts, *col_te;
     int32_t col0;
     __device__ __forceinline__ void sample(float t_last, float t_next, bool, int32_t k) {
-        col_ts[col0 + k] = t_last; col_te[col0 + k] = t_next;
+        // unsigned 32-bit byte offset from the (wave-uniform) array base: a scalar-base store, no 64-bit address math per sample
+        const uint32_t off = (uint32_t)(col0 + k) * 4u;
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(col_ts) + off) = t_last;
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(col_te) + off) = t_next;
     }
 };
 
