@@ -289,6 +289,9 @@ struct HashBwdArgs {
 // of a level (always at the coarse levels, often at the fine ones).  A scattered float atomic is the slow operation
 // here (MI355X: ~17x below the contiguous rate), so each wave first sums the 8 corners x 4 features of runs of lanes
 // that share a cell (segmented inclusive scan over the lanes) and only the last lane of every run issues atomics.
+// (A formulation without scan or LDS -- half-waves walking 128 consecutive samples with the 8 corners x 4 features of the
+// open cell in 32 lanes' registers, flushing on cell change -- was measured at the same 3.8-3.9 ms: the kernel is bound by
+// the rate of memory-side read-modify-writes, ~12 M run flushes x 8 corners per step, not by how the runs are summed.)
 // The coarsest dense levels have a few thousand entries that every ray of a camera crosses near its origin: their
 // atomics pile up on the same addresses (level 0 alone cost as much as the finest level).  Workgroups therefore add
 // into one of kReplicas private copies of those levels, which a small kernel folds into the gradient afterwards.
