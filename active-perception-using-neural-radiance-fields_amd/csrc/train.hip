@@ -8,7 +8,7 @@
 //   wgrad_kernel   dW[n][k] = sum_samples dOut^T[n][c] * In^T[k][c]: the contraction runs over samples, and with
 //                  feature-major fp16 activations both MFMA operands are plain 16-byte loads; split over sample
 //                  chunks, fp32 atomics into the flat parameter-gradient vectors.
-//   hash_bwd_kernel  trilinear scatter of dL/d(features) into the dense fp32 table gradient (float atomics).
+//   hash_bwd_walk_kernel  trilinear scatter of dL/d(features) into the dense fp32 table gradient (float atomics).
 //
 // Gradients of activations travel in fp16 scaled by `loss_scale` (tcnn does the same with its default scale of
 // 128); parameter gradients are accumulated and returned in fp32, un-scaled.
@@ -16,7 +16,7 @@
 #include <cstring>
 #include <vector>
 
-#include "composite_dev.h"
+#include "field_dev.h"
 
 namespace mnf {
 
@@ -285,13 +285,12 @@ struct HashBwdArgs {
     LevelMeta levels[16];
 };
 
-// Samples arrive sorted by ray and by distance along the ray, so neighbouring lanes usually sit in the same grid cell
+// Samples arrive sorted by ray and by distance along the ray, so consecutive samples usually sit in the same grid cell
 // of a level (always at the coarse levels, often at the fine ones).  A scattered float atomic is the slow operation
-// here (MI355X: ~17x below the contiguous rate), so each wave first sums the 8 corners x 4 features of runs of lanes
-// that share a cell (segmented inclusive scan over the lanes) and only the last lane of every run issues atomics.
-// (A formulation without scan or LDS -- half-waves walking 128 consecutive samples with the 8 corners x 4 features of the
-// open cell in 32 lanes' registers, flushing on cell change -- was measured at the same 3.8-3.9 ms: the kernel is bound by
-// the rate of memory-side read-modify-writes, ~12 M run flushes x 8 corners per step, not by how the runs are summed.)
+// here (MI355X: ~17x below the contiguous rate) and the kernel is bound by the rate of memory-side read-modify-writes,
+// so everything below is about issuing fewer of them.  (History: one atomic per lane and corner 94 ms; runs of lanes in
+// one cell summed by a segmented lane scan, tails only 21 ms; LDS transpose to 16-byte quad atomics 3.7 ms; the walk
+// below with face sharing 3.4 ms.)
 // The coarsest dense levels have a few thousand entries that every ray of a camera crosses near its origin: their
 // atomics pile up on the same addresses (level 0 alone cost as much as the finest level).  Workgroups therefore add
 // into one of kReplicas private copies of those levels, which a small kernel folds into the gradient afterwards.
@@ -307,87 +306,120 @@ __global__ void __launch_bounds__(256) fold_replicas_kernel(const float *__restr
     if (acc != 0.f) g_table[i] += acc;
 }
 
-template <bool PRE>
-__global__ void __launch_bounds__(256) hash_bwd_kernel(const HashBwdArgs args) {
-    __shared__ float s_val[4][64 * 32];
-    __shared__ uint32_t s_off[4][64 * 8];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool valid = i < args.n;
-    float xn[3] = {0.5f, 0.5f, 0.5f};
-    if (valid) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) xn[d] = (args.positions[3 * i + d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);
-    }
-    // One level per blockIdx.y, and the level is the slow grid dimension: at any time the chip scatters into one or two
-    // levels' slice of the gradient table (<= 8 MB) instead of all 200 MB, so the memory-side atomics stay cache hits.
-    {
-        const int l = blockIdx.y + args.level0;
-        const LevelMeta m = args.levels[l];
-        float *const g_dst = l < args.repl_levels ? args.repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.g_table;
-        LevelPrep p;
-        hash_prep(m, xn, p);
-        float4 g = {0.f, 0.f, 0.f, 0.f};
-        if (valid) g = reinterpret_cast<const float4 *>(args.dX)[(int64_t)l * args.Np + i];
-        // cell identity: the three integer cell coordinates (recomputed exactly as hash_prep does)
-        int cell[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) cell[d] = (int)floorf(__builtin_fmaf(m.scale, xn[d], 0.5f));
-        bool head = true;
-        if (PRE) {
-            const int px = __shfl_up(cell[0], 1, 64), py = __shfl_up(cell[1], 1, 64), pz = __shfl_up(cell[2], 1, 64);
-            const int pv = __shfl_up((int)valid, 1, 64);
-            if (lane > 0 && pv && valid && px == cell[0] && py == cell[1] && pz == cell[2]) head = false;
+// The scatter as a WALK along the sample order.  A half-wave owns a chunk of kWalkChunk consecutive samples of one level;
+// its 32 lanes are the 8 corners x 4 features of a grid cell.  Samples are visited in order, every lane accumulating
+// w_corner * g_feature for the open cell in a register; when the cell changes the sums go out as quad-atomics (the four
+// features of a corner are 16 contiguous bytes).  What the lane-scan form cannot do: when the ray steps into a FACE
+// neighbour, the four corners on the shared face stay in registers (they move to the partner lanes, lane ^ 4 / 8 / 16)
+// and only the four corners left behind are flushed; edge and vertex neighbours are reached by two or three such
+// crossings (6 or 7 flushed corners instead of 8).  The kernel is bound by the rate of memory-side read-modify-writes.  Ray structure is not needed: runs are found by comparing
+// consecutive cells, and a chunk boundary only costs one extra flush.
+constexpr int kWalkChunk = 128;
+
+__global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs args) {
+    const int sub = threadIdx.x & 31;                 // lane inside the half-wave
+    const int corner = sub >> 2, feat = sub & 3;
+    const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int64_t i0 = chunk * kWalkChunk;
+    if (i0 >= args.n) return;
+    const int64_t i1 = i0 + kWalkChunk < args.n ? i0 + kWalkChunk : args.n;
+    const int l = blockIdx.y + args.level0;
+    const LevelMeta m = args.levels[l];
+    float *const g_dst = l < args.repl_levels ? args.repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.g_table;
+    const float *gl = args.dX + ((int64_t)l * args.Np) * 4 + feat;
+    const float ext[3] = {args.aabb[3] - args.aabb[0], args.aabb[4] - args.aabb[1], args.aabb[5] - args.aabb[2]};
+    const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+
+    float acc = 0.0f;
+    bool open = false;
+    int cx = 0, cy = 0, cz = 0;                       // cell of the open run
+    auto flush = [&]() {                              // this lane's corner of the open cell
+        if (acc != 0.0f) {
+            const uint32_t px = (uint32_t)cx + bx, py = (uint32_t)cy + by, pz = (uint32_t)cz + bz;
+            uint32_t idx;
+            if (m.hashed) {
+                idx = (px ^ (py * 2654435761u) ^ (pz * 805459861u)) & (m.size - 1u);
+            } else {
+                idx = px + py * m.res + pz * m.res * m.res;
+                uint32_t q = __umulhi(m.div_magic, idx);
+                q = (((idx - q) >> 1) + q) >> m.div_shift;
+                idx -= q * m.size;
+            }
+            atomicAdd(g_dst + ((size_t)(m.offset + idx) << 2) + feat, acc);
         }
-        float v[32];
+        acc = 0.0f;
+    };
+    constexpr int B = 8;                              // samples fetched ahead of the sequential part
+    for (int64_t i = i0; i < i1; i += B) {
+        float sx[B], sy[B], sz[B], g[B];
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
-            v[4 * corner + 0] = w * g.x; v[4 * corner + 1] = w * g.y; v[4 * corner + 2] = w * g.z; v[4 * corner + 3] = w * g.w;
+        for (int b = 0; b < B; ++b) {
+            const int64_t k = i + b < i1 ? i + b : i1 - 1;
+            sx[b] = args.positions[3 * k]; sy[b] = args.positions[3 * k + 1]; sz[b] = args.positions[3 * k + 2];
+            g[b] = gl[k * 4];
         }
-        // segmented inclusive scan (Hillis-Steele) over the wave, only as many doubling steps as the longest run of this
-        // level needs (fine levels: runs of one or two samples; coarse levels: the whole wave in one cell)
-        int maxlen = 1;
-        if (PRE) {
-            unsigned long long cont = ~__ballot(head || !valid);   // lanes that continue the run of the lane below
-            while (cont) { cont &= cont << 1; ++maxlen; }
-        }
-        if (PRE) seg_scan_dpp<32>(v, __ballot(head || !valid), lane, maxlen);
-        // the last lane of a run holds the run total
-        const unsigned long long brk = __ballot(head || !valid);   // lanes that start a run (or are past the end)
-        const bool tail = valid && (lane == 63 || ((brk >> (lane + 1)) & 1ull));
-        if (!PRE) {
-            if (tail) {
 #pragma unroll
-                for (int corner = 0; corner < 8; ++corner) {
-                    float *dst = g_dst + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (v[4 * corner + k] != 0.f) atomicAdd(dst + k, v[4 * corner + k]);
+        for (int b = 0; b < B; ++b) {
+            if (i + b >= i1) break;
+            // position -> cell and fractions, exactly as hash_prep
+            const float x0 = __builtin_fmaf(m.scale, (sx[b] - args.aabb[0]) / ext[0], 0.5f);
+            const float x1 = __builtin_fmaf(m.scale, (sy[b] - args.aabb[1]) / ext[1], 0.5f);
+            const float x2 = __builtin_fmaf(m.scale, (sz[b] - args.aabb[2]) / ext[2], 0.5f);
+            const float f0 = floorf(x0), f1 = floorf(x1), f2 = floorf(x2);
+            const int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
+            const int dx = c0 - cx, dy = c1 - cy, dz = c2 - cz;
+            if (!open) {
+                open = true;
+                cx = c0; cy = c1; cz = c2;
+            } else if ((dx | dy | dz) != 0) {         // half-wave uniform
+                const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
+                if ((ax | ay | az) > 1) {
+                    flush();                           // a jump (new ray, or a step longer than a cell)
+                    cx = c0; cy = c1; cz = c2;
+                } else {
+                    // one face crossing per changed axis, through the intermediate cells: the corners on the far side of
+                    // the cell being left are the near side of the next one and stay in registers (partner lane)
+                    auto face_move = [&](int bit, int dir, int mask) {
+                        const bool stays_behind = dir > 0 ? bit == 0 : bit == 1;
+                        if (stays_behind) flush();
+                        const float moved = __shfl_xor(acc, mask, 64);
+                        acc = stays_behind ? moved : 0.0f;
+                    };
+                    if (dx) { face_move(bx, dx, 4); cx = c0; }
+                    if (dy) { face_move(by, dy, 8); cy = c1; }
+                    if (dz) { face_move(bz, dz, 16); cz = c2; }
                 }
             }
-            return;
+            const float fx = x0 - f0, fy = x1 - f1, fz = x2 - f2;
+            const float wx = bx ? fx : 1.0f - fx, wy = by ? fy : 1.0f - fy, wz = bz ? fz : 1.0f - fz;
+            acc += (((1.0f * wx) * wy) * wz) * g[b];
         }
-        // Transpose through LDS so that one atomic wave-instruction covers 16 (sample, corner) pairs x 4 consecutive
-        // floats: the four floats of a table entry share one 64-byte memory-side atomic request, so a wave issues 16
-        // requests per instruction instead of 64 scattered dwords.
-        float *w_val = s_val[threadIdx.x >> 6];
-        uint32_t *w_off = s_off[threadIdx.x >> 6];
+    }
+    flush();
+}
+
+// Reference form of the scatter (MNF_HASH_BWD_SIMPLE=1, debugging and A/B timing): one lane per sample, one atomic per
+// corner and feature, no run merging.
+__global__ void __launch_bounds__(256) hash_bwd_simple_kernel(const HashBwdArgs args) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= args.n) return;
+    float xn[3];
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            float4 q = {v[4 * corner], v[4 * corner + 1], v[4 * corner + 2], v[4 * corner + 3]};
-            reinterpret_cast<float4 *>(w_val)[lane * 8 + corner] = q;
-            w_off[lane * 8 + corner] = tail ? p.off[corner] : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int sidx = 0; sidx < 32; ++sidx) {
-            const int pi = 16 * sidx + (lane >> 2);          // (sample, corner) pair handled by this lane quad
-            const uint32_t off = w_off[pi];
-            if (__ballot(off != 0xFFFFFFFFu) == 0ull) continue;   // none of these 16 pairs closes a run (common at coarse levels)
-            const float val = w_val[pi * 4 + (lane & 3)];
-            if (off != 0xFFFFFFFFu && val != 0.f) atomicAdd(g_dst + (off >> 1) + (lane & 3), val);
-        }
+    for (int d = 0; d < 3; ++d) xn[d] = (args.positions[3 * i + d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);
+    const int l = blockIdx.y + args.level0;
+    const LevelMeta m = args.levels[l];
+    float *const g_dst = l < args.repl_levels ? args.repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.g_table;
+    LevelPrep p;
+    hash_prep(m, xn, p);
+    const float4 g = reinterpret_cast<const float4 *>(args.dX)[(int64_t)l * args.Np + i];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
+        float *dst = g_dst + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
+        const float v[4] = {w * g.x, w * g.y, w * g.z, w * g.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (v[k] != 0.f) atomicAdd(dst + k, v[k]);
     }
 }
 
@@ -705,10 +737,10 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     const size_t repl_bytes = (size_t)kReplicas * hb.repl_floats * sizeof(float);
     if ((size_t)ts->tt.rows * v.Np * 2 < repl_bytes) { hb.repl_levels = 0; hb.repl_floats = 0; }
     if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.repl, 0, repl_bytes, s));
-    static const bool simple = getenv("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane and corner
-    if (simple) hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, s, hb);
-    else hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, s, hb);
-    rc = launch_status("hash_bwd_kernel");
+    static const bool simple = getenv("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane, corner and feature
+    if (simple) hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, s, hb);
+    else hipLaunchKernelGGL(hash_bwd_walk_kernel, dim3((unsigned)ceil_div(ceil_div(n, kWalkChunk) * 32, 256), n_levels), dim3(256), 0, s, hb);
+    rc = launch_status("hash_bwd_walk_kernel");
     if (rc) return rc;
     if (hb.repl_levels)
         hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, s, hb.repl, hb.repl_floats, hb.g_table);
