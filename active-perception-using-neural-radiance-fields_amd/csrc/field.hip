@@ -1,14 +1,14 @@
 // Fused radiance-field forward for gfx950: multiresolution hash-grid gather -> base MLP ->
-// {trunc_exp density, SH + rgb head, semantic head}, one wave per 64 samples.
+// {trunc_exp density, SH + rgb head, semantic head} (-> per-ray compositing in renderer mode), one wave per 64 samples.
 //
 // Replaces the tiny-cuda-nn modules the reference builds at
 // perception/models/radiance_fields/ngp.py:108-169 and the Python glue of ngp.py:171-238.
 //
 // Data flow per wave (64 lanes, 64 samples = two 32-column tiles "ct"):
-//   * lane (c = lane&31, h = lane>>5) gathers 8 of the 16 hash levels for samples c and c+32:
-//     exactly the fp16 B-operand fragments of v_mfma_f32_32x32x16_f16 for the first layer
-//     (feature k = 16*ks + 8*h + j lives in element j of k-step ks), so encoded features never
-//     touch LDS or HBM;
+//   * lane = sample for the gather: each lane encodes all 16 hash levels of its own sample (level metadata is
+//     wave-uniform and read with scalar loads); one v_permlane32_swap per dword between lanes l and l+32 then turns
+//     "lane = sample" into the fp16 B-operand fragments of v_mfma_f32_32x32x16_f16 for the first layer (feature
+//     k = 16*ks + 8*h + j lives in element j of k-step ks of lane (c, h)), so encoded features never touch LDS or HBM;
 //   * every layer computes H_out^T[n][c] = sum_k W[n][k] * H_in^T[k][c]: the weights are the A
 //     operand (read from LDS, pre-permuted on the host side of the handle into fragment order,
 //     one conflict-free ds_read_b128 per lane), the activations are the B operand.  The 32x32
