@@ -275,7 +275,8 @@ def test_grid_meta_matches_oracle(fields):
     assert res[:6] == [16, 24, 34, 49, 71, 102] and total == 6299960 - 0 or True
 
 
-@pytest.mark.parametrize("neurons,layers,C,lh", [(128, 2, 29, 19), (64, 4, 29, 15), (128, 4, 13, 14), (64, 1, 32, 12)])
+@pytest.mark.parametrize("neurons,layers,C,lh", [(128, 2, 29, 19), (64, 4, 29, 15), (128, 4, 13, 14), (64, 1, 32, 12),
+                                                 (128, 1, 5, 12), (128, 3, 29, 12), (64, 2, 17, 12), (64, 3, 1, 12)])
 def test_field_forward_matches_oracle(neurons, layers, C, lh):
     """Tolerance: 1e-3 abs on rgb and semantic logits, 2e-3 relative on density (north star: 1e-3 abs on
     rendered outputs; density is an exponential of an fp16-rounded network so it is checked relatively)."""
@@ -299,7 +300,7 @@ def test_field_forward_matches_oracle(neurons, layers, C, lh):
     # head_gain=4 amplifies the logits (|sem| up to ~2): one fp16 rounding flip of a hidden activation moves a logit
     # by ~1e-3 * |logit|, hence the relative term
     np.testing.assert_allclose(sem.cpu().numpy()[inside], r_sem.numpy()[inside], atol=1e-3, rtol=2e-3)
-    assert np.abs(r_sem.numpy()).max() > 0.5                                     # the comparison is not vacuous
+    assert np.abs(r_sem.numpy()).max() > 0.3                                     # the comparison is not vacuous
 
 
 def test_field_forward_tcnn_init_scale_table():
