@@ -424,6 +424,14 @@ def test_render_batched_views_equal_single_calls(scene, fields):
             np.testing.assert_allclose(batched[key][k * 256:(k + 1) * 256].cpu().numpy(), single[key].cpu().numpy(),
                                        rtol=2e-6, atol=1e-7, err_msg=key)
         assert int(batched["total"][0]) > 0
+    # ragged sizes: 3 views of 150 rays (neither a multiple of 64 nor of the 1024-ray march workgroup) == single calls
+    o3, d3 = o[:450].contiguous(), d[:450].contiguous()
+    ragged = RD.render_views(hip, est, o3, d3, 150, 1024, render_bkgd=bk, **H.RENDER_KW)
+    for k in range(3):
+        single = RD.render_views(hip, est, o3[k * 150:(k + 1) * 150], d3[k * 150:(k + 1) * 150], 150, 1024, render_bkgd=bk, **H.RENDER_KW)
+        for key in ("rgb", "acc", "depth", "sem"):
+            np.testing.assert_allclose(ragged[key][k * 150:(k + 1) * 150].cpu().numpy(), single[key].cpu().numpy(),
+                                       rtol=2e-6, atol=1e-7, err_msg=key)
     # rays that miss the grid entirely: zero opacity, background colour, no samples
     far_o = torch.full((64, 3), 100.0, device=DEV)
     far_d = torch.tensor([[0.0, 1.0, 0.0]], device=DEV).repeat(64, 1)
