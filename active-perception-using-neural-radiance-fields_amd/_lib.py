@@ -53,6 +53,8 @@ SIGNATURES = {
     "mnf_composite_train_backward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int32, c_void_p]),
+    "mnf_count_nan": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_generate_rays": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mnf_field_create": (c_int32, [POINTER(FieldConfig), POINTER(c_void_p)]),
     "mnf_field_destroy": (c_int32, [c_void_p]),

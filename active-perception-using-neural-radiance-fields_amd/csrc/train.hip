@@ -12,6 +12,7 @@
 //
 // Gradients of activations travel in fp16 scaled by `loss_scale` (tcnn does the same with its default scale of
 // 128); parameter gradients are accumulated and returned in fp32, un-scaled.
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -590,6 +591,28 @@ static int ensure_train_state(mnf_field_t f) {
     return MNF_OK;
 }
 
+// ------------------------------------------------------------------ optimizer step (pipeline.py:173-178, :531)
+// torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) on one flat parameter vector in a single pass
+// (torch's foreach implementation is six passes over the 25 M table entries): lerp of the first moment, addcmul of the
+// second, bias-corrected step.  `any_nan` counts NaN gradients (the reference skips the whole iteration then).
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, float beta1, float beta2, float eps,
+                                                   float step_size, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
+__global__ void __launch_bounds__(256) count_nan_kernel(const float *__restrict__ g, int64_t n, int32_t *__restrict__ count) {
+    int local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) local += g[i] != g[i];
+    if (__ballot(local != 0) != 0ull && local) atomicAdd(count, local);
+}
+
 void free_train_state(mnf_field_t f) {
     TrainState *ts = reinterpret_cast<TrainState *>(f->train_state);
     if (!ts) return;
@@ -745,4 +768,24 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     if (hb.repl_levels)
         hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, s, hb.repl, hb.repl_floats, hb.g_table);
     return launch_status("fold_replicas_kernel");
+}
+
+extern "C" int mnf_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int32_t step, mnf_stream_t stream) {
+    if (n == 0) return MNF_OK;
+    MNF_REQUIRE(params && grads && exp_avg && exp_avg_sq && step >= 1, "adam_step: bad arguments");
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const int64_t blocks = ceil_div(n, 256 * 4);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks < 8192 ? (blocks < 1 ? 1 : blocks) : 8192)), dim3(256), 0, as_stream(stream), params,
+                       grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps, (float)((double)lr / bc1), (float)std::sqrt(bc2));
+    return launch_status("adam_kernel");
+}
+
+extern "C" int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf_stream_t stream) {
+    if (n == 0) return MNF_OK;
+    MNF_REQUIRE(values && count, "count_nan: null pointer");
+    const int64_t blocks = ceil_div(n, 256 * 8);
+    hipLaunchKernelGGL(count_nan_kernel, dim3((unsigned)(blocks < 4096 ? (blocks < 1 ? 1 : blocks) : 4096)), dim3(256), 0, as_stream(stream),
+                       values, n, count);
+    return launch_status("count_nan_kernel");
 }

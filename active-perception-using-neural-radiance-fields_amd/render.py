@@ -268,10 +268,8 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     loss.backward()
     if data_parallel:
         allreduce_gradients(radiance_field.parameters(), data_parallel_group)
-    bad = torch.zeros((), device=rgb.device)
-    for p_ in radiance_field.parameters():
-        if p_.grad is not None:
-            bad = bad + torch.isnan(p_.grad).sum()
+    from .optim import count_nan_gradients
+    bad = count_nan_gradients(radiance_field.parameters())
     skipped = bool(bad.item() > 0)          # one host sync (the reference syncs once per parameter)
     if skipped:
         optimizer.zero_grad()

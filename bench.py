@@ -121,7 +121,8 @@ def main():
         # BASELINE config 5 shape: scene 102344280, 8192-ray train batches; targets are synthetic (no Habitat data offline)
         scene = H.make_scene("102344280", n_poses=8)
         field, est = H.hip_field(scene, dev), H.hip_estimator(scene, dev)
-        opt = torch.optim.Adam(field.parameters(), lr=1e-3, eps=1e-15)
+        from apnrf_amd.optim import FusedAdam
+        opt = FusedAdam(field.parameters(), lr=1e-3, eps=1e-15)     # torch.optim.Adam's update as one kernel per parameter
         R_ = args.train_rays
         c2w = np.stack([RD.pose_to_c2w(p) for p in scene["poses"]]).astype(np.float32)
         K = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
@@ -140,7 +141,7 @@ def main():
             state["samples"] += out["n_rendering_samples"]
             return None
         units_per_step = R_
-        workload = f"train step, scene 102344280 (synthetic stand-in), {R_} rays/step, hash-grid + MLP 128x2, loss+backward+Adam (torch)"
+        workload = f"train step, scene 102344280 (synthetic stand-in), {R_} rays/step, hash-grid + MLP 128x2, loss (torch) + backward + fused Adam"
     else:
         scene = H.make_scene("102344250", n_poses=256)
         sc2 = dict(scene); sc2["params"] = H.S.make_field_params(seed=1)

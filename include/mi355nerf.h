@@ -120,6 +120,14 @@ int mnf_composite_train_backward(const int64_t *chunk_starts, const int64_t *chu
                                  const float *out_depth, const float *g_rgb, const float *g_acc, const float *g_depth,
                                  const float *g_sem, float *d_sigmas, float *d_rgbs, float *d_sems, mnf_stream_t stream);
 
+/* One `torch.optim.Adam` step (weight_decay 0, amsgrad off: scripts/pipeline.py:173-178, :531) on a flat fp32
+ * parameter vector in a single pass; `step` counts from 1.  State buffers are the optimizer's exp_avg / exp_avg_sq. */
+int mnf_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int32_t step, mnf_stream_t stream);
+
+/* Adds the number of NaN entries of `values` to *count (device int32): the gradient guard of pipeline.py:520-529. */
+int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf_stream_t stream);
+
 /* ---------------------------------------------------------------- ray generation */
 
 /* Dataset.generate_image_rays (perception/data_proc/habitat_to_data.py:274-301) for n_views poses,

@@ -594,6 +594,36 @@ def test_train_step_matches_oracle(scene):
 
 
 # ------------------------------------------------------------------ §8(f) rows: dataset ingest, checkpoints, planner map
+def test_fused_adam_matches_torch_adam():
+    """optim.FusedAdam (one HIP kernel per parameter) against torch.optim.Adam with the reference's hyper-parameters
+    (pipeline.py:173-178: lr 1e-3, eps 1e-15) over several steps, state_dict interchange, and the NaN-gradient counter."""
+    from apnrf_amd.optim import FusedAdam, count_nan_gradients
+    g = torch.Generator().manual_seed(3)
+    shapes = (100003, 4096, 37)
+    init = [torch.randn(n, generator=g) * 0.1 for n in shapes]
+    ref_p = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    hip_p = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    ref, hip = torch.optim.Adam(ref_p, lr=1e-3, eps=1e-15), FusedAdam(hip_p, lr=1e-3, eps=1e-15)
+    for step in range(6):
+        if step == 3:                       # a checkpoint written by torch's optimizer loads into the fused one
+            import copy
+            hip.load_state_dict(copy.deepcopy(ref.state_dict()))     # (a live state_dict aliases the tensors)
+        for a, b in zip(ref_p, hip_p):
+            grad = (torch.randn(a.shape, generator=g) * (10.0 ** (step - 3))).to(DEV)
+            grad[::7] = 0.0                 # untouched hash-table entries have exactly zero gradient
+            a.grad, b.grad = grad.clone(), grad.clone()
+        v0 = hip_p[0]._version
+        ref.step(); hip.step()
+        assert hip_p[0]._version > v0       # the field handle notices the in-place update
+        for a, b in zip(ref_p, hip_p):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=5e-8)
+    sd = hip.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 6
+    assert int(count_nan_gradients(hip_p).item()) == 0
+    hip_p[1].grad[5] = float("nan"); hip_p[2].grad[:3] = float("nan")
+    assert int(count_nan_gradients(hip_p).item()) == 4
+
+
 def test_dataset_matches_reference(golden, tmp_path):
     from apnrf_amd.dataset import Dataset
     g = golden("dataset")
