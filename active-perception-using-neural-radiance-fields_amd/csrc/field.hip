@@ -232,26 +232,32 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) bfeat[ct][ks] = src[(ks * 2 + ct) * 64];
         } else {
+            // double-buffered: the loads of batch kb+1 are issued before batch kb is blended
+            LevelPrep prep[2][4];
+            half4 v[2][4][8];
 #pragma unroll
-            for (int kb = 0; kb < 4 / KSB; ++kb) {
-                LevelPrep prep[4 * KSB];
-                half4 v[4 * KSB][8];
+            for (int q = 0; q < 4; ++q) {
+                hash_prep(lv[q], xn, prep[0][q], in_box);
+                hash_load(args.table, prep[0][q], v[0][q]);
+            }
 #pragma unroll
-                for (int q = 0; q < 4 * KSB; ++q) {
-                    hash_prep(lv[4 * KSB * kb + q], xn, prep[q], in_box);
-                    hash_load(args.table, prep[q], v[q]);
+            for (int kb = 0; kb < 4; ++kb) {
+                const int cur = kb & 1, nxt = cur ^ 1;
+                if (kb < 3) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        hash_prep(lv[4 * (kb + 1) + q], xn, prep[nxt][q], in_box);
+                        hash_load(args.table, prep[nxt][q], v[nxt][q]);
+                    }
                 }
+                float f[16];
 #pragma unroll
-                for (int k2 = 0; k2 < KSB; ++k2) {
-                    float f[16];
+                for (int q = 0; q < 4; ++q) hash_blend(prep[cur][q], v[cur][q], f + 4 * q);
+                half8 lo, hi;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) hash_blend(prep[4 * k2 + q], v[4 * k2 + q], f + 4 * q);
-                    half8 lo, hi;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
-                    exchange_halves(lo, hi);
-                    bfeat[0][KSB * kb + k2] = lo; bfeat[1][KSB * kb + k2] = hi;
-                }
+                for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
+                exchange_halves(lo, hi);
+                bfeat[0][kb] = lo; bfeat[1][kb] = hi;
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
