@@ -27,10 +27,6 @@
 #include <cmath>
 #include <cstring>
 
-#ifndef MNF_KSB
-#define MNF_KSB 1
-#endif
-
 namespace mnf {
 
 // ------------------------------------------------------------------ sample fetch (shared by the kernels below)
@@ -185,7 +181,6 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     using L = Layout<W, NH>;
     using T = TrainLayout<W, NH>;
     constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
-    constexpr int KSB = MNF_KSB;   // k-steps (4 levels each) gathered per batch
     __shared__ half8 s_w[kBlocks * 64];
 
     const int lane = threadIdx.x & 63;
