@@ -174,11 +174,14 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
                                                                     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                                     const uint8_t *__restrict__ binaries, I3 res, int n_words,
                                                                     float a0, float a1, float a2, float a3, float a4, float a5,
-                                                                    float far_plane, float step_size, float cone_angle, RenderWs ws) {
+                                                                    float far_plane, float step_size, float cone_angle, RenderWs ws,
+                                                                    const int32_t *__restrict__ view_order) {
     __shared__ int s_wave_tot[kMarchThreads / 64], s_wave_max[kMarchThreads / 64];
     __shared__ int s_base, s_stride, s_total;
     __shared__ uint32_t s_bits[LDS_GRID ? kMaxGridWords : 1];
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // thread -> ray: identity, or the caller's order inside every view (neighbouring rays into the same tile)
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (view_order && r < n_rays) { const int64_t v0 = r / rays_per_view; r = v0 * rays_per_view + view_order[r - v0 * rays_per_view]; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool go = false;
     int ns = 0;
@@ -462,11 +465,11 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
         if (lds_grid)
             hipLaunchKernelGGL(round_march_kernel<true>, dim3((int)ceil_div(n_rays, kMarchThreads)), dim3(kMarchThreads), 0, s, n_rays,
                                opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
-                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws);
+                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order);
         else
             hipLaunchKernelGGL(round_march_kernel<false>, dim3((int)ceil_div(n_rays, kMarchThreads)), dim3(kMarchThreads), 0, s, n_rays,
                                opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
-                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws);
+                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order);
         profile_mark(s, true);
         rc = launch_field(f, io, false, s);   // field evaluation + compositing + ray retirement of this round
         profile_mark(s, false);

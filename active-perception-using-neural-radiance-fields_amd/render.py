@@ -52,9 +52,29 @@ def _single_level(estimator):
     return b, host[1]
 
 
+_VIEW_ORDERS = {}
+
+
+def _view_order(h: int, w: int, device, block: int = 8) -> torch.Tensor:
+    """Device int32 permutation of the h*w row-major pixels of a view into block x block tiles (tiles row-major, pixels
+    row-major inside a tile): the order in which the renderer marches a view's rays (`mnf_render_opts.view_order`).
+    A 64-sample tile of the field kernel then covers a compact pixel patch instead of a one-pixel-high strip and touches
+    fewer hash-table lines (-5 % render time at 800x800); results are per ray and do not depend on it."""
+    key = (h, w, block, str(device))
+    t = _VIEW_ORDERS.get(key)
+    if t is None:
+        ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        k = ((ys // block) * ((w + block - 1) // block) + xs // block) * (block * block) + (ys % block) * block + xs % block
+        t = torch.from_numpy(np.argsort(k.reshape(-1), kind="stable").astype(np.int32)).to(device)
+        _VIEW_ORDERS[key] = t
+    return t
+
+
 def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane, render_step_size, render_bkgd,
-                 cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view=None, sync_every=8):
+                 cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view=None, sync_every=8, image_hw=None):
     rays_shape = rays.origins.shape
+    if image_hw is None and rays_per_view is None and len(rays_shape) == 3:
+        image_hw = (int(rays_shape[0]), int(rays_shape[1]))      # [H,W,3] rays (utils.py:574-580): one image
     o = L.contig(rays.origins.reshape(-1, 3), torch.float32)
     d = L.contig(rays.viewdirs.reshape(-1, 3), torch.float32)
     L.require_gpu(o, d)
@@ -72,6 +92,10 @@ def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_p
     for i in range(3):
         opts.render_bkgd[i] = bk[i]
     opts.max_samples, opts.probabilistic, opts.rays_per_view, opts.sync_every = int(max_samples), int(probabilistic), rpv, sync_every
+    order = None
+    if image_hw is not None and image_hw[0] * image_hw[1] == rpv and min(image_hw) >= 16:
+        order = _view_order(image_hw[0], image_hw[1], dev)
+    opts.view_order = L.ptr(order)
     rgb = torch.empty(n, 3, device=dev); acc = torch.empty(n, 1, device=dev); depth = torch.empty(n, 1, device=dev)
     sem = torch.empty(n, C, device=dev)
     rgb_var = torch.empty(n, 3, device=dev) if probabilistic else None
@@ -125,11 +149,13 @@ def render_probablistic_image_with_occgrid_test(max_samples: int, radiance_field
 @torch.no_grad()
 def render_views(radiance_field, estimator, rays_o, rays_d, rays_per_view, max_samples=1024, near_plane=0.0,
                  far_plane=1e10, render_step_size=1e-3, render_bkgd=None, cone_angle=0.0, alpha_thre=0.0,
-                 early_stop_eps=1e-4, probabilistic=False, sync_every=8):
+                 early_stop_eps=1e-4, probabilistic=False, sync_every=8, image_hw=None):
     """Batched form: rays_o/rays_d [V*rays_per_view, 3]; every group of rays_per_view rays is rendered exactly as one
-    call of the reference function (own round schedule), all views in the same launches.  Returns a dict of device tensors."""
+    call of the reference function (own round schedule), all views in the same launches.  `image_hw=(H, W)` says that the
+    rays of a view are the row-major pixels of an H x W image (a speed hint only: see `_view_order`).
+    Returns a dict of device tensors."""
     return _render_test(max_samples, radiance_field, estimator, Rays(rays_o, rays_d), near_plane, far_plane, render_step_size,
-                        render_bkgd, cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view, sync_every)
+                        render_bkgd, cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view, sync_every, image_hw)
 
 
 # ------------------------------------------------------------------ train-mode forward (utils.py:63-219, :362-461)
@@ -340,7 +366,7 @@ def render_image_from_pose(radiance_field, estimator, poses, width, height, foca
     poses = np.asarray(poses)
     o, d, h, w = _pose_rays(poses, width, height, focal, scale, device)
     r = render_views(radiance_field, estimator, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
-                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre)
+                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, image_hw=(h, w))
     P, C = poses.shape[0], radiance_field.num_semantic_classes
     f64 = lambda t, *s: t.reshape(P, h, w, *s).double().cpu().numpy()
     return f64(r["rgb"], 3), f64(r["depth"]), f64(r["acc"]), f64(r["sem"], C)
@@ -354,7 +380,7 @@ def render_probablistic_image_from_pose(radiance_field, estimator, poses, width,
     poses = np.asarray(poses)
     o, d, h, w = _pose_rays(poses, width, height, focal, scale, device)
     r = render_views(radiance_field, estimator, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
-                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, probabilistic=True)
+                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, probabilistic=True, image_hw=(h, w))
     P, C = poses.shape[0], radiance_field.num_semantic_classes
     f64 = lambda t, *s: t.reshape(P, h, w, *s).double().cpu().numpy()
     return f64(r["rgb"], 3), f64(r["rgb_var"], 3), f64(r["depth"]), f64(r["depth_var"]), f64(r["acc"]), f64(r["sem"], C)

@@ -113,7 +113,7 @@ def main():
 
         def step(i):
             o, d = view_batches[i % len(view_batches)]
-            return RD.render_views(field, est, o, d, n_per_view, 1024, render_bkgd=bk, **H.RENDER_KW)
+            return RD.render_views(field, est, o, d, n_per_view, 1024, render_bkgd=bk, image_hw=(height, width), **H.RENDER_KW)
         units_per_step = n_per_view * V
         workload = (f"scene 102344529 (synthetic stand-in), 800x800 RGB+depth+29-class semantic render, {V} view(s) per step in one "
                     "batched call, hash-grid 16x4 T=2^19 + MLP 128x2 + 64x2 heads")
@@ -210,6 +210,7 @@ def main():
             # evaluated samples of the timed steps and of the warm-up (PMC sums cover both): tools/reduce_pmc.py
             line["samples"] = {"timed": int(samples), "warmup": int(warm.item())}
             line["config"]["views_per_step"] = args.views
+            line["config"]["march_order"] = "8x8 pixel blocks inside every view (mnf_render_opts.view_order); per-ray results do not depend on it"
             line["config"]["ms_per_view"] = 1e3 * dt / args.steps / args.views
         if launches and samples:
             achieved = ALGO_BYTES_PER_SAMPLE * samples / (field_ms * 1e-3) / 1e9

@@ -218,6 +218,11 @@ typedef struct {
                                 function (its own n_alive / n_samples round schedule, utils.py:667-672). */
     int32_t sync_every;      /* host checks the device "all views finished" flag every this many rounds
                                 (stream sync); 0 = never (all ceil(max_samples/min_samples) rounds are enqueued) */
+    const int32_t *view_order; /* optional (NULL = identity): device permutation of 0..rays_per_view-1, the order in which the
+                                rays of every view are marched and packed into the field kernel's 64-column tiles.  Results
+                                are per ray and do not depend on it; rays that are neighbours in the image should be
+                                neighbours in this order (e.g. 8x8 pixel blocks instead of one-pixel-high strips) so that
+                                a tile's samples share hash-table lines. */
 } mnf_render_opts;
 
 /* bytes of workspace mnf_render_test needs for n_rays rays */

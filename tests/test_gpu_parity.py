@@ -454,6 +454,11 @@ def test_render_batched_views_equal_single_calls(scene, fields):
             np.testing.assert_allclose(batched[key][k * 256:(k + 1) * 256].cpu().numpy(), single[key].cpu().numpy(),
                                        rtol=2e-6, atol=1e-7, err_msg=key)
         assert int(batched["total"][0]) > 0
+    # marching a view's rays in 8x8 pixel blocks (mnf_render_opts.view_order) changes tile composition, not results
+    ordered = RD.render_views(hip, est, o, d, 256, 1024, render_bkgd=bk, probabilistic=True, image_hw=(16, 16), **H.RENDER_KW)
+    for key in ("rgb", "acc", "depth", "sem", "rgb_var", "depth_var"):
+        np.testing.assert_allclose(ordered[key].cpu().numpy(), batched[key].cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=key)
+    assert int(ordered["total"][0]) == int(batched["total"][0]) and int(ordered["total"][1]) == int(batched["total"][1])
     # ragged sizes: 3 views of 150 rays (neither a multiple of 64 nor of the 1024-ray march workgroup) == single calls
     o3, d3 = o[:450].contiguous(), d[:450].contiguous()
     ragged = RD.render_views(hip, est, o3, d3, 150, 1024, render_bkgd=bk, **H.RENDER_KW)

@@ -13,10 +13,10 @@ bk = torch.zeros(3)
 for V in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 8)):
     o = rays.origins[:V].reshape(-1, 3).contiguous(); d = rays.viewdirs[:V].reshape(-1, 3).contiguous()
     for i in range(3):
-        RD.render_views(field, est, o, d, 640000, 1024, render_bkgd=bk, **H.RENDER_KW)
+        RD.render_views(field, est, o, d, 640000, 1024, render_bkgd=bk, image_hw=(800, 800), **H.RENDER_KW)
     torch.cuda.synchronize(); t = time.perf_counter()
     n = max(2, 16 // V)
     for i in range(n):
-        out = RD.render_views(field, est, o, d, 640000, 1024, render_bkgd=bk, **H.RENDER_KW)
+        out = RD.render_views(field, est, o, d, 640000, 1024, render_bkgd=bk, image_hw=(800, 800), **H.RENDER_KW)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
     print(f"V={V}: {dt*1e3:.2f} ms/call  {dt*1e3/V:.2f} ms/view  {V*640000/dt/1e6:.1f} Mrays/s  evaluated/ray={float(out['total'][1])/(V*640000):.2f}")
