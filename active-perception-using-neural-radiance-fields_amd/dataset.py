@@ -95,6 +95,10 @@ class Dataset(torch.utils.data.Dataset):
             image_id = torch.randint(0, self.size, size=(1,), device=self.device)
             x = torch.randint(0, W, size=(num_rays,), device=self.device)
             y = torch.randint(0, H, size=(num_rays,), device=self.device)
+            # same random pixels, grouped by 32x32 image block: the batch is a set (every loss is a mean over rays), and
+            # neighbouring rays share hash-table lines in the sampler's pre-pass, the forward and the gradient scatter
+            order = torch.argsort((y // 32) * ((W + 31) // 32) + x // 32)
+            x, y = x[order], y[order]
         else:
             image_id = torch.tensor([index], device=self.device)
             x, y = torch.meshgrid(torch.arange(W, device=self.device), torch.arange(H, device=self.device), indexing="xy")

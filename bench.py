@@ -130,6 +130,8 @@ def main():
         batches = []
         for k in range(8):
             idx = torch.randint(0, 640 * 640, (R_,), generator=g).numpy()
+            ys, xs = idx // 640, idx % 640                      # grouped by 32x32 image block, as dataset.Dataset.fetch_data does
+            idx = idx[np.argsort((ys // 32) * 20 + xs // 32, kind="stable")]
             r = RD.generate_image_rays(torch.from_numpy(c2w[k:k + 1]), 640, 640, K, dev, idx)
             batches.append((r, torch.rand(R_, 3, generator=g).to(dev), (torch.rand(R_, generator=g) * 4 + 0.5).to(dev),
                             torch.randint(0, 29, (R_,), generator=g).to(dev)))
