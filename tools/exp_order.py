@@ -12,8 +12,20 @@ K = np.array([[400.0, 0, 400], [0, 400.0, 400], [0, 0, 1.0]])
 rays = RD.generate_image_rays(torch.from_numpy(c2w), 800, 800, K, dev)
 bk = torch.zeros(3)
 V = 4
-for block in (0, 2, 4, 8, 16):
-    if block:
+def morton(ys, xs):
+    k = np.zeros_like(ys)
+    for b in range(10):
+        k |= ((xs >> b) & 1) << (2 * b)
+        k |= ((ys >> b) & 1) << (2 * b + 1)
+    return k
+for block in (0, 8, -1, -2):
+    if block == -1 or block == -2:
+        ys, xs = np.meshgrid(np.arange(800), np.arange(800), indexing="ij")
+        if block == -1: key = morton(ys, xs)
+        else: key = ((ys // 8) * 100 + xs // 8) * 64 + morton(ys % 8, xs % 8)     # 8x8 blocks, Z-order inside
+        perm = torch.from_numpy(np.argsort(key.reshape(-1), kind="stable")).to(dev)
+        o = rays.origins[:V][:, perm].reshape(-1, 3).contiguous(); d = rays.viewdirs[:V][:, perm].reshape(-1, 3).contiguous()
+    elif block:
         ys, xs = np.meshgrid(np.arange(800), np.arange(800), indexing="ij")
         key = ((ys // block) * (800 // block) + xs // block) * (block * block) + (ys % block) * block + xs % block
         perm = torch.from_numpy(np.argsort(key.reshape(-1), kind="stable")).to(dev)
