@@ -110,12 +110,35 @@ def require_gpu(*tensors) -> None:
             raise MnfError("libmi355nerf operates on GPU tensors only (got a CPU tensor); there is no CPU fallback")
 
 
+class DevPtr(c_void_p):
+    """A device pointer that remembers which GPU owns it (`launch` derives the device guard and the stream from it)."""
+    device = None
+
+
 def ptr(t):
-    return None if t is None else c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    p = DevPtr(t.data_ptr())
+    p.device = t.device if t.is_cuda else None
+    return p
 
 
-def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream(device=None):
+    """hipStream_t of torch's current stream on `device` (default: the current device)."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def launch(fn, *args):
+    """Call a stream-taking entry point of the C ABI: the GPU that owns the tensors (first device pointer among
+    `args`) is made current for the duration of the call and the work goes onto torch's current stream OF THAT GPU —
+    a model on cuda:1 runs on GPU 1 whatever the caller's current device is (the reference's `DEVICE_GUARD`,
+    utils_cuda.cuh:23-24).  Appends the stream argument and raises MnfError on a non-zero return code."""
+    dev = next((a.device for a in args if isinstance(a, DevPtr) and a.device is not None), None)
+    if dev is None:
+        check(fn(*args, stream()))
+        return
+    with torch.cuda.device(dev):
+        check(fn(*args, stream(dev)))
 
 
 def contig(t, dtype=None):

@@ -35,7 +35,7 @@ struct mnf_field_s {
     void *d_frags;       // fp16 fragment-ordered MLP weights, blocks_total KiB
     int32_t *d_frag_src; // gather table: (buffer << 28) | index, or -1 for a structural zero
     bool params_loaded;
-    const float *master[3];   // fp32 master parameter vectors last passed to mnf_field_set_params (caller-owned)
+    std::vector<int32_t> frag_src_host;   // host copy of the gather table (train.hip inverts it: parameter -> fragment slot)
     void *train_state;        // lazily built by train.hip (transposed fragments, weight-gradient job table)
 };
 
@@ -65,6 +65,7 @@ struct FieldIO {
     const float *t_starts, *t_ends;          // mode 1, 2
     int64_t n;                               // modes 0, 1
     const int32_t *n_dev;                    // mode 2: number of columns (device)
+    int64_t n_cap;                           // mode 2: capacity of the column arrays (the device count is clamped to it)
     const void *enc;                         // optional [ceil(n/64)][8][64] x 16 B feature scratch: non-null selects the
                                              // two-launch path (encode_kernel, then the MLP kernel on its output)
     // outputs: user layout (modes 0,1) ...

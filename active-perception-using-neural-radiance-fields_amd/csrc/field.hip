@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
     constexpr int kWaves = kEncodeThreads / 64;
     constexpr int LPB = 2;   // levels per batch of gathers (16 loads in flight per wave, <= 80 VGPRs, 6 waves per SIMD)
     int64_t n = args.io.n;
-    if (MODE == 2) n = *args.io.n_dev;
+    if (MODE == 2) { n = *args.io.n_dev; if (n > args.io.n_cap) n = args.io.n_cap; }
     const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
     const int64_t n_groups = (n_tiles + kWaves - 1) / kWaves;
     int64_t g_first, g_end, g_step;
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     const int h = lane >> 5;
 
     int64_t n = args.io.n;
-    if (MODE == 2) n = *args.io.n_dev;
+    if (MODE == 2) { n = *args.io.n_dev; if (n > args.io.n_cap) n = args.io.n_cap; }
     const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
     if (n_tiles == 0) return;
     const int wpb = args.active_waves;
@@ -595,8 +595,9 @@ extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
     f->n_sem = (int64_t)Wh * 16 + (int64_t)Wh * Wh + (int64_t)sem_pad * Wh;
     std::vector<int32_t> table = build_frag_table(*cfg);
     f->shape = {W, NH, Wh, cfg->num_semantic_classes, (int)(table.size() / 512)};
+    f->frag_src_host = table;
     f->d_table = nullptr; f->d_frags = nullptr; f->d_frag_src = nullptr; f->params_loaded = false;
-    f->master[0] = f->master[1] = f->master[2] = nullptr; f->train_state = nullptr;
+    f->train_state = nullptr;
     hipError_t e = hipMalloc(&f->d_table, (size_t)f->table_entries * 4 * sizeof(uint16_t) );
     if (e == hipSuccess) e = hipMalloc(&f->d_frags, table.size() * sizeof(uint16_t) + sizeof(LevelMeta) * 16);
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_frag_src, table.size() * sizeof(int32_t));
@@ -651,8 +652,7 @@ extern "C" int mnf_field_set_params(mnf_field_t f, const float *mlp_base, const 
                        mlp_sem, (half_t *)f->d_frags, n_frag);
     rc = launch_status("gather_frags_kernel");
     if (rc) return rc;
-    f->params_loaded = true;
-    f->master[0] = mlp_base; f->master[1] = mlp_head; f->master[2] = mlp_sem;
+    f->params_loaded = true;   // the handle keeps no pointer into the caller's vectors: everything it needs later is in d_table / d_frags
     return MNF_OK;
 }
 

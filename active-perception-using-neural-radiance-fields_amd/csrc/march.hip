@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) traverse_kernel(int32_t n_rays, const flo
                                                        float step_size, float cone_angle, int32_t limit, bool first_pass,
                                                        SegOut iv, SegOut sm, float *__restrict__ terminate_planes) {
     const int64_t cells = (int64_t)res.x * res.y * res.z;
-    for (int32_t tid = blockIdx.x * blockDim.x + threadIdx.x; tid < n_rays; tid += blockDim.x * gridDim.x) {
+    for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < n_rays; tid += (int64_t)blockDim.x * gridDim.x) {
         if (rays_mask && !rays_mask[tid]) continue;
         if (iv.chunk_cnts && !first_pass && iv.chunk_cnts[tid] == 0) continue;
         if (sm.chunk_cnts && !first_pass && sm.chunk_cnts[tid] == 0) continue;
@@ -84,9 +84,9 @@ __global__ void __launch_bounds__(256) traverse_kernel(int32_t n_rays, const flo
         const F3 org = {rays_o[3 * tid], rays_o[3 * tid + 1], rays_o[3 * tid + 2]};
         const F3 dir = {rays_d[3 * tid], rays_d[3 * tid + 1], rays_d[3 * tid + 2]};
         const F3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
-        const int32_t base_hits = tid * n_grids, base_t = tid * n_grids * 2;
+        const int64_t base_hits = tid * n_grids, base_t = tid * n_grids * 2;
         MarchState st = {near_plane, false, 0};
-        for (int32_t i = base_t; i < base_t + n_grids * 2 - 1; ++i) {   // grid.cu:125-151
+        for (int64_t i = base_t; i < base_t + n_grids * 2 - 1; ++i) {   // grid.cu:125-151
             const bool is_entering = t_indices[i] < n_grids;
             int64_t level = t_indices[i] % n_grids;
             if (!hits[base_hits + level]) continue;
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) sample_rays_kernel(int32_t n_rays, const 
         __syncthreads();
     }
     const float ab[6] = {a0, a1, a2, a3, a4, a5};
-    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += blockDim.x * gridDim.x) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)blockDim.x * gridDim.x) {
         const F3 org = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
         const F3 dir = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
         const F3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
@@ -185,12 +185,12 @@ __global__ void __launch_bounds__(64) compact_samples_kernel(const float *__rest
 __global__ void __launch_bounds__(256) exclusive_sum_kernel(int32_t n_rays, const int64_t *__restrict__ starts,
                                                             const int64_t *__restrict__ cnts, const float *__restrict__ in,
                                                             float *__restrict__ out, bool backward) {
-    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rays) return;
-    const int64_t s = starts[r], c = cnts[r];
-    float acc = 0.0f;
-    if (!backward) for (int64_t k = 0; k < c; ++k) { out[s + k] = acc; acc += in[s + k]; }
-    else           for (int64_t k = c - 1; k >= 0; --k) { out[s + k] = acc; acc += in[s + k]; }
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t s = starts[r], c = cnts[r];
+        float acc = 0.0f;
+        if (!backward) for (int64_t k = 0; k < c; ++k) { out[s + k] = acc; acc += in[s + k]; }
+        else           for (int64_t k = c - 1; k >= 0; --k) { out[s + k] = acc; acc += in[s + k]; }
+    }
 }
 
 // volrend.py:258-267 + :361-365 fused: sigma*dt -> alpha, T = exp(-excl_sum) * prefix, w = T*alpha.
@@ -269,16 +269,16 @@ __global__ void __launch_bounds__(256) raygen_kernel(const float *__restrict__ c
 // height index `y_slice`, merge (any member occupied), dilate with a 3x3 box ("symm" boundary == clamped neighbours)
 __global__ void __launch_bounds__(256) planner_map_kernel(const uint8_t *__restrict__ binaries, int n_members, int X, int Y, int Z,
                                                           int y_slice, int32_t *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= X * Z) return;
-    const int x = i / Z, z = i % Z;
-    int hit = 0;
-    for (int dx = -1; dx <= 1; ++dx)
-        for (int dz = -1; dz <= 1; ++dz) {
-            const int xx = min(max(x + dx, 0), X - 1), zz = min(max(z + dz, 0), Z - 1);
-            for (int m = 0; m < n_members; ++m) hit |= binaries[(((int64_t)m * X + xx) * Y + y_slice) * Z + zz];
-        }
-    out[i] = hit ? 1 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)X * Z; i += (int64_t)blockDim.x * gridDim.x) {
+        const int x = (int)(i / Z), z = (int)(i % Z);
+        int hit = 0;
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int xx = min(max(x + dx, 0), X - 1), zz = min(max(z + dz, 0), Z - 1);
+                for (int m = 0; m < n_members; ++m) hit |= binaries[(((int64_t)m * X + xx) * Y + y_slice) * Z + zz];
+            }
+        out[i] = hit ? 1 : 0;
+    }
 }
 
 static inline int grid_for(int64_t n, int threads) {

@@ -31,7 +31,7 @@ struct RenderWs {
     // per view
     int32_t *alive_count, *n_samples, *iter_samples, *active;
     // global
-    int32_t *n_cols, *any_active;
+    int32_t *n_cols, *any_active, *overflow;   // overflow: set if a round ever asked for more columns than col_cap (never, by construction)
     uint32_t *bitgrid;   // bit-packed copy of the occupancy grid (built once per call)
     // per column
     int32_t *col_ray;
@@ -48,11 +48,17 @@ static bool split_field() {
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// A view's rays are marched by its own ceil(rays_per_view / kMarchThreads) workgroups (the last one partly idle when the
+// size is not a multiple): every marching ray of a workgroup then has the same per-ray budget n_samples[view], which is what
+// bounds the columns a round can allocate (below).
+static inline int64_t march_blocks_per_view(int32_t rays_per_view) { return (rays_per_view + kMarchThreads - 1) / kMarchThreads; }
+
 static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_view) {
     const int64_t n_views = n_rays / rays_per_view;
     // columns of one round: a tile of 64 holds floor(64/stride) rays of `stride` columns, so it is at least half
     // used; n_alive*stride <= max(R, 4*n_alive) <= 4R (utils.py:670) -> <= 8R, plus one partial tile per workgroup
-    const int64_t col_cap = 8 * n_rays + 64 * (n_rays / kMarchThreads + 2);
+    // (a march workgroup never mixes views: march_blocks_per_view() workgroups per view, so `stride` is the view's budget)
+    const int64_t col_cap = 8 * n_rays + 64 * (n_views * march_blocks_per_view(rays_per_view) + 2);
     size_t off = 0;
     auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += align_up(bytes); return p; };
     char *p;
@@ -67,7 +73,7 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     p = take(n_views * 4); if (ws) ws->n_samples = (int32_t *)p;
     p = take(n_views * 4); if (ws) ws->iter_samples = (int32_t *)p;
     p = take(n_views * 4); if (ws) ws->active = (int32_t *)p;
-    p = take(256); if (ws) { ws->n_cols = (int32_t *)p; ws->any_active = (int32_t *)p + 1; }
+    p = take(256); if (ws) { ws->n_cols = (int32_t *)p; ws->any_active = (int32_t *)p + 1; ws->overflow = (int32_t *)p + 2; }
     p = take(kMaxGridWords * 4); if (ws) ws->bitgrid = (uint32_t *)p;
     p = take(col_cap * 4); if (ws) ws->col_ray = (int32_t *)p;
     p = take(col_cap * 4); if (ws) ws->col_ts = (float *)p;
@@ -91,7 +97,7 @@ __global__ void __launch_bounds__(kRayThreads) init_kernel(int64_t n_rays, int32
                                                            float a0, float a1, float a2, float a3, float a4, float a5,
                                                            float near_plane, RenderWs ws, RenderOut out) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r == 0) { out.total_samples[0] = 0; out.total_samples[1] = 0; }
+    if (r == 0) { out.total_samples[0] = 0; out.total_samples[1] = 0; *ws.overflow = 0; }
     if (r < n_rays / rays_per_view) { ws.alive_count[r] = rays_per_view; ws.iter_samples[r] = 0; }
     if (r >= n_rays) return;
     const float ab[6] = {a0, a1, a2, a3, a4, a5};
@@ -175,18 +181,20 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
                                                                     const uint8_t *__restrict__ binaries, I3 res, int n_words,
                                                                     float a0, float a1, float a2, float a3, float a4, float a5,
                                                                     float far_plane, float step_size, float cone_angle, RenderWs ws,
-                                                                    const int32_t *__restrict__ view_order) {
+                                                                    const int32_t *__restrict__ view_order, int32_t blocks_per_view) {
     __shared__ int s_wave_tot[kMarchThreads / 64], s_wave_max[kMarchThreads / 64];
     __shared__ int s_base, s_stride, s_total;
     __shared__ uint32_t s_bits[LDS_GRID ? kMaxGridWords : 1];
-    // thread -> ray: identity, or the caller's order inside every view (neighbouring rays into the same tile)
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (view_order && r < n_rays) { const int64_t v0 = r / rays_per_view; r = v0 * rays_per_view + view_order[r - v0 * rays_per_view]; }
+    // workgroup -> (view, slice of the view): a workgroup never mixes views, so all its marching rays share one budget.
+    // thread -> ray inside the view: identity, or the caller's order (neighbouring rays into the same tile)
+    const int v = (int)(blockIdx.x / blocks_per_view);
+    const int in_view = (int)(blockIdx.x - (int64_t)v * blocks_per_view) * kMarchThreads + (int)threadIdx.x;
+    const bool in_range = in_view < rays_per_view;
+    int64_t r = (int64_t)v * rays_per_view + (in_range ? (view_order ? view_order[in_view] : in_view) : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool go = false;
     int ns = 0;
-    if (r < n_rays) {
-        const int v = (int)(r / rays_per_view);
+    if (in_range) {
         go = ws.alive[r] && ws.active[v];
         ns = go ? ws.n_samples[v] : 0;
     }
@@ -206,14 +214,19 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
         s_stride = smax;
         if (tot) {
             const int cap = 64 / smax;
-            s_base = atomicAdd(ws.n_cols, ((tot + cap - 1) / cap) * 64);
+            const int need = ((tot + cap - 1) / cap) * 64;
+            s_base = atomicAdd(ws.n_cols, need);
+            if ((int64_t)s_base + need > ws.col_cap) {   // cannot happen with one view per workgroup (carve()); never write past the workspace
+                atomicExch(ws.overflow, 1);
+                s_base = -1;
+            }
         } else {
             s_base = -1;
         }
         s_total = tot;
     }
     __syncthreads();
-    if (s_base < 0) return;   // uniform: no ray of this workgroup marches this round
+    if (s_base < 0) return;   // uniform: no ray of this workgroup marches this round (or the workspace guard fired)
     if (LDS_GRID) {
         for (int i = threadIdx.x; i < n_words; i += kMarchThreads) s_bits[i] = ws.bitgrid[i];
         __syncthreads();
@@ -443,7 +456,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
 
     FieldIO io = {};
     io.mode = 2; io.rays_o = rays_o; io.rays_d = rays_d; io.col_ray = ws.col_ray; io.t_starts = ws.col_ts; io.t_ends = ws.col_te;
-    io.n_dev = ws.n_cols;
+    io.n_dev = ws.n_cols; io.n_cap = ws.col_cap;
     io.enc = ws.enc;   // non-null only under MNF_FIELD_SPLIT (diagnostic: gather and MLP as two launches)
     io.fr.tile_hdr = ws.tile_hdr; io.fr.alive = ws.alive; io.fr.alive_count = ws.alive_count;
     io.fr.n_samples = ws.n_samples; io.fr.rgb = rgb; io.fr.acc = acc; io.fr.depth = depth; io.fr.sem = sem;
@@ -453,23 +466,29 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     io.fr.alpha_thre = opts->alpha_thre; io.fr.opc_thre = opc_thre;
 
     const int max_rounds = (int)ceil_div(opts->max_samples, min_samples);
+    const int32_t bpv = (int32_t)march_blocks_per_view(opts->rays_per_view);
+    const int march_grid = (int)((int64_t)n_views * bpv);
     for (int round = 0; round < max_rounds; ++round) {
         hipLaunchKernelGGL(round_prep_kernel, dim3(1), dim3(256), 0, s, n_views, opts->rays_per_view, opts->max_samples, min_samples, ws);
         if (opts->sync_every > 0 && round > 0 && round % opts->sync_every == 0) {
             // the prep just enqueued decided whether any view still has a round to run
-            int32_t any = 1;
-            MNF_HIP(hipMemcpyAsync(&any, ws.any_active, sizeof(any), hipMemcpyDeviceToHost, s));
+            int32_t flags[2] = {1, 0};   // any_active, overflow (adjacent words)
+            MNF_HIP(hipMemcpyAsync(flags, ws.any_active, sizeof(flags), hipMemcpyDeviceToHost, s));
             MNF_HIP(hipStreamSynchronize(s));
-            if (!any) break;
+            if (flags[1]) {
+                set_error("render_test: a round needed more sample columns than the workspace holds");
+                return MNF_ERR_WORKSPACE;
+            }
+            if (!flags[0]) break;
         }
         if (lds_grid)
-            hipLaunchKernelGGL(round_march_kernel<true>, dim3((int)ceil_div(n_rays, kMarchThreads)), dim3(kMarchThreads), 0, s, n_rays,
+            hipLaunchKernelGGL(round_march_kernel<true>, dim3(march_grid), dim3(kMarchThreads), 0, s, n_rays,
                                opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
-                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order);
+                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order, bpv);
         else
-            hipLaunchKernelGGL(round_march_kernel<false>, dim3((int)ceil_div(n_rays, kMarchThreads)), dim3(kMarchThreads), 0, s, n_rays,
+            hipLaunchKernelGGL(round_march_kernel<false>, dim3(march_grid), dim3(kMarchThreads), 0, s, n_rays,
                                opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
-                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order);
+                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order, bpv);
         profile_mark(s, true);
         rc = launch_field(f, io, false, s);   // field evaluation + compositing + ray retirement of this round
         profile_mark(s, false);

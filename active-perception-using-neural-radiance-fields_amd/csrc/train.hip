@@ -545,18 +545,15 @@ static bool tables_for(int W, int NH, int C, TrainTables &tt) {
     return false;
 }
 
-__global__ void __launch_bounds__(256) gather_fragsT_kernel(const int32_t *__restrict__ src_idx, const float *__restrict__ p0,
-                                                            const float *__restrict__ p1, const float *__restrict__ p2,
+// Transposed fragments are a re-ordering of the forward fragments the handle already holds in fp16 (every weight sits in
+// exactly one forward slot): `src_slot[i]` = forward slot of transposed element i, -1 = structural zero.  No pointer into
+// the caller's fp32 vectors is kept between calls.
+__global__ void __launch_bounds__(256) gather_fragsT_kernel(const int32_t *__restrict__ src_slot, const half_t *__restrict__ frags,
                                                             half_t *__restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int32_t s = src_idx[i];
-    float v = 0.0f;
-    if (s >= 0) {
-        const int buf = s >> 28, idx = s & 0x0FFFFFFF;
-        v = buf == 0 ? p0[idx] : (buf == 1 ? p1[idx] : p2[idx]);
-    }
-    dst[i] = (half_t)v;
+    const int32_t s = src_slot[i];
+    dst[i] = s >= 0 ? frags[s] : (half_t)0.0f;
 }
 
 struct TrainState {
@@ -574,6 +571,16 @@ static int ensure_train_state(mnf_field_t f) {
         delete ts;
         set_error("train: unsupported neurons=%d layers=%d", f->cfg.neurons, f->cfg.layers);
         return MNF_ERR_UNSUPPORTED;
+    }
+    {   // parameter id -> forward fragment slot
+        std::vector<int32_t> slot_of[3];
+        slot_of[0].assign((size_t)f->n_base_mlp, -1); slot_of[1].assign((size_t)f->n_head, -1); slot_of[2].assign((size_t)f->n_sem, -1);
+        for (size_t i = 0; i < f->frag_src_host.size(); ++i) {
+            const int32_t s = f->frag_src_host[i];
+            if (s >= 0) slot_of[s >> 28][s & 0x0FFFFFFF] = (int32_t)i;
+        }
+        for (auto &s : ts->tt.fragT)
+            if (s >= 0) s = slot_of[s >> 28][s & 0x0FFFFFFF];
     }
     hipError_t e = hipMalloc((void **)&ts->d_fragT_src, ts->tt.fragT.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ts->d_fragT, ts->tt.fragT.size() * sizeof(uint16_t));
@@ -701,10 +708,10 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
         set_error("field_backward: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)v.bytes);
         return MNF_ERR_WORKSPACE;
     }
-    // transposed fp16 weight fragments from the current fp32 master parameters (held by the forward's set_params)
+    // transposed fp16 weight fragments from the handle's forward fragments (the parameters of the last set_params)
     const int64_t n_frag = (int64_t)ts->tt.fragT.size();
     hipLaunchKernelGGL(gather_fragsT_kernel, dim3((unsigned)ceil_div(n_frag, 256)), dim3(256), 0, s, ts->d_fragT_src,
-                       f->master[0], f->master[1], f->master[2], ts->d_fragT, n_frag);
+                       reinterpret_cast<const half_t *>(f->d_frags), ts->d_fragT, n_frag);
     BwdArgs a;
     a.fragsT = reinterpret_cast<const half8 *>(ts->d_fragT);
     a.d_rgb = d_rgb; a.d_sigma = d_density; a.d_sem = d_sem; a.rgb = rgb; a.sigma = density;

@@ -112,8 +112,7 @@ class Dataset(torch.utils.data.Dataset):
         origins = torch.empty(1, n, 3, device=self.device)
         viewdirs = torch.empty(1, n, 3, device=self.device)
         L.require_gpu(c2w, pix)
-        L.check(L.load_library().mnf_generate_rays(L.ptr(c2w), 1, W, H, self._focal, L.ptr(pix), n, L.ptr(origins), L.ptr(viewdirs),
-                                                   L.stream()))
+        L.launch(L.load_library().mnf_generate_rays, L.ptr(c2w), 1, W, H, self._focal, L.ptr(pix), n, L.ptr(origins), L.ptr(viewdirs))
         shape = (n,) if self.training else (H, W)
         rays = Rays(origins=origins.reshape(*shape, 3), viewdirs=viewdirs.reshape(*shape, 3))
         return {"rgb": rgb.reshape(*shape, rgb.shape[-1]), "dep": dep.reshape(shape), "sem": sem.reshape(shape), "rays": rays,
@@ -154,7 +153,7 @@ def planner_path_finding_map(estimators, current_state_xzy=None, aabb_xzy=None, 
     bu = b.view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8)
     M, X, Y, Z = bu.shape
     out = torch.empty(X, Z, dtype=torch.int32, device=b.device)
-    L.check(L.load_library().mnf_planner_map(L.ptr(bu), M, X, Y, Z, y_slice, L.ptr(out), L.stream()))
+    L.launch(L.load_library().mnf_planner_map, L.ptr(bu), M, X, Y, Z, y_slice, L.ptr(out))
     m = out.cpu().numpy()
     if current_state_xzy is not None:
         v = np.array((np.asarray(current_state_xzy)[:3] - np.asarray(aabb_xzy)[:3]) // voxel_grid_size, dtype=int)

@@ -59,8 +59,8 @@ def ray_aabb_intersect(rays_o: Tensor, rays_d: Tensor, aabbs: Tensor, near_plane
     t_mins = torch.empty((n, m), device=rays_o.device, dtype=torch.float32)
     t_maxs = torch.empty_like(t_mins)
     hits = torch.empty((n, m), device=rays_o.device, dtype=torch.bool)
-    L.check(L.load_library().mnf_ray_aabb_intersect(L.ptr(rays_o), L.ptr(rays_d), n, L.ptr(aabbs), m, near_plane, far_plane,
-                                                    miss_value, L.ptr(t_mins), L.ptr(t_maxs), L.ptr(hits), L.stream()))
+    L.launch(L.load_library().mnf_ray_aabb_intersect, L.ptr(rays_o), L.ptr(rays_d), n, L.ptr(aabbs), m, near_plane, far_plane,
+                                                    miss_value, L.ptr(t_mins), L.ptr(t_maxs), L.ptr(hits))
     return t_mins, t_maxs, hits
 
 
@@ -115,12 +115,12 @@ def traverse_grids(rays_o: Tensor, rays_d: Tensor, binaries: Tensor, aabbs: Tens
     def call(first_pass, iv, sm, mask, term_t):
         iv_vals, iv_r, iv_l, iv_rt, iv_st, iv_cnt = iv
         sm_vals, sm_r, sm_valid, sm_st, sm_cnt = sm
-        L.check(lib.mnf_traverse_grids(
+        L.launch(lib.mnf_traverse_grids, 
             L.ptr(rays_o), L.ptr(rays_d), L.ptr(mask), n, L.ptr(binaries_u8), L.ptr(aabbs), n_grids, rx, ry, rz,
             L.ptr(hits_c), L.ptr(t_sorted), L.ptr(t_indices), L.ptr(near_planes), L.ptr(far_planes),
             float(step_size), float(cone_angle), int(traverse_steps_limit), 1 if first_pass else 0,
             L.ptr(iv_vals), L.ptr(iv_r), L.ptr(iv_l), L.ptr(iv_rt), L.ptr(iv_st), L.ptr(iv_cnt),
-            L.ptr(sm_vals), L.ptr(sm_r), L.ptr(sm_valid), L.ptr(sm_st), L.ptr(sm_cnt), L.ptr(term_t), L.stream()))
+            L.ptr(sm_vals), L.ptr(sm_r), L.ptr(sm_valid), L.ptr(sm_st), L.ptr(sm_cnt), L.ptr(term_t))
 
     if over_allocate:
         # grid.cu:364-404
@@ -169,7 +169,7 @@ def pack_info_grouped(ray_indices: Tensor, n_rays: int) -> Tensor:
     [n_rays, 2] result, from run boundaries instead of an index_add over all samples."""
     ray_indices = ray_indices.contiguous()
     bounds = torch.zeros((2, n_rays), device=ray_indices.device, dtype=torch.int64)
-    L.check(L.load_library().mnf_run_bounds(L.ptr(ray_indices), ray_indices.shape[0], L.ptr(bounds[0]), L.ptr(bounds[1]), L.stream()))
+    L.launch(L.load_library().mnf_run_bounds, L.ptr(ray_indices), ray_indices.shape[0], L.ptr(bounds[0]), L.ptr(bounds[1]))
     cnts = bounds[1] - bounds[0]
     return torch.stack([cnts.cumsum(0) - cnts, cnts], dim=-1)
 
@@ -182,8 +182,8 @@ class _ExclusiveSum(torch.autograd.Function):
         chunk_starts, chunk_cnts = chunk_starts.contiguous(), chunk_cnts.contiguous()
         inputs = inputs.contiguous()
         out = torch.empty_like(inputs)
-        L.check(L.load_library().mnf_exclusive_sum(L.ptr(chunk_starts), L.ptr(chunk_cnts), chunk_cnts.shape[0], L.ptr(inputs),
-                                                   L.ptr(out), inputs.shape[0], 0, L.stream()))
+        L.launch(L.load_library().mnf_exclusive_sum, L.ptr(chunk_starts), L.ptr(chunk_cnts), chunk_cnts.shape[0], L.ptr(inputs),
+                                                   L.ptr(out), inputs.shape[0], 0)
         ctx.save_for_backward(chunk_starts, chunk_cnts)
         return out
 
@@ -192,8 +192,8 @@ class _ExclusiveSum(torch.autograd.Function):
         chunk_starts, chunk_cnts = ctx.saved_tensors
         g = g.contiguous()
         out = torch.empty_like(g)
-        L.check(L.load_library().mnf_exclusive_sum(L.ptr(chunk_starts), L.ptr(chunk_cnts), chunk_cnts.shape[0], L.ptr(g),
-                                                   L.ptr(out), g.shape[0], 1, L.stream()))
+        L.launch(L.load_library().mnf_exclusive_sum, L.ptr(chunk_starts), L.ptr(chunk_cnts), chunk_cnts.shape[0], L.ptr(g),
+                                                   L.ptr(out), g.shape[0], 1)
         return None, None, out
 
 
@@ -239,9 +239,9 @@ def render_visibility_from_density(t_starts, t_ends, sigmas, packed_info=None, r
         ts, te, sg = L.contig(t_starts, torch.float32), L.contig(t_ends, torch.float32), L.contig(sigmas, torch.float32)
         pf = L.contig(prefix_trans, torch.float32)
         trans, alphas = torch.empty_like(sg), torch.empty_like(sg)
-        L.check(L.load_library().mnf_render_weight_from_density(L.ptr(starts), L.ptr(cnts), cnts.shape[0], L.ptr(ts), L.ptr(te),
+        L.launch(L.load_library().mnf_render_weight_from_density, L.ptr(starts), L.ptr(cnts), cnts.shape[0], L.ptr(ts), L.ptr(te),
                                                                 L.ptr(sg), L.ptr(pf), sg.shape[0], None, L.ptr(trans),
-                                                                L.ptr(alphas), L.stream()))
+                                                                L.ptr(alphas))
     vis = trans >= early_stop_eps
     if alpha_thre > 0:
         vis = vis & (alphas >= alpha_thre)
@@ -325,6 +325,16 @@ class OccGridEstimator(torch.nn.Module):
     def device(self):
         return self.occs.device
 
+    def aabb_host(self, lvl: int = 0):
+        """Six host floats of `aabbs[lvl]`, cached on this module and refreshed whenever the buffer is replaced, moved or
+        written in place (keyed on the tensor itself, not on the module's identity)."""
+        a = self.aabbs
+        key = (a.data_ptr(), a._version, str(a.device), tuple(a.shape))
+        if getattr(self, "_aabb_host_key", None) != key:
+            self._aabb_host_vals = [[float(x) for x in row] for row in a.detach().cpu().tolist()]
+            self._aabb_host_key = key
+        return self._aabb_host_vals[lvl]
+
     @torch.no_grad()
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
                  alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
@@ -383,21 +393,17 @@ class OccGridEstimator(torch.nn.Module):
             cap = int(max(64, min(2048, (1 << 27) // n)))   # scratch <= 1 GiB; longest reference-config ray: ~1400 samples
         b = self.binaries
         b = b.contiguous().view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8).contiguous()
-        key = (self.aabbs.data_ptr(), self.aabbs._version)
-        if getattr(self, "_aabb_host_key", None) != key:
-            self._aabb_host = [float(x) for x in self.aabbs[0].detach().cpu().tolist()]
-            self._aabb_host_key = key
         import ctypes
-        aabb_host = (ctypes.c_float * 6)(*self._aabb_host)
+        aabb_host = (ctypes.c_float * 6)(*self.aabb_host(0))
         rays_o, rays_d = L.contig(rays_o, torch.float32), L.contig(rays_d, torch.float32)
         near_planes, far_planes = L.contig(near_planes, torch.float32), L.contig(far_planes, torch.float32)
         scratch = torch.empty((2, n, cap), device=dev, dtype=torch.float32)
         counts = torch.empty((n,), device=dev, dtype=torch.int64)
         res = [int(x) for x in b.shape[1:]]
         lib = L.load_library()
-        L.check(lib.mnf_sample_rays(L.ptr(rays_o), L.ptr(rays_d), n, L.ptr(b), res[0], res[1], res[2], aabb_host, L.ptr(near_planes),
+        L.launch(lib.mnf_sample_rays, L.ptr(rays_o), L.ptr(rays_d), n, L.ptr(b), res[0], res[1], res[2], aabb_host, L.ptr(near_planes),
                                     L.ptr(far_planes), float(step_size), float(cone_angle), cap, L.ptr(scratch[0]), L.ptr(scratch[1]),
-                                    L.ptr(counts), L.stream()))
+                                    L.ptr(counts))
         cum = counts.cumsum(0)
         total, longest = (int(x) for x in torch.stack([cum[-1], counts.max()]).tolist())   # the one sync (data_spec.hpp:91 has it too)
         if longest > cap:
@@ -406,8 +412,8 @@ class OccGridEstimator(torch.nn.Module):
         t_starts, t_ends = torch.empty((total,), device=dev), torch.empty((total,), device=dev)
         ray_indices = torch.empty((total,), device=dev, dtype=torch.int64)
         if total:
-            L.check(lib.mnf_compact_samples(L.ptr(scratch[0]), L.ptr(scratch[1]), cap, L.ptr(starts), L.ptr(counts), n, L.ptr(t_starts),
-                                            L.ptr(t_ends), L.ptr(ray_indices), L.stream()))
+            L.launch(lib.mnf_compact_samples, L.ptr(scratch[0]), L.ptr(scratch[1]), cap, L.ptr(starts), L.ptr(counts), n, L.ptr(t_starts),
+                                            L.ptr(t_ends), L.ptr(ray_indices))
         return ray_indices, t_starts, t_ends, torch.stack([starts, counts], dim=-1)
 
     @torch.no_grad()

@@ -51,8 +51,8 @@ class _FieldFunction(torch.autograd.Function):
         nbytes = lib.mnf_field_train_workspace_bytes(h, n)
         ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
         if n:
-            L.check(lib.mnf_field_forward_train(h, L.ptr(pos), L.ptr(dirs), n, L.ptr(rgb), L.ptr(sigma), L.ptr(sem), L.ptr(ws),
-                                                nbytes, L.stream()))
+            L.launch(lib.mnf_field_forward_train, h, L.ptr(pos), L.ptr(dirs), n, L.ptr(rgb), L.ptr(sigma), L.ptr(sem), L.ptr(ws),
+                                                nbytes)
         ctx.module, ctx.ws, ctx.nbytes, ctx.n = module, ws, nbytes, n
         ctx.save_for_backward(pos, rgb, sigma)
         return rgb, sigma, sem
@@ -70,9 +70,8 @@ class _FieldFunction(torch.autograd.Function):
         zeros = lambda g, shape: torch.zeros(shape, device=dev) if g is None else L.contig(g, torch.float32)
         g_rgb, g_sigma = zeros(g_rgb, rgb.shape), zeros(g_sigma, sigma.shape)
         g_sem = zeros(g_sem, (ctx.n, module.num_semantic_classes))
-        L.check(lib.mnf_field_backward(h, L.ptr(pos), ctx.n, L.ptr(g_rgb), L.ptr(g_sigma), L.ptr(g_sem), L.ptr(rgb), L.ptr(sigma),
-                                       L.ptr(ctx.ws), ctx.nbytes, float(module.loss_scale), L.ptr(g_base), L.ptr(g_head), L.ptr(g_s),
-                                       L.stream()))
+        L.launch(lib.mnf_field_backward, h, L.ptr(pos), ctx.n, L.ptr(g_rgb), L.ptr(g_sigma), L.ptr(g_sem), L.ptr(rgb), L.ptr(sigma),
+                                       L.ptr(ctx.ws), ctx.nbytes, float(module.loss_scale), L.ptr(g_base), L.ptr(g_head), L.ptr(g_s))
         ctx.ws = None
         return None, None, None, g_base, g_head, g_s
 
@@ -163,8 +162,8 @@ class NGPRadianceField(torch.nn.Module):
         versions = (self.mlp_base.params._version, self.mlp_head.params._version, self.mlp_sem.params._version,
                     self.mlp_base.params.data_ptr())
         if versions != self._loaded_versions:
-            L.check(lib.mnf_field_set_params(self._handle, L.ptr(self.mlp_base.params), L.ptr(self.mlp_head.params),
-                                             L.ptr(self.mlp_sem.params), L.stream()))
+            L.launch(lib.mnf_field_set_params, self._handle, L.ptr(self.mlp_base.params), L.ptr(self.mlp_head.params),
+                                             L.ptr(self.mlp_sem.params))
             self._loaded_versions = versions
         return self._handle
 
@@ -195,7 +194,7 @@ class NGPRadianceField(torch.nn.Module):
         shp = x.shape[:-1]
         pos = L.contig(x.reshape(-1, 3), torch.float32)
         out = torch.empty(pos.shape[0], 1, device=pos.device, dtype=torch.float32)
-        L.check(L.load_library().mnf_field_density(h, L.ptr(pos), pos.shape[0], L.ptr(out), L.stream()))
+        L.launch(L.load_library().mnf_field_density, h, L.ptr(pos), pos.shape[0], L.ptr(out))
         return out.view(*shp, 1)
 
     def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
@@ -215,7 +214,7 @@ class NGPRadianceField(torch.nn.Module):
         rgb = torch.empty(n, 3, device=pos.device, dtype=torch.float32)
         sigma = torch.empty(n, 1, device=pos.device, dtype=torch.float32)
         sem = torch.empty(n, self.num_semantic_classes, device=pos.device, dtype=torch.float32)
-        L.check(L.load_library().mnf_field_forward(h, L.ptr(pos), L.ptr(dirs), n, L.ptr(rgb), L.ptr(sigma), L.ptr(sem), L.stream()))
+        L.launch(L.load_library().mnf_field_forward, h, L.ptr(pos), L.ptr(dirs), n, L.ptr(rgb), L.ptr(sigma), L.ptr(sem))
         return rgb.view(*shp, 3), sigma.view(*shp, 1), sem.view(*shp, self.num_semantic_classes)
 
     @torch.no_grad()
@@ -232,6 +231,6 @@ class NGPRadianceField(torch.nn.Module):
         if not density_only:
             rgb = torch.empty(n, 3, device=o.device, dtype=torch.float32)
             sem = torch.empty(n, self.num_semantic_classes, device=o.device, dtype=torch.float32)
-        L.check(L.load_library().mnf_field_forward_samples(h, L.ptr(o), L.ptr(d), L.ptr(ri), L.ptr(ts), L.ptr(te), n,
-                                                           L.ptr(rgb), L.ptr(sigma), L.ptr(sem), L.stream()))
+        L.launch(L.load_library().mnf_field_forward_samples, h, L.ptr(o), L.ptr(d), L.ptr(ri), L.ptr(ts), L.ptr(te), n,
+                                                           L.ptr(rgb), L.ptr(sigma), L.ptr(sem))
         return (sigma,) if density_only else (rgb, sigma, sem)

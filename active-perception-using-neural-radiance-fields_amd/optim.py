@@ -39,9 +39,8 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 g = p.grad.contiguous()
-                L.check(lib.mnf_adam_step(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
-                                          float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), int(st["step"].item()),
-                                          L.stream()))
+                L.launch(lib.mnf_adam_step, L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
+                                          float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), int(st["step"].item()))
                 torch.autograd.graph.increment_version(p)      # in-place update outside autograd's view: the handle reloads
         return loss
 
@@ -57,5 +56,5 @@ def count_nan_gradients(parameters) -> torch.Tensor:
         if count is None:
             count = torch.zeros((), dtype=torch.int32, device=p.grad.device)
         g = p.grad.contiguous()
-        L.check(lib.mnf_count_nan(L.ptr(g), g.numel(), L.ptr(count), L.stream()))
+        L.launch(lib.mnf_count_nan, L.ptr(g), g.numel(), L.ptr(count))
     return count if count is not None else torch.zeros((), dtype=torch.int32)

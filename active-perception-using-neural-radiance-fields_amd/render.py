@@ -32,24 +32,20 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
     return ws
 
 
-_AABB_HOST = {}
+def release_workspaces():
+    """Drop the cached render workspaces (they only ever grow: one per device, sized for the largest call so far)."""
+    _WORKSPACES.clear()
 
 
 def _single_level(estimator):
-    """-> (binaries u8 [1,X,Y,Z] on device, aabb as 6 host floats).  The host copy of the aabb is cached per
-    tensor version so that a render call does not synchronise the device."""
+    """-> (binaries u8 [1,X,Y,Z] on device, aabb as 6 host floats).  The host copy of the aabb lives on the estimator
+    and is refreshed when the tensor changes (`OccGridEstimator.aabb_host`), so a render call does not synchronise."""
     if estimator.binaries.shape[0] != 1:
         raise NotImplementedError("the fused renderer supports one occupancy level (the reference configs use "
                                   "main_grid_nlvl: 1); use nerfacc.traverse_grids for multi-level grids")
     b = estimator.binaries
     b = b.contiguous().view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8).contiguous()
-    a = estimator.aabbs
-    key = (a.data_ptr(), a._version, a.device)
-    host = _AABB_HOST.get(id(estimator))
-    if host is None or host[0] != key:
-        host = (key, [float(x) for x in a[0].detach().cpu().tolist()])
-        _AABB_HOST[id(estimator)] = host
-    return b, host[1]
+    return b, estimator.aabb_host(0)
 
 
 _VIEW_ORDERS = {}
@@ -109,9 +105,9 @@ def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_p
         ws = _workspace(dev, nbytes)
         aabb_host = (ctypes.c_float * 6)(*aabb)
         res = binaries.shape[1:]
-        L.check(lib.mnf_render_test(handle, L.ptr(binaries), res[0], res[1], res[2], aabb_host, L.ptr(o), L.ptr(d), n,
+        L.launch(lib.mnf_render_test, handle, L.ptr(binaries), res[0], res[1], res[2], aabb_host, L.ptr(o), L.ptr(d), n,
                                     ctypes.byref(opts), L.ptr(rgb), L.ptr(acc), L.ptr(depth), L.ptr(sem), L.ptr(rgb_var),
-                                    L.ptr(depth_var), L.ptr(total), L.ptr(ws), nbytes, L.stream()))
+                                    L.ptr(depth_var), L.ptr(total), L.ptr(ws), nbytes)
     shp = tuple(rays_shape[:-1])
     out = dict(rgb=rgb.view(*shp, -1), acc=acc.view(*shp, -1), depth=depth.view(*shp, -1), sem=sem.view(*shp, -1), total=total)
     if probabilistic:
@@ -172,10 +168,10 @@ class _CompositeTrain(torch.autograd.Function):
         colors, semantics = torch.empty((R, 3), device=dev), torch.empty((R, C), device=dev)
         opacities, depths = torch.empty((R, 1), device=dev), torch.empty((R, 1), device=dev)
         weights, trans, alphas = torch.empty((N,), device=dev), torch.empty((N,), device=dev), torch.empty((N,), device=dev)
-        L.check(L.load_library().mnf_composite_train_forward(
+        L.launch(L.load_library().mnf_composite_train_forward, 
             L.ptr(chunk_starts), L.ptr(chunk_cnts), R, L.ptr(t_starts), L.ptr(t_ends), L.ptr(sigmas), L.ptr(rgbs), L.ptr(sems), C, N,
             L.ptr(bkgd), L.ptr(colors), L.ptr(opacities), L.ptr(depths), L.ptr(semantics), L.ptr(weights), L.ptr(trans),
-            L.ptr(alphas), L.stream()))
+            L.ptr(alphas))
         ctx.save_for_backward(chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, weights, trans, opacities, depths)
         ctx.bkgd = bkgd
         ctx.mark_non_differentiable(weights, trans, alphas)
@@ -187,10 +183,10 @@ class _CompositeTrain(torch.autograd.Function):
         R, N, C = chunk_cnts.shape[0], sigmas.shape[0], sems.shape[-1]
         d_sig, d_rgb, d_sem = torch.empty_like(sigmas), torch.empty_like(rgbs), torch.empty_like(sems)
         g = [None if t is None else t.contiguous().float() for t in (g_rgb, g_acc, g_dep, g_sem)]
-        L.check(L.load_library().mnf_composite_train_backward(
+        L.launch(L.load_library().mnf_composite_train_backward, 
             L.ptr(chunk_starts), L.ptr(chunk_cnts), R, L.ptr(t_starts), L.ptr(t_ends), L.ptr(sigmas), L.ptr(rgbs), L.ptr(sems), C, N,
             L.ptr(ctx.bkgd), L.ptr(weights), L.ptr(trans), L.ptr(opacities), L.ptr(depths), L.ptr(g[0]), L.ptr(g[1]), L.ptr(g[2]),
-            L.ptr(g[3]), L.ptr(d_sig), L.ptr(d_rgb), L.ptr(d_sem), L.stream()))
+            L.ptr(g[3]), L.ptr(d_sig), L.ptr(d_rgb), L.ptr(d_sem))
         return None, None, None, None, d_sig, d_rgb, d_sem, None
 
 
@@ -341,8 +337,8 @@ def generate_image_rays(pose, width, height, K, device, pix_idx=None):
         n_pix = idx_t.shape[0]
     origins = torch.empty(V, n_pix, 3, device=device)
     viewdirs = torch.empty(V, n_pix, 3, device=device)
-    L.check(L.load_library().mnf_generate_rays(L.ptr(c2w), V, width, height, float(np.float32(K[0, 0])), L.ptr(idx_t), n_pix,
-                                               L.ptr(origins), L.ptr(viewdirs), L.stream()))
+    L.launch(L.load_library().mnf_generate_rays, L.ptr(c2w), V, width, height, float(np.float32(K[0, 0])), L.ptr(idx_t), n_pix,
+                                               L.ptr(origins), L.ptr(viewdirs))
     if V == 1:
         return Rays(origins=origins[0], viewdirs=viewdirs[0])
     return Rays(origins=origins, viewdirs=viewdirs)
@@ -396,7 +392,7 @@ def score_view_terms(rgb_var, depth_var, acc, sem):
     M, V, P, C = sem.shape
     rv, dv, ac, sm = (L.contig(t, torch.float32) for t in (rgb_var, depth_var, acc, sem))
     terms = torch.empty(V, 4, dtype=torch.float64, device=sem.device)
-    L.check(L.load_library().mnf_score_views(L.ptr(rv), L.ptr(dv), L.ptr(ac), L.ptr(sm), M, V, P, C, L.ptr(terms), L.stream()))
+    L.launch(L.load_library().mnf_score_views, L.ptr(rv), L.ptr(dv), L.ptr(ac), L.ptr(sm), M, V, P, C, L.ptr(terms))
     return terms
 
 

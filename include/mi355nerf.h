@@ -194,7 +194,7 @@ int mnf_field_forward_train(mnf_field_t f, const float *positions, const float *
  * forward outputs; `workspace` is the one the forward filled.  g_base / g_head / g_sem receive dL/d(params) in the
  * state_dict layout (fp32, overwritten).  Activation gradients are carried in fp16 scaled by loss_scale (tcnn's
  * default is 128); the returned gradients are un-scaled.  The parameters are the ones last passed to
- * mnf_field_set_params (they must still be alive). */
+ * mnf_field_set_params (the handle holds its own fp16 copies; the caller's vectors need not be alive). */
 int mnf_field_backward(mnf_field_t f, const float *positions, int64_t n,
                        const float *d_rgb, const float *d_density, const float *d_sem,
                        const float *rgb, const float *density,

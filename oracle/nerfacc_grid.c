@@ -24,7 +24,7 @@
  * (a) the CPU-runnable pure-torch twin `_ray_aabb_intersect` (grid.py:54-90) through
  * golden vectors, (b) the reference's own property tests re-run on this code
  * (samples lie in occupied cells per the reference's `_query`, near/far bounds,
- * chunked == two-pass), see tests/test_oracle_marcher.py.  The build must use
+ * chunked == two-pass), see tests/test_oracle_golden.py (test_marcher_*).  The build must use
  * -ffp-contract=off: the marcher's t values come from chains of fp32 adds whose
  * rounding must not be altered by FMA contraction (nvcc's default -fmad=true may
  * contract some of them in the reference build; that choice is compiler-internal and

@@ -69,3 +69,23 @@ def planner_path_finding_map(binaries_list, current_state_xzy=None, aabb_xzy=Non
         path[v[1], v[0]] = 0; path[v[1] + 1, v[0]] = 0; path[v[1] - 1, v[0]] = 0
         path[v[1], v[0] + 1] = 0; path[v[1], v[0] - 1] = 0
     return path
+
+
+def query(x, data, base_aabb):
+    """grid.py:201-237 `_query`: occupancy value and mip selector of world points in a 2x-nested multi-level grid.
+    x [N,3], data [L,X,Y,Z], base_aabb [6] -> (values * selector, selector).  Pinned against the reference function through
+    tests/golden/query.npz (tests/test_oracle_golden.py::test_marcher_samples_in_occupied_cells)."""
+    x = np.asarray(x, np.float32)
+    data = np.asarray(data)
+    a = np.asarray(base_aabb, np.float32)
+    x_norm = (x - a[:3]) / (a[3:] - a[:3])
+    maxval = np.maximum(np.abs(x_norm - np.float32(0.5)).max(-1), np.float32(0.1))
+    exponent = np.frexp(maxval)[1].astype(np.int64)
+    mip = np.maximum(exponent + 1, 0)
+    selector = mip < data.shape[0]
+    scale = (2.0 ** mip).astype(np.float32)
+    x_unit = (x_norm - np.float32(0.5)) / scale[:, None] + np.float32(0.5)
+    res = np.asarray(data.shape[1:], np.int64)
+    ix = np.minimum((x_unit * res.astype(np.float32)).astype(np.int64), res - 1)
+    mip = np.minimum(mip, data.shape[0] - 1)
+    return data[mip, ix[:, 0], ix[:, 1], ix[:, 2]] * selector, selector

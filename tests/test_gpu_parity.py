@@ -90,8 +90,10 @@ def test_traverse_grids_two_pass_bit_exact(n_grids, cone):
     assert ref[1].packed_info[:, 1].sum() > 10000
     # reference property (tests/test_grid.py:39-68): every sample lies in an occupied cell
     iv, sm, _ = got
-    ts, te, ri = iv.vals[iv.is_left], iv.vals[iv.is_right], sm.ray_indices
+    ts, te, ri = (t.cpu().numpy() for t in (iv.vals[iv.is_left], iv.vals[iv.is_right], sm.ray_indices))
     assert ts.shape == te.shape == ri.shape
+    occ, sel = OG.query(o[ri] + d[ri] * ((ts + te)[:, None] / np.float32(2.0)), binaries, aabbs[0])
+    assert occ.all() and sel.all()
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
@@ -300,7 +302,8 @@ def test_grid_meta_matches_oracle(fields):
     assert [int(x["res"]) for x in lv] == res and [x["n"] for x in lv] == size and [x["offset"] for x in lv] == off
     assert [int(x["hashed"]) for x in lv] == hashed
     np.testing.assert_array_equal(np.asarray(scale, np.float32), np.asarray([x["scale"] for x in lv], np.float32))
-    assert res[:6] == [16, 24, 34, 49, 71, 102] and total == 6299960 - 0 or True
+    assert res[:6] == [16, 24, 34, 49, 71, 102] and hashed[:6] == [0, 0, 0, 0, 0, 1]
+    assert total == 6299960 and sum(size) == total      # 6 299 960 entries x 4 features (16 levels, T = 2^19)
 
 
 @pytest.mark.parametrize("neurons,layers,C,lh", [(128, 2, 29, 19), (64, 4, 29, 15), (128, 4, 13, 14), (64, 1, 32, 12),

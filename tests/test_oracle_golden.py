@@ -149,6 +149,11 @@ def test_marcher_samples_in_occupied_cells(golden):
     np.testing.assert_array_equal(sm.packed_info[:, 1], g["chunk_cnts"])
     assert int(g["n_samples"]) == iv.is_left.sum() == iv.is_right.sum() == len(sm.vals)
     np.testing.assert_allclose(iv.vals[iv.is_left].astype(np.float64).sum(), g["t_starts_sum"], rtol=1e-9)
+    # the oracle's own `_query` restatement (used by the GPU property test) agrees with what the reference function said
+    ts, te, ri = iv.vals[iv.is_left], iv.vals[iv.is_right], sm.ray_indices
+    pos = g["rays_o"][ri] + g["rays_d"][ri] * ((ts + te)[:, None] / np.float32(2.0))
+    occ, sel = OG.query(pos, binaries, g["aabbs"][0])
+    assert bool(occ.all()) == bool(g["ref_query_all_occupied"]) and bool(sel.all()) == bool(g["ref_query_all_selected"])
 
 
 def test_marcher_chunked_equals_two_pass():
