@@ -2,7 +2,7 @@
 memory and streams; tensors cross the boundary as raw device pointers."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uint64, c_void_p
 
 import torch
 
@@ -25,7 +25,7 @@ class RenderOpts(ctypes.Structure):
     _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float),
                 ("cone_angle", c_float), ("alpha_thre", c_float), ("early_stop_eps", c_float),
                 ("render_bkgd", c_float * 3), ("max_samples", c_int32), ("probabilistic", c_int32),
-                ("rays_per_view", c_int32), ("sync_every", c_int32), ("view_order", c_void_p)]
+                ("rays_per_view", c_int32), ("sync_every", c_int32), ("view_order", c_void_p), ("bitgrid", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/mi355nerf.h
@@ -41,7 +41,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_sample_rays": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                  c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_compact_samples": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_exclusive_sum": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "mnf_render_weight_from_density": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -55,6 +55,20 @@ SIGNATURES = {
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int32, c_void_p]),
     "mnf_count_nan": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mnf_scan_workspace_bytes": (c_int64, [c_int64]),
+    "mnf_pack_info": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_exclusive_scan_i64": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_accumulate_along_rays": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "mnf_accumulate_along_rays_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_occ_workspace_bytes": (c_int64, [c_int64, c_int32]),
+    "mnf_occ_list_capacity": (c_int64, [c_int64, c_int32, c_int32]),
+    "mnf_pack_bitgrid": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "mnf_occ_sample_cells": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_uint64, c_void_p, c_void_p,
+                                       c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "mnf_occ_apply": (c_int32, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_float, c_void_p, c_int64, c_void_p]),
+    "mnf_occ_binarize": (c_int32, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_update_occupancy": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_float,
+                                       c_float, c_float, c_uint64, c_void_p, c_int64, c_void_p]),
     "mnf_generate_rays": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mnf_field_create": (c_int32, [POINTER(FieldConfig), POINTER(c_void_p)]),
     "mnf_field_destroy": (c_int32, [c_void_p]),

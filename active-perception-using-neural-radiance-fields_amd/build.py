@@ -20,6 +20,7 @@ SOURCES = {
     "field.hip": [],
     "train.hip": [],
     "composite_train.hip": [],
+    "occupancy.hip": ["-ffp-contract=off"],
 }
 
 

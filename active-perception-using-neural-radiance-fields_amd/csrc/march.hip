@@ -130,18 +130,22 @@ __global__ void __launch_bounds__(256) sample_rays_kernel(int32_t n_rays, const 
                                                           float a3, float a4, float a5, const float *__restrict__ near_planes,
                                                           const float *__restrict__ far_planes, float step_size, float cone_angle,
                                                           int32_t cap, float *__restrict__ scratch_ts, float *__restrict__ scratch_te,
-                                                          int64_t *__restrict__ counts) {
+                                                          int64_t *__restrict__ counts, const uint32_t *__restrict__ bitgrid) {
     __shared__ uint32_t s_bits[LDS_GRID ? kSamplerGridWords : 1];
     const int64_t cells = (int64_t)res.x * res.y * res.z;
     if (LDS_GRID) {
         const int n_words = (int)((cells + 31) / 32);
-        for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
-            uint32_t v = 0;
-            for (int b = 0; b < 32; ++b) {
-                const int64_t c = (int64_t)w * 32 + b;
-                if (c < cells && binaries[c]) v |= 1u << b;
+        if (bitgrid) {   // the estimator's bit-packed grid (kept current by mnf_occ_binarize): 1/8 of the bytes, no packing here
+            for (int w = threadIdx.x; w < n_words; w += blockDim.x) s_bits[w] = bitgrid[w];
+        } else {
+            for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
+                uint32_t v = 0;
+                for (int b = 0; b < 32; ++b) {
+                    const int64_t c = (int64_t)w * 32 + b;
+                    if (c < cells && binaries[c]) v |= 1u << b;
+                }
+                s_bits[w] = v;
             }
-            s_bits[w] = v;
         }
         __syncthreads();
     }
@@ -240,6 +244,107 @@ __global__ void __launch_bounds__(256) run_bounds_kernel(const int64_t *__restri
     }
 }
 
+// ------------------------------------------------------------------ int64 exclusive prefix sum (chunk starts from chunk counts)
+// `RaySegmentsSpec::memalloc_data_from_chunk` (include/data_spec.hpp:86-96) and `pack_info` (pack.py:10-38) turn per-ray
+// counts into chunk starts.  Three short launches: tile sums, a one-workgroup scan of the tile sums, tile-local scans.
+constexpr int kScanTile = 2048;   // 256 threads x 8 values
+
+__device__ __forceinline__ int64_t block_exclusive_scan_256(int64_t v, int64_t *s_wave, int64_t &block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int64_t off = 0;
+    for (int k = 0; k < wave; ++k) off += s_wave[k];
+    block_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return off + incl - v;
+}
+
+__global__ void __launch_bounds__(256) scan_tile_sums_kernel(const int64_t *__restrict__ in, int64_t n, int64_t *__restrict__ tile_sums) {
+    __shared__ int64_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 8;
+    int64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n) v += in[base + k];
+    int64_t total;
+    block_exclusive_scan_256(v, s_wave, total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) scan_spine_kernel(int64_t *__restrict__ tile_sums, int64_t n_tiles, int64_t *__restrict__ total_out) {
+    __shared__ int64_t s_wave[4];
+    __shared__ int64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_tiles; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < n_tiles ? tile_sums[i] : 0;
+        int64_t total;
+        const int64_t ex = block_exclusive_scan_256(v, s_wave, total);
+        if (i < n_tiles) tile_sums[i] = s_carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = s_carry;
+}
+
+__global__ void __launch_bounds__(256) scan_apply_kernel(const int64_t *__restrict__ in, int64_t n, const int64_t *__restrict__ tile_offsets,
+                                                         int64_t *__restrict__ out) {
+    __shared__ int64_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 8;
+    int64_t x[8], v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { x[k] = base + k < n ? in[base + k] : 0; v += x[k]; }
+    int64_t total;
+    int64_t run = tile_offsets[blockIdx.x] + block_exclusive_scan_256(v, s_wave, total);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += x[k]; }
+}
+
+// pack.py:10-38 for ray indices in ANY order: per-ray sample counts (the reference uses index_add_ of ones)
+__global__ void __launch_bounds__(256) count_per_ray_kernel(const int64_t *__restrict__ ray_indices, int64_t n, unsigned long long *__restrict__ cnts) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x)
+        atomicAdd(&cnts[ray_indices[i]], 1ull);
+}
+
+// [n_rays] starts + cnts -> interleaved [n_rays, 2] packed_info
+__global__ void __launch_bounds__(256) interleave2_kernel(const int64_t *__restrict__ a, const int64_t *__restrict__ b, int64_t n,
+                                                          int64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) {
+        out[2 * i] = a[i]; out[2 * i + 1] = b[i];
+    }
+}
+
+// ------------------------------------------------------------------ accumulate_along_rays (volrend.py:486-576), packed branch
+// outputs[ray] += w * v for samples in any order (float atomics, like the reference's index_add_), and its adjoint.
+__global__ void __launch_bounds__(256) accumulate_fwd_kernel(const float *__restrict__ w, const float *__restrict__ v, const int64_t *__restrict__ ri,
+                                                             int64_t n, int32_t D, float *__restrict__ out) {
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t k = i / D;
+        const int d = (int)(i - k * D);
+        atomicAdd(&out[ri[k] * D + d], v ? w[k] * v[i] : w[k]);
+    }
+}
+
+__global__ void __launch_bounds__(256) accumulate_bwd_kernel(const float *__restrict__ w, const float *__restrict__ v, const int64_t *__restrict__ ri,
+                                                             int64_t n, int32_t D, const float *__restrict__ g_out, float *__restrict__ g_w,
+                                                             float *__restrict__ g_v) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)blockDim.x * gridDim.x) {
+        const float *g = g_out + ri[k] * D;
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            acc += v ? g[d] * v[k * D + d] : g[d];
+            if (g_v) g_v[k * D + d] = w[k] * g[d];
+        }
+        if (g_w) g_w[k] = acc;
+    }
+}
+
 // ------------------------------------------------------------------ ray generation
 // habitat_to_data.py:274-301; arithmetic order pinned by tests/golden/raygen.npz (oracle/render.py).
 __global__ void __launch_bounds__(256) raygen_kernel(const float *__restrict__ c2w, int32_t n_views, int32_t width, int32_t height,
@@ -334,7 +439,7 @@ extern "C" int mnf_traverse_grids(const float *rays_o, const float *rays_d, cons
 extern "C" int mnf_sample_rays(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries, int32_t res_x,
                                int32_t res_y, int32_t res_z, const float *aabb_host, const float *near_planes, const float *far_planes,
                                float step_size, float cone_angle, int32_t cap, float *scratch_ts, float *scratch_te, int64_t *counts,
-                               mnf_stream_t stream) {
+                               const uint32_t *bitgrid, mnf_stream_t stream) {
     if (n_rays == 0) return MNF_OK;
     MNF_REQUIRE(rays_o && rays_d && binaries && aabb_host && near_planes && far_planes && scratch_ts && scratch_te && counts,
                 "sample_rays: null pointer");
@@ -345,10 +450,10 @@ extern "C" int mnf_sample_rays(const float *rays_o, const float *rays_d, int32_t
     const int grid = grid_for(n_rays, 256);
     if (lds)
         hipLaunchKernelGGL(sample_rays_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, ab[0],
-                           ab[1], ab[2], ab[3], ab[4], ab[5], near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts);
+                           ab[1], ab[2], ab[3], ab[4], ab[5], near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts, bitgrid);
     else
         hipLaunchKernelGGL(sample_rays_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, ab[0],
-                           ab[1], ab[2], ab[3], ab[4], ab[5], near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts);
+                           ab[1], ab[2], ab[3], ab[4], ab[5], near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts, bitgrid);
     return launch_status("sample_rays_kernel");
 }
 
@@ -388,6 +493,62 @@ extern "C" int mnf_run_bounds(const int64_t *ray_indices, int64_t n_samples, int
     hipLaunchKernelGGL(run_bounds_kernel, dim3(grid_for(n_samples, 256)), dim3(256), 0, as_stream(stream), ray_indices, n_samples,
                        first, last);
     return launch_status("run_bounds_kernel");
+}
+
+extern "C" int64_t mnf_scan_workspace_bytes(int64_t n) { return n < 0 ? -1 : (ceil_div(n > 0 ? n : 1, kScanTile) + 1) * (int64_t)sizeof(int64_t); }
+
+static int exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, int64_t *total, int64_t *tiles, hipStream_t s) {
+    const int64_t n_tiles = ceil_div(n, kScanTile);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, in, n, tiles);
+    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, s, tiles, n_tiles, total);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, in, n, tiles, out);
+    return launch_status("scan_apply_kernel");
+}
+
+extern "C" int mnf_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, int64_t *total_out, void *workspace, int64_t workspace_bytes,
+                                      mnf_stream_t stream) {
+    if (n == 0) {
+        if (total_out) MNF_HIP(hipMemsetAsync(total_out, 0, sizeof(int64_t), as_stream(stream)));
+        return MNF_OK;
+    }
+    MNF_REQUIRE(in && out && workspace && n > 0, "exclusive_scan_i64: bad arguments");
+    MNF_REQUIRE(workspace_bytes >= mnf_scan_workspace_bytes(n), "exclusive_scan_i64: workspace too small");
+    return exclusive_scan_i64(in, n, out, total_out, (int64_t *)workspace, as_stream(stream));
+}
+
+extern "C" int mnf_pack_info(const int64_t *ray_indices, int64_t n_samples, int64_t n_rays, int64_t *packed_info, void *workspace,
+                             int64_t workspace_bytes, mnf_stream_t stream) {
+    if (n_rays == 0) return MNF_OK;
+    MNF_REQUIRE(packed_info && workspace && n_rays > 0 && n_samples >= 0 && (ray_indices || n_samples == 0), "pack_info: bad arguments");
+    const int64_t need = 2 * n_rays * (int64_t)sizeof(int64_t) + mnf_scan_workspace_bytes(n_rays);
+    MNF_REQUIRE(workspace_bytes >= need, "pack_info: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)need);
+    hipStream_t s = as_stream(stream);
+    int64_t *cnts = (int64_t *)workspace, *starts = cnts + n_rays, *tiles = starts + n_rays;
+    MNF_HIP(hipMemsetAsync(cnts, 0, (size_t)n_rays * sizeof(int64_t), s));
+    if (n_samples) hipLaunchKernelGGL(count_per_ray_kernel, dim3(grid_for(n_samples, 256)), dim3(256), 0, s, ray_indices, n_samples, (unsigned long long *)cnts);
+    int rc = exclusive_scan_i64(cnts, n_rays, starts, nullptr, tiles, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(interleave2_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, starts, cnts, n_rays, packed_info);
+    return launch_status("interleave2_kernel");
+}
+
+extern "C" int mnf_accumulate_along_rays(const float *weights, const float *values, const int64_t *ray_indices, int64_t n_samples, int32_t dim,
+                                         float *outputs, mnf_stream_t stream) {
+    if (n_samples == 0) return MNF_OK;
+    MNF_REQUIRE(weights && ray_indices && outputs && dim >= 1, "accumulate_along_rays: bad arguments");
+    hipLaunchKernelGGL(accumulate_fwd_kernel, dim3(grid_for(n_samples * dim, 256)), dim3(256), 0, as_stream(stream), weights, values, ray_indices,
+                       n_samples, dim, outputs);
+    return launch_status("accumulate_fwd_kernel");
+}
+
+extern "C" int mnf_accumulate_along_rays_backward(const float *weights, const float *values, const int64_t *ray_indices, int64_t n_samples,
+                                                  int32_t dim, const float *grad_outputs, float *grad_weights, float *grad_values,
+                                                  mnf_stream_t stream) {
+    if (n_samples == 0) return MNF_OK;
+    MNF_REQUIRE(weights && ray_indices && grad_outputs && dim >= 1 && (values || !grad_values), "accumulate_along_rays_backward: bad arguments");
+    hipLaunchKernelGGL(accumulate_bwd_kernel, dim3(grid_for(n_samples, 256)), dim3(256), 0, as_stream(stream), weights, values, ray_indices,
+                       n_samples, dim, grad_outputs, grad_weights, grad_values);
+    return launch_status("accumulate_bwd_kernel");
 }
 
 extern "C" int mnf_generate_rays(const float *c2w, int32_t n_views, int32_t width, int32_t height, float focal,

@@ -446,8 +446,10 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     const int64_t cells = (int64_t)res_x * res_y * res_z;
     const int n_words = (int)ceil_div(cells, 32);
     const bool lds_grid = n_words <= kMaxGridWords;
-    if (lds_grid)
-        hipLaunchKernelGGL(pack_grid_kernel, dim3((int)ceil_div(n_words, 256)), dim3(256), 0, s, binaries, cells, ws.bitgrid, n_words);
+    if (lds_grid) {
+        if (opts->bitgrid) ws.bitgrid = const_cast<uint32_t *>(opts->bitgrid);   // the estimator's own packed grid: nothing to build
+        else hipLaunchKernelGGL(pack_grid_kernel, dim3((int)ceil_div(n_words, 256)), dim3(256), 0, s, binaries, cells, ws.bitgrid, n_words);
+    }
     MNF_HIP(hipMemsetAsync(sem, 0, (size_t)n_rays * C * sizeof(float), s));   // [R,C] accumulators: one streaming fill
     hipLaunchKernelGGL(init_kernel, dim3(ray_blocks), dim3(kRayThreads), 0, s, n_rays, opts->rays_per_view, C, rays_o, rays_d,
                        ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], opts->near_plane, ws, out);

@@ -151,27 +151,50 @@ def _enlarge_aabb(aabb, factor: float) -> Tensor:
 
 
 # ------------------------------------------------------------------ pack.py / scan.py / volrend.py
+def _scratch(device, nbytes: int) -> Tensor:
+    return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=device)
+
+
 @torch.no_grad()
 def pack_info(ray_indices: Tensor, n_rays: Optional[int] = None) -> Tensor:
+    """pack.py:10-38: [n_rays, 2] = (first sample, sample count) per ray, for ray indices in any order
+    (`mnf_pack_info`: atomic counts, then a device prefix sum)."""
     assert ray_indices.dim() == 1, "ray_indices must be a 1D tensor with shape (n_samples)."
     if not ray_indices.is_cuda:
-        raise NotImplementedError("Only support cuda inputs.")
+        raise NotImplementedError("Only support cuda inputs.")          # pack.py:48, same message
     if n_rays is None:
-        n_rays = ray_indices.max().item() + 1
-    cnts = torch.zeros((n_rays,), device=ray_indices.device, dtype=ray_indices.dtype)
-    cnts.index_add_(0, ray_indices, torch.ones_like(ray_indices))
-    starts = cnts.cumsum(dim=0, dtype=ray_indices.dtype) - cnts
-    return torch.stack([starts, cnts], dim=-1)
+        n_rays = int(ray_indices.max().item()) + 1
+    ri = L.contig(ray_indices, torch.int64)
+    out = torch.empty((n_rays, 2), dtype=torch.int64, device=ri.device)
+    lib = L.load_library()
+    nbytes = 16 * n_rays + lib.mnf_scan_workspace_bytes(n_rays)
+    ws = _scratch(ri.device, nbytes)
+    L.launch(lib.mnf_pack_info, L.ptr(ri), ri.shape[0], n_rays, L.ptr(out), L.ptr(ws), nbytes)
+    return out.to(ray_indices.dtype)
+
+
+def exclusive_scan_counts(counts: Tensor, want_total: bool = False):
+    """Chunk starts from chunk counts on the device (`RaySegmentsSpec::memalloc_data_from_chunk`, data_spec.hpp:86-96);
+    optionally also the grand total as a device scalar."""
+    counts = L.contig(counts, torch.int64)
+    n = counts.shape[0]
+    starts = torch.empty_like(counts)
+    total = torch.zeros((), dtype=torch.int64, device=counts.device) if want_total else None
+    lib = L.load_library()
+    nbytes = lib.mnf_scan_workspace_bytes(n)
+    ws = _scratch(counts.device, nbytes)
+    L.launch(lib.mnf_exclusive_scan_i64, L.ptr(counts), n, L.ptr(starts), L.ptr(total), L.ptr(ws), nbytes)
+    return (starts, total) if want_total else starts
 
 
 def pack_info_grouped(ray_indices: Tensor, n_rays: int) -> Tensor:
     """`pack_info` for ray indices grouped by ray (every output of `traverse_grids` / `sampling`, masked or not): same
-    [n_rays, 2] result, from run boundaries instead of an index_add over all samples."""
+    [n_rays, 2] result, from run boundaries instead of one atomic per sample."""
     ray_indices = ray_indices.contiguous()
     bounds = torch.zeros((2, n_rays), device=ray_indices.device, dtype=torch.int64)
     L.launch(L.load_library().mnf_run_bounds, L.ptr(ray_indices), ray_indices.shape[0], L.ptr(bounds[0]), L.ptr(bounds[1]))
     cnts = bounds[1] - bounds[0]
-    return torch.stack([cnts.cumsum(0) - cnts, cnts], dim=-1)
+    return torch.stack([exclusive_scan_counts(cnts), cnts], dim=-1)
 
 
 class _ExclusiveSum(torch.autograd.Function):
@@ -248,49 +271,88 @@ def render_visibility_from_density(t_starts, t_ends, sigmas, packed_info=None, r
     return vis
 
 
-def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
-                          n_rays: Optional[int] = None) -> Tensor:
-    if values is None:
-        src = weights[..., None]
-    else:
+class _Accumulate(torch.autograd.Function):
+    """Packed branch of volrend.py:486-576 on the HIP kernels: forward scatter-add, backward = the two products autograd
+    derives for `index_add_(0, ray_indices, weights[:, None] * values)`."""
+
+    @staticmethod
+    def forward(ctx, weights, values, ray_indices, outputs):
+        w = L.contig(weights, torch.float32)
+        v = None if values is None else L.contig(values, torch.float32)
+        ri = L.contig(ray_indices, torch.int64)
+        D = 1 if v is None else v.shape[-1]
+        L.launch(L.load_library().mnf_accumulate_along_rays, L.ptr(w), L.ptr(v), L.ptr(ri), w.shape[0], D, L.ptr(outputs))
+        ctx.save_for_backward(w, v if v is not None else w.new_empty(0), ri)
+        ctx.has_values, ctx.D = v is not None, D
+        ctx.mark_dirty(outputs)
+        return outputs
+
+    @staticmethod
+    def backward(ctx, g_out):
+        w, v, ri = ctx.saved_tensors
+        v = v if ctx.has_values else None
+        g_out = L.contig(g_out, torch.float32)
+        g_w = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+        g_v = torch.empty_like(v) if (v is not None and ctx.needs_input_grad[1]) else None
+        if g_w is not None or g_v is not None:
+            L.launch(L.load_library().mnf_accumulate_along_rays_backward, L.ptr(w), L.ptr(v), L.ptr(ri), w.shape[0], ctx.D,
+                     L.ptr(g_out), L.ptr(g_w), L.ptr(g_v))
+        return g_w, g_v, None, g_out
+
+
+def _check_accumulate_args(weights, values):
+    if values is not None:
         assert values.dim() == weights.dim() + 1
         assert weights.shape == values.shape[:-1]
-        src = weights[..., None] * values
-    if ray_indices is not None:
-        assert n_rays is not None, "n_rays must be provided"
-        assert weights.dim() == 1, "weights must be flattened"
-        outputs = torch.zeros((n_rays, src.shape[-1]), device=src.device, dtype=src.dtype)
-        outputs.index_add_(0, ray_indices, src)
-    else:
-        outputs = torch.sum(src, dim=-2)
-    return outputs
+
+
+def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                          n_rays: Optional[int] = None) -> Tensor:
+    """volrend.py:486-535 -> [n_rays, D] (packed samples) or [..., D] (batched samples)."""
+    _check_accumulate_args(weights, values)
+    if ray_indices is None:                                   # batched [..., S] samples: a plain sum over the sample axis
+        return weights.sum(dim=-1, keepdim=True) if values is None else (weights.unsqueeze(-1) * values).sum(dim=-2)
+    assert n_rays is not None, "n_rays must be provided"
+    assert weights.dim() == 1, "weights must be flattened"
+    L.require_gpu(weights, ray_indices)
+    D = 1 if values is None else values.shape[-1]
+    return _Accumulate.apply(weights, values, ray_indices, torch.zeros((n_rays, D), device=weights.device, dtype=torch.float32))
 
 
 def accumulate_along_rays_(weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
                            outputs: Optional[Tensor] = None) -> None:
-    if values is None:
-        src = weights[..., None]
-    else:
-        assert values.dim() == weights.dim() + 1
-        assert weights.shape == values.shape[:-1]
-        src = weights[..., None] * values
-    if ray_indices is not None:
-        assert weights.dim() == 1, "weights must be flattened"
-        assert outputs.dim() == 2 and outputs.shape[-1] == src.shape[-1], "outputs must be of shape (n_rays, D)"
-        outputs.index_add_(0, ray_indices, src)
-    else:
-        outputs.add_(src.sum(dim=-2))
+    """volrend.py:538-576: the in-place form (the test-time renderers' running accumulators)."""
+    _check_accumulate_args(weights, values)
+    D = 1 if values is None else values.shape[-1]
+    if ray_indices is None:
+        outputs.add_(weights.sum(dim=-1, keepdim=True) if values is None else (weights.unsqueeze(-1) * values).sum(dim=-2))
+        return
+    assert weights.dim() == 1, "weights must be flattened"
+    assert outputs.dim() == 2 and outputs.shape[-1] == D, "outputs must be of shape (n_rays, D)"
+    L.require_gpu(weights, ray_indices, outputs)
+    if outputs.dtype != torch.float32 or not outputs.is_contiguous():
+        raise L.MnfError("accumulate_along_rays_: outputs must be a contiguous float32 tensor")
+    _Accumulate.apply(weights, values, ray_indices, outputs)
 
 
 # ------------------------------------------------------------------ estimators/occ_grid.py
-def _meshgrid3d(res: Tensor, device: Union[torch.device, str] = "cpu") -> Tensor:
-    res = res.tolist()
-    return torch.stack(torch.meshgrid([torch.arange(res[0], dtype=torch.long), torch.arange(res[1], dtype=torch.long),
-                                       torch.arange(res[2], dtype=torch.long)], indexing="ij"), dim=-1).to(device)
+class FieldDensityOcc:
+    """The `occ_eval_fn` that scripts/pipeline.py:376-378 builds: `radiance_field.query_density(x) * render_step_size`.
+    Passing this object (instead of an opaque closure) lets `OccGridEstimator._update` run the whole refresh as ONE C call
+    (`mnf_update_occupancy`: cell pick, density query, EMA update and re-binarisation chained on the device)."""
+
+    def __init__(self, radiance_field, render_step_size: float):
+        self.field, self.scale = radiance_field, float(render_step_size)
+
+    def __call__(self, x):
+        return self.field.query_density(x) * self.scale
 
 
 class OccGridEstimator(torch.nn.Module):
-    """Occupancy-grid estimator, same buffers and methods as estimators/occ_grid.py:13-437."""
+    """Occupancy-grid estimator with the buffers and methods of estimators/occ_grid.py:13-437 (`resolution`, `aabbs`,
+    `occs`, `binaries`; `sampling`, `update_every_n_steps`, `mark_invisible_cells`, `_update`).  The grid refresh and the
+    marching run on the device kernels of csrc/occupancy.hip and csrc/march.hip; besides the reference's byte grid the
+    estimator keeps the bit-packed copy the marchers stage in LDS (`bitgrid()`)."""
 
     DIM: int = 3
 
@@ -298,28 +360,50 @@ class OccGridEstimator(torch.nn.Module):
                  levels: int = 1, **kwargs) -> None:
         super().__init__()
         if "contraction_type" in kwargs:
-            raise ValueError("`contraction_type` is not supported anymore for nerfacc >= 0.4.0.")
-        if isinstance(resolution, int):
-            resolution = [resolution] * self.DIM
-        if isinstance(resolution, (list, tuple)):
-            resolution = torch.tensor(resolution, dtype=torch.int32)
-        assert isinstance(resolution, Tensor), f"Invalid type: {resolution}!"
-        assert resolution.shape[0] == self.DIM, f"Invalid shape: {resolution}!"
-        if isinstance(roi_aabb, (list, tuple)):
-            roi_aabb = torch.tensor(roi_aabb, dtype=torch.float32)
-        assert isinstance(roi_aabb, Tensor), f"Invalid type: {roi_aabb}!"
-        assert roi_aabb.shape[0] == self.DIM * 2, f"Invalid shape: {roi_aabb}!"
-        roi_aabb = roi_aabb.detach().cpu().float()
-        aabbs = torch.stack([_enlarge_aabb(roi_aabb, 2 ** i) for i in range(levels)], dim=0)
-        self.cells_per_lvl = int(resolution.prod().item())
+            raise ValueError("`contraction_type` is not supported anymore for nerfacc >= 0.4.0.")   # occ_grid.py:34-37
+        res = resolution if isinstance(resolution, Tensor) else torch.tensor(
+            [resolution] * self.DIM if isinstance(resolution, int) else list(resolution), dtype=torch.int32)
+        box = roi_aabb if isinstance(roi_aabb, Tensor) else torch.tensor(list(roi_aabb), dtype=torch.float32)
+        assert res.shape[0] == self.DIM, f"Invalid shape: {res}!"
+        assert box.shape[0] == 2 * self.DIM, f"Invalid shape: {box}!"
+        box = box.detach().cpu().float()
         self.levels = levels
-        self.register_buffer("resolution", resolution)
-        self.register_buffer("aabbs", aabbs)
-        self.register_buffer("occs", torch.zeros(self.levels * self.cells_per_lvl))
-        self.register_buffer("binaries", torch.zeros([levels] + resolution.tolist(), dtype=torch.bool))
-        grid_coords = _meshgrid3d(resolution).reshape(self.cells_per_lvl, self.DIM)
-        self.register_buffer("grid_coords", grid_coords, persistent=False)
-        self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
+        self.cells_per_lvl = int(res.prod().item())
+        # level i covers the region of interest enlarged 2^i times about its centre (occ_grid.py:58-62)
+        self.register_buffer("resolution", res)
+        self.register_buffer("aabbs", torch.stack([_enlarge_aabb(box, 2 ** lvl) for lvl in range(levels)]))
+        self.register_buffer("occs", torch.zeros(levels * self.cells_per_lvl))
+        self.register_buffer("binaries", torch.zeros([levels] + [int(r) for r in res], dtype=torch.bool))
+        self._bits, self._bits_key, self._occ_ws = None, None, None
+
+    @property
+    def grid_coords(self) -> Tensor:
+        """[cells, 3] integer coordinates of the flat cell ids ('ij' order, z fastest: occ_grid.py:440-455); computed on
+        demand — the kernels derive them from the flat id."""
+        return self._cell_coords(torch.arange(self.cells_per_lvl, device=self.occs.device))
+
+    @property
+    def grid_indices(self) -> Tensor:
+        return torch.arange(self.cells_per_lvl, device=self.occs.device)
+
+    def _cell_coords(self, ids: Tensor) -> Tensor:
+        ry, rz = int(self.resolution[1]), int(self.resolution[2])
+        return torch.stack([ids // (ry * rz), (ids // rz) % ry, ids % rz], dim=-1)
+
+    def bitgrid(self) -> Tensor:
+        """int32 [levels, ceil(cells/32)]: bit (c & 31) of word (c >> 5) = binaries.flatten()[c] per level.  Maintained by
+        `_update`; rebuilt here whenever `binaries` was assigned or edited by someone else (viewer, checkpoint load)."""
+        b = self.binaries
+        L.require_gpu(b)
+        key = (b.data_ptr(), b._version, tuple(b.shape), str(b.device))
+        if self._bits_key != key:
+            bu = b.contiguous().view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8).contiguous()
+            words = (self.cells_per_lvl + 31) // 32
+            if self._bits is None or self._bits.device != b.device or self._bits.shape != (self.levels, words):
+                self._bits = torch.empty((self.levels, words), dtype=torch.int32, device=b.device)
+            L.launch(L.load_library().mnf_pack_bitgrid, L.ptr(bu), self.cells_per_lvl, self.levels, L.ptr(self._bits))
+            self._bits_key = key
+        return self._bits
 
     @property
     def device(self):
@@ -403,12 +487,11 @@ class OccGridEstimator(torch.nn.Module):
         lib = L.load_library()
         L.launch(lib.mnf_sample_rays, L.ptr(rays_o), L.ptr(rays_d), n, L.ptr(b), res[0], res[1], res[2], aabb_host, L.ptr(near_planes),
                                     L.ptr(far_planes), float(step_size), float(cone_angle), cap, L.ptr(scratch[0]), L.ptr(scratch[1]),
-                                    L.ptr(counts))
-        cum = counts.cumsum(0)
-        total, longest = (int(x) for x in torch.stack([cum[-1], counts.max()]).tolist())   # the one sync (data_spec.hpp:91 has it too)
+                                    L.ptr(counts), L.ptr(self.bitgrid()[0]))
+        starts, total_t = exclusive_scan_counts(counts, want_total=True)
+        total, longest = (int(x) for x in torch.stack([total_t, counts.max()]).tolist())   # the one sync (data_spec.hpp:91 has it too)
         if longest > cap:
             return None
-        starts = cum - counts
         t_starts, t_ends = torch.empty((total,), device=dev), torch.empty((total,), device=dev)
         ray_indices = torch.empty((total,), device=dev, dtype=torch.int64)
         if total:
@@ -426,28 +509,6 @@ class OccGridEstimator(torch.nn.Module):
             self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay, warmup_steps=warmup_steps)
 
     @torch.no_grad()
-    def _get_all_cells(self) -> List[Tensor]:
-        out = []
-        for lvl in range(self.levels):
-            cell_ids = lvl * self.cells_per_lvl + self.grid_indices
-            out.append(self.grid_indices[self.occs[cell_ids] >= 0.0])
-        return out
-
-    @torch.no_grad()
-    def _sample_uniform_and_occupied_cells(self, n: int) -> List[Tensor]:
-        out = []
-        for lvl in range(self.levels):
-            uniform_indices = torch.randint(self.cells_per_lvl, (n,), device=self.device)
-            cell_ids = lvl * self.cells_per_lvl + uniform_indices
-            uniform_indices = uniform_indices[self.occs[cell_ids] >= 0.0]
-            occupied_indices = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
-            if n < len(occupied_indices):
-                selector = torch.randint(len(occupied_indices), (n,), device=self.device)
-                occupied_indices = occupied_indices[selector]
-            out.append(torch.cat([uniform_indices, occupied_indices], dim=0))
-        return out
-
-    @torch.no_grad()
     def mark_invisible_cells(self, K: Tensor, c2w: Tensor, width: int, height: int, near_plane: float = 0.0,
                              chunk: int = 32 ** 3) -> None:
         """occ_grid.py:279-342: cells no camera sees (or that sit closer than near_plane to one) get occupancy -1 and are
@@ -457,11 +518,13 @@ class OccGridEstimator(torch.nn.Module):
         assert K.shape[0] == c2w.shape[0] or K.shape[0] == 1
         rot = c2w[:, :3, :3].transpose(2, 1)                      # world -> camera rotation, one per camera
         shift = -rot @ c2w[:, :3, 3:]
-        for lvl, cells in enumerate(self._get_all_cells()):
+        for lvl in range(self.levels):
+            lvl_occs = self.occs[lvl * self.cells_per_lvl:(lvl + 1) * self.cells_per_lvl]
+            cells = torch.nonzero(lvl_occs >= 0.0)[:, 0]                       # cells still eligible (occ_grid.py:328-343)
             lo, hi = self.aabbs[lvl, :3], self.aabbs[lvl, 3:]
             for begin in range(0, len(cells), chunk):
                 ids = cells[begin:begin + chunk]
-                unit = self.grid_coords[ids] / (self.resolution - 1)          # cell corner in [0, 1]^3
+                unit = self._cell_coords(ids) / (self.resolution - 1)         # cell corner in [0, 1]^3
                 world = (lo + unit * (hi - lo)).T                             # [3, n]
                 pix = K @ (rot @ world + shift)                                # [cams, 3, n]: (u*d, v*d, d)
                 depth = pix[:, 2]
@@ -473,22 +536,55 @@ class OccGridEstimator(torch.nn.Module):
 
     @torch.no_grad()
     def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
-                warmup_steps: int = 256) -> None:
-        """occ_grid.py:377-437 (EMA-max update with the fork's NaN roll-back)."""
-        if step < warmup_steps:
-            lvl_indices = self._get_all_cells()
+                warmup_steps: int = 256, _draws=None) -> None:
+        """occ_grid.py:377-437 on the device (csrc/occupancy.hip): cells and in-cell points are drawn by
+        `mnf_occ_sample_cells`, `occ_eval_fn` gives their occupancy, `mnf_occ_apply` does the EMA-max with the NaN
+        roll-back and `mnf_occ_binarize` re-thresholds into `binaries` and the bit grid — no boolean-mask compaction and
+        no host sync.  With `occ_eval_fn` a `FieldDensityOcc` the chain is one C call (`mnf_update_occupancy`).
+        `_draws` (tests): per level (cell ids int64 [n], offsets f32 [n,3]) in place of the device RNG, e.g. the draws
+        recorded from the reference in tests/golden/occgrid.npz.  The seed of the device RNG comes from torch's CPU
+        generator, so `torch.manual_seed` makes a run repeatable."""
+        import ctypes
+        L.require_gpu(self.occs, self.binaries)
+        lib, dev, cells = L.load_library(), self.occs.device, self.cells_per_lvl
+        if self.occs.dtype != torch.float32 or not self.occs.is_contiguous() or not self.binaries.is_contiguous():
+            raise L.MnfError("OccGridEstimator._update: occs must be contiguous float32 and binaries contiguous")
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        fused = isinstance(occ_eval_fn, FieldDensityOcc) and self.levels == 1 and _draws is None
+        nbytes = int(lib.mnf_occ_workspace_bytes(cells, 1 if fused else 0))
+        if self._occ_ws is None or self._occ_ws.device != dev or self._occ_ws.numel() < nbytes:
+            self._occ_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = self._occ_ws
+        res = [int(r) for r in self.resolution]
+        bin_u8 = self.binaries.view(torch.uint8) if self.binaries.dtype == torch.bool else self.binaries
+        bits = self.bitgrid()                                       # current before the refresh (the occupied half reads it)
+        if fused:
+            handle = occ_eval_fn.field._ensure_handle()
+            L.launch(lib.mnf_update_occupancy, handle, L.ptr(self.occs), L.ptr(bin_u8), L.ptr(bits), res[0], res[1], res[2],
+                     (ctypes.c_float * 6)(*self.aabb_host(0)), int(step), int(warmup_steps), float(occ_thre), float(ema_decay),
+                     float(occ_eval_fn.scale), seed, L.ptr(ws), nbytes)
         else:
-            lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
-        for lvl, indices in enumerate(lvl_indices):
-            grid_coords = self.grid_coords[indices]
-            x = (grid_coords + torch.rand_like(grid_coords, dtype=torch.float32)) / self.resolution
-            x = self.aabbs[lvl, :3] + x * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])
-            occs_backup = torch.clone(self.occs)
-            occ = occ_eval_fn(x).squeeze(-1)
-            cell_ids = lvl * self.cells_per_lvl + indices
-            self.occs[cell_ids] = torch.maximum(self.occs[cell_ids] * ema_decay, occ)
-            nan = torch.isnan(self.occs)
-            if nan.any():
-                self.occs[nan] = occs_backup[nan]
-        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
-        self.binaries = (self.occs > thre).view(self.binaries.shape)
+            for lvl in range(self.levels):
+                lvl_occs = self.occs[lvl * cells:(lvl + 1) * cells]
+                aabb = (ctypes.c_float * 6)(*self.aabb_host(lvl))
+                if _draws is not None:
+                    ids_in = L.contig(_draws[lvl][0].to(dev), torch.int64)
+                    jit_in = L.contig(_draws[lvl][1].to(dev), torch.float32)
+                    cap = n_in = ids_in.shape[0]
+                else:
+                    ids_in = jit_in = None
+                    n_in, cap = 0, int(lib.mnf_occ_list_capacity(cells, int(step), int(warmup_steps)))
+                ids = torch.empty((cap,), dtype=torch.int64, device=dev)
+                pts = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+                L.launch(lib.mnf_occ_sample_cells, L.ptr(lvl_occs), L.ptr(bits[lvl]), res[0], res[1], res[2], aabb, int(step),
+                         int(warmup_steps), seed + lvl, L.ptr(ids_in), L.ptr(jit_in), n_in, L.ptr(ids), L.ptr(pts), cap, L.ptr(ws), nbytes)
+                occ = L.contig(occ_eval_fn(pts).reshape(-1), torch.float32) if cap else pts.new_empty(0)
+                assert occ.shape[0] == cap, f"occ_eval_fn must return one value per point, got {tuple(occ.shape)} for {cap} points"
+                L.launch(lib.mnf_occ_apply, L.ptr(lvl_occs), L.ptr(ids), L.ptr(occ), 1.0, cap, cells, float(ema_decay), L.ptr(ws), nbytes)
+            L.launch(lib.mnf_occ_binarize, L.ptr(self.occs), cells, self.levels, float(occ_thre), L.ptr(bin_u8), L.ptr(bits), None,
+                     L.ptr(ws), nbytes)
+        # the kernels wrote occs / binaries / bits in place, outside autograd's view
+        torch.autograd.graph.increment_version(self.occs)
+        torch.autograd.graph.increment_version(self.binaries)
+        b = self.binaries
+        self._bits_key = (b.data_ptr(), b._version, tuple(b.shape), str(b.device))

@@ -91,7 +91,9 @@ def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_p
     order = None
     if image_hw is not None and image_hw[0] * image_hw[1] == rpv and min(image_hw) >= 16:
         order = _view_order(image_hw[0], image_hw[1], dev)
-    opts.view_order = L.ptr(order)
+    opts.view_order = None if order is None else order.data_ptr()
+    bits = estimator.bitgrid() if hasattr(estimator, "bitgrid") else None     # the estimator's packed grid (no per-call packing)
+    opts.bitgrid = None if bits is None else bits.data_ptr()
     rgb = torch.empty(n, 3, device=dev); acc = torch.empty(n, 1, device=dev); depth = torch.empty(n, 1, device=dev)
     sem = torch.empty(n, C, device=dev)
     rgb_var = torch.empty(n, 3, device=dev) if probabilistic else None
@@ -273,8 +275,7 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     radiance_field.train()
     estimator.train()
 
-    def occ_eval_fn(x):
-        return radiance_field.query_density(x) * render_step_size
+    occ_eval_fn = NA.FieldDensityOcc(radiance_field, render_step_size)     # pipeline.py:376-378; one fused C call per refresh
 
     estimator.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre)
     rgb, acc, depth, semantic, n_rendering_samples = render_image_with_occgrid_with_depth_guide(

@@ -70,12 +70,13 @@ int mnf_traverse_grids(const float *rays_o, const float *rays_d, const uint8_t *
 /* Single-pass form of the sampling traversal for one grid level (what `OccGridEstimator.sampling`,
  * occ_grid.py:80-238, needs from `traverse_grids`): every ray is marched ONCE; its samples (t_start, t_end) go to row r of
  * the caller's scratch [n_rays][cap] and counts[r] receives the ray's full sample count (rows are truncated at cap:
- * if any count exceeds cap the caller falls back to mnf_traverse_grids).  aabb_host: 6 host floats.  The t values are
- * those of mnf_traverse_grids, bit for bit. */
+ * if any count exceeds cap the caller falls back to mnf_traverse_grids).  aabb_host: 6 host floats.  bitgrid: optional
+ * bit-packed form of `binaries` (mnf_pack_bitgrid / mnf_occ_binarize; NULL = packed from the bytes by every workgroup).
+ * The t values are those of mnf_traverse_grids, bit for bit. */
 int mnf_sample_rays(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries, int32_t res_x,
                     int32_t res_y, int32_t res_z, const float *aabb_host, const float *near_planes, const float *far_planes,
                     float step_size, float cone_angle, int32_t cap, float *scratch_ts, float *scratch_te, int64_t *counts,
-                    mnf_stream_t stream);
+                    const uint32_t *bitgrid, mnf_stream_t stream);
 
 /* Pack the scratch rows: samples of ray r go to [chunk_starts[r], chunk_starts[r] + counts[r]) of t_starts / t_ends /
  * ray_indices (chunk_starts = exclusive prefix of counts, `RaySegmentsSpec::memalloc_data_from_chunk`, data_spec.hpp:86-96). */
@@ -127,6 +128,57 @@ int mnf_adam_step(float *params, const float *grads, float *exp_avg, float *exp_
 
 /* Adds the number of NaN entries of `values` to *count (device int32): the gradient guard of pipeline.py:520-529. */
 int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf_stream_t stream);
+
+/* `pack_info` (nerfacc/pack.py:10-38) for ray indices in any order: packed_info [n_rays,2] = (chunk start, chunk count).
+ * workspace: 2*n_rays*8 + mnf_scan_workspace_bytes(n_rays) bytes. */
+int64_t mnf_scan_workspace_bytes(int64_t n);
+int mnf_pack_info(const int64_t *ray_indices, int64_t n_samples, int64_t n_rays, int64_t *packed_info, void *workspace,
+                  int64_t workspace_bytes, mnf_stream_t stream);
+/* Exclusive prefix sum of int64 counts (chunk starts of `RaySegmentsSpec::memalloc_data_from_chunk`,
+ * include/data_spec.hpp:86-96); total_out (device, optional) receives the grand total. */
+int mnf_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, int64_t *total_out, void *workspace, int64_t workspace_bytes,
+                           mnf_stream_t stream);
+
+/* `accumulate_along_rays` / `accumulate_along_rays_` with ray_indices (nerfacc/volrend.py:486-576): outputs [n_rays,dim]
+ * (caller-initialised) += weights[k] * values[k,:] at row ray_indices[k]; values NULL = weights alone (dim 1).
+ * The backward gives what autograd derives for the reference's index_add_: grad_weights [n] and grad_values [n,dim]
+ * (either may be NULL) from grad_outputs [n_rays,dim]. */
+int mnf_accumulate_along_rays(const float *weights, const float *values, const int64_t *ray_indices, int64_t n_samples, int32_t dim,
+                              float *outputs, mnf_stream_t stream);
+int mnf_accumulate_along_rays_backward(const float *weights, const float *values, const int64_t *ray_indices, int64_t n_samples,
+                                       int32_t dim, const float *grad_outputs, float *grad_weights, float *grad_values,
+                                       mnf_stream_t stream);
+
+/* ---------------------------------------------------------------- occupancy-grid refresh
+ * `OccGridEstimator._update` (nerfacc/estimators/occ_grid.py:345-437) without host round trips.  A refresh of one level is
+ *   mnf_occ_sample_cells -> (density of the points: occ_eval_fn) -> mnf_occ_apply, then mnf_occ_binarize over all levels;
+ * mnf_update_occupancy does the whole chain for one level with the field's own density kernel as occ_eval_fn
+ * (scripts/pipeline.py:376-378: query_density(x) * render_step_size).
+ * The sample list has a fixed capacity (mnf_occ_list_capacity: every cell during warm-up, 2 * (cells / 4) afterwards);
+ * unused slots hold cell index -1 and a point inside the box.  Draws: Philox4x32-10, counter (element, 0, kind, step),
+ * key = seed, kind 0 uniform / 1 occupied / 2 warm-up; word 0 -> cell, words 1..3 -> in-cell offsets (24-bit).  Tests
+ * pass the reference's recorded draws instead (indices_in, jitter_in [n_in,3]).  Duplicate cells: the last list element
+ * wins.  workspace: mnf_occ_workspace_bytes(cells, fused), the same buffer for sample and apply of one refresh. */
+int64_t mnf_occ_workspace_bytes(int64_t cells_per_level, int32_t fused);
+int64_t mnf_occ_list_capacity(int64_t cells_per_level, int32_t step, int32_t warmup_steps);
+/* binaries [levels, cells] u8 -> bitgrid [levels, ceil(cells/32)] (bit c & 31 of word c >> 5) */
+int mnf_pack_bitgrid(const uint8_t *binaries, int64_t cells_per_level, int32_t levels, uint32_t *bitgrid, mnf_stream_t stream);
+int mnf_occ_sample_cells(const float *occs, const uint32_t *bitgrid, int32_t res_x, int32_t res_y, int32_t res_z,
+                         const float *aabb_host, int32_t step, int32_t warmup_steps, uint64_t seed,
+                         const int64_t *indices_in, const float *jitter_in, int64_t n_in,
+                         int64_t *cell_idx, float *points, int64_t capacity, void *workspace, int64_t workspace_bytes,
+                         mnf_stream_t stream);
+/* occs[cell] = max(occs[cell] * ema_decay, values[e] * value_scale), NaN candidates leave the cell unchanged (occ_grid.py:403-434) */
+int mnf_occ_apply(float *occs, const int64_t *cell_idx, const float *values, float value_scale, int64_t n, int64_t cells_per_level,
+                  float ema_decay, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
+/* thre = min(mean(occs[occs >= 0]), occ_thre); binaries = occs > thre as bytes and as bits (occ_grid.py:436-437);
+ * threshold_out (device float, optional) receives thre */
+int mnf_occ_binarize(const float *occs, int64_t cells_per_level, int32_t levels, float occ_thre, uint8_t *binaries,
+                     uint32_t *bitgrid, float *threshold_out, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
+int mnf_update_occupancy(mnf_field_t f, float *occs, uint8_t *binaries, uint32_t *bitgrid, int32_t res_x, int32_t res_y,
+                         int32_t res_z, const float *aabb_host, int32_t step, int32_t warmup_steps, float occ_thre,
+                         float ema_decay, float density_scale, uint64_t seed, void *workspace, int64_t workspace_bytes,
+                         mnf_stream_t stream);
 
 /* ---------------------------------------------------------------- ray generation */
 
@@ -223,6 +275,8 @@ typedef struct {
                                 are per ray and do not depend on it; rays that are neighbours in the image should be
                                 neighbours in this order (e.g. 8x8 pixel blocks instead of one-pixel-high strips) so that
                                 a tile's samples share hash-table lines. */
+    const uint32_t *bitgrid; /* optional (NULL = packed from `binaries` at the start of the call): the bit-packed form of
+                                `binaries` that mnf_occ_binarize / mnf_pack_bitgrid maintain (bit c & 31 of word c >> 5) */
 } mnf_render_opts;
 
 /* bytes of workspace mnf_render_test needs for n_rays rays */

@@ -470,6 +470,22 @@ def test_render_batched_views_equal_single_calls(scene, fields):
         for key in ("rgb", "acc", "depth", "sem"):
             np.testing.assert_allclose(ragged[key][k * 150:(k + 1) * 150].cpu().numpy(), single[key].cpu().numpy(),
                                        rtol=2e-6, atol=1e-7, err_msg=key)
+    # views with very different per-ray budgets side by side (a nearly dead view runs at 64 samples per ray while its
+    # neighbours run at 4): 12 views x 256 rays, every third view keeps only 4 rays that hit the grid.  A march workgroup
+    # must not stretch the neighbours' column slots to the dying view's budget (the workspace is sized for per-view budgets).
+    ov, dv = [], []
+    for k in range(12):
+        ok, dk = (t.clone() for t in H.view_rays(scene, k % 8, h=16, w=16))
+        if k % 3 == 1:
+            ok[4:] = 100.0; dk[4:] = torch.tensor([0.0, 1.0, 0.0])
+        ov.append(ok); dv.append(dk)
+    ov, dv = torch.cat(ov).to(DEV), torch.cat(dv).to(DEV)
+    mixed = RD.render_views(hip, est, ov, dv, 256, 1024, render_bkgd=bk, **H.RENDER_KW)
+    for k in (0, 1, 2, 10):
+        single = RD.render_views(hip, est, ov[k * 256:(k + 1) * 256], dv[k * 256:(k + 1) * 256], 256, 1024, render_bkgd=bk, **H.RENDER_KW)
+        for key in ("rgb", "acc", "depth", "sem"):
+            np.testing.assert_allclose(mixed[key][k * 256:(k + 1) * 256].cpu().numpy(), single[key].cpu().numpy(),
+                                       rtol=2e-6, atol=1e-7, err_msg=f"mixed budgets, view {k}, {key}")
     # rays that miss the grid entirely: zero opacity, background colour, no samples
     far_o = torch.full((64, 3), 100.0, device=DEV)
     far_d = torch.tensor([[0.0, 1.0, 0.0]], device=DEV).repeat(64, 1)
@@ -787,3 +803,143 @@ def test_full_resolution_render_properties():
     np.testing.assert_allclose(a["rgb"][idx].cpu().numpy(), ref["rgb"].numpy(), atol=2e-3)
     np.testing.assert_allclose(a["depth"][idx].cpu().numpy(), ref["depth"].numpy(), atol=5e-3, rtol=2e-3)
     np.testing.assert_allclose(a["sem"][idx].cpu().numpy(), ref["sem"].numpy(), atol=2e-3)
+
+
+# ------------------------------------------------------------------ occupancy refresh on the device (a5)
+def _golden_draws(g, k, occs, binaries, cells):
+    """cell list + offsets of golden step k, derived from the reference's recorded RNG draws exactly as
+    occ_grid.py:328-375 derives them from the state before the step"""
+    step = int(g[f"s{k}_step"])
+    draws = [g[[n for n in g.files if n.startswith(f"s{k}_draw{j}_")][0]] for j in range(int(g[f"s{k}_ndraws"]))]
+    if step < 256:
+        return step, np.arange(cells)[occs >= 0], draws[0]
+    uni = draws[0]
+    uni = uni[occs[uni] >= 0]
+    occupied = np.nonzero(binaries)[0]
+    if cells // 4 < len(occupied):
+        return step, np.concatenate([uni, occupied[draws[1]]]), draws[2]
+    return step, np.concatenate([uni, occupied]), draws[1]
+
+
+def test_occupancy_update_golden_trajectory(golden):
+    """`OccGridEstimator._update` (csrc/occupancy.hip) driven with the reference's recorded draws reproduces the
+    reference's own trajectory (tests/golden/occgrid.npz: five updates, two of them warm-up): occs to 2e-5 relative
+    (occ_eval_fn uses sin / cos, evaluated by torch on the GPU here and on the CPU in the golden), binaries bit-exact for
+    every cell whose occupancy is not within that tolerance of the threshold, and the bit-packed grid equal to the bytes."""
+    from apnrf_amd.nerfacc import OccGridEstimator
+    g = golden("occgrid")
+    res = g["resolution"].tolist()
+    cells = int(np.prod(res))
+    est = OccGridEstimator(torch.from_numpy(g["roi_aabb"]), resolution=res, levels=1).to(DEV).train()
+
+    def occ_eval_fn(x):
+        return (torch.sin(x[:, :1] * 1.3) * torch.cos(x[:, 2:3] * 0.7) + 0.2 * x[:, 1:2]).clamp_min(0) * 0.02
+
+    occs, binaries = np.zeros(cells, np.float32), np.zeros(cells, bool)
+    for k in range(5):
+        step, idx, jit = _golden_draws(g, k, occs, binaries, cells)
+        est._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=1e-2, _draws=[(torch.from_numpy(idx), torch.from_numpy(jit))])
+        want_occs, want_bin = g[f"s{k}_occs"], g[f"s{k}_binaries"].reshape(-1)
+        got_occs, got_bin = est.occs.cpu().numpy(), est.binaries.cpu().numpy().reshape(-1)
+        np.testing.assert_allclose(got_occs, want_occs, rtol=2e-5, atol=1e-9, err_msg=f"step {step}")
+        thre = min(float(want_occs[want_occs >= 0].mean()), 1e-2)
+        clear = np.abs(want_occs - thre) > 2e-5 * max(thre, 1e-6) + 1e-9
+        np.testing.assert_array_equal(got_bin[clear], want_bin[clear], err_msg=f"step {step}")
+        assert clear.mean() > 0.99 and 0 < want_bin.sum() < cells
+        bits = est.bitgrid().cpu().numpy().view(np.uint32).reshape(-1)
+        unpacked = ((bits[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1)[:cells].astype(bool)
+        np.testing.assert_array_equal(unpacked, got_bin)
+        occs, binaries = want_occs, want_bin          # the next step's draws were made from the reference's own state
+        est.occs.copy_(torch.from_numpy(want_occs)); est.binaries = torch.from_numpy(g[f"s{k}_binaries"]).to(DEV)
+
+
+def test_occupancy_update_device_rng_and_fused_path(scene):
+    """The production path: cells and offsets from the device Philox stream.  Properties that do not depend on the draws:
+    warm-up touches every cell once (occs == max(0 * decay, density * step) of a point inside the cell); afterwards only
+    listed cells change, the uniform half lands on ~N distinct cells, every occupied cell is re-evaluated while there are
+    fewer than N of them, the same seed reproduces the update bit for bit, and the single-call fused form
+    (mnf_update_occupancy) equals the three-call form with the same seed."""
+    from apnrf_amd.nerfacc import FieldDensityOcc, OccGridEstimator
+    hip = H.hip_field(scene)
+    step_size = 1e-3
+    res, cells = scene["res"], int(np.prod(scene["res"]))
+
+    def fresh():
+        return OccGridEstimator(torch.from_numpy(scene["aabb"]), resolution=res, levels=1).to(DEV).train()
+
+    closure = lambda x: hip.query_density(x) * step_size
+    a, b, c = fresh(), fresh(), fresh()
+    for est, fn in ((a, closure), (b, closure), (c, FieldDensityOcc(hip, step_size))):
+        torch.manual_seed(11)
+        est._update(step=0, occ_eval_fn=fn, occ_thre=1e-3)
+    assert torch.equal(a.occs, b.occs) and torch.equal(a.binaries, b.binaries)            # repeatable under torch.manual_seed
+    assert torch.equal(a.occs, c.occs) and torch.equal(a.binaries, c.binaries)            # fused == three calls
+    occ0 = a.occs.cpu().numpy()
+    assert (occ0 > 0).all()                                                               # every cell was evaluated (density > 0 inside the box)
+    thre = min(float(occ0.mean()), 1e-3)
+    np.testing.assert_array_equal(a.binaries.cpu().numpy().reshape(-1), occ0 > np.float32(thre))
+    # each warm-up value is the density of SOME point inside its own cell: compare with the cell's density range on a 3x3x3 lattice
+    ids = np.random.default_rng(0).integers(0, cells, 200)
+    X, Y, Z = res
+    coords = np.stack([ids // (Y * Z), (ids // Z) % Y, ids % Z], -1).astype(np.float32)
+    lat = np.stack(np.meshgrid(*[np.linspace(0.02, 0.98, 5)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    pts = scene["aabb"][:3] + (coords[:, None, :] + lat[None]) / np.asarray(res, np.float32) * (scene["aabb"][3:] - scene["aabb"][:3])
+    dens = hip.query_density(_cu(pts.reshape(-1, 3))).cpu().numpy().reshape(200, -1) * step_size
+    inside_range = (occ0[ids] >= dens.min(1) * 0.5) & (occ0[ids] <= dens.max(1) * 2.0)
+    assert inside_range.mean() > 0.9
+    # after the warm-up: N uniform + occupied cells
+    a.occs.mul_(0.5)                                  # so that a re-evaluated cell visibly changes (max(0.475 old, new) != old)
+    before = a.occs.clone()
+    n_occ = int(a.binaries.sum())
+    torch.manual_seed(12)
+    a._update(step=256, occ_eval_fn=closure, occ_thre=1e-3)
+    changed = (a.occs != before).cpu().numpy()
+    N = cells // 4
+    expect_uniform = cells * (1 - np.exp(-N / cells))                                    # distinct cells of N draws with replacement
+    occupied_before = b.binaries.cpu().numpy().reshape(-1)
+    if n_occ <= N:
+        assert changed[occupied_before].all()                                            # every occupied cell re-evaluated
+    assert 0.8 * expect_uniform < changed.sum() <= N + min(n_occ, N)
+    assert not torch.isnan(a.occs).any()
+    # NaN candidates leave the cell unchanged (the fork's roll-back, occ_grid.py:409-434)
+    before = a.occs.clone()
+    a._update(step=272, occ_eval_fn=lambda x: torch.full((x.shape[0], 1), float("nan"), device=x.device), occ_thre=1e-3)
+    assert torch.equal(a.occs, before)
+
+
+def test_pack_info_and_accumulate_kernels():
+    """`pack_info` for ungrouped ray indices (pack.py:10-38) and the packed `accumulate_along_rays[_]` with its
+    gradients (volrend.py:486-576) against the reference's definition evaluated by torch on the CPU."""
+    from apnrf_amd import nerfacc as NA
+    rng = np.random.default_rng(8)
+    n_rays, n = 5000, 60000
+    ri = rng.integers(0, n_rays, n)
+    ri[ri % 11 == 0] = 7                                        # empty rays and one heavy ray
+    cnts = np.bincount(ri, minlength=n_rays)
+    want = np.stack([np.cumsum(cnts) - cnts, cnts], -1)
+    np.testing.assert_array_equal(NA.pack_info(_cu(ri), n_rays).cpu().numpy(), want)
+    np.testing.assert_array_equal(NA.pack_info(_cu(np.sort(ri)), n_rays).cpu().numpy(), want)
+    np.testing.assert_array_equal(NA.exclusive_scan_counts(_cu(cnts)).cpu().numpy(), want[:, 0])
+    big = rng.integers(0, 1000, 300001)                         # several scan tiles and a ragged tail
+    st, tot = NA.exclusive_scan_counts(_cu(big), want_total=True)
+    np.testing.assert_array_equal(st.cpu().numpy(), np.cumsum(big) - big)
+    assert int(tot) == int(big.sum())
+    for D in (1, 3, 29):
+        w = rng.random(n).astype(np.float32)
+        v = rng.normal(size=(n, D)).astype(np.float32)
+        g = rng.normal(size=(n_rays, D)).astype(np.float32)
+        cw, cv = torch.from_numpy(w).requires_grad_(True), torch.from_numpy(v).requires_grad_(True)
+        ref = torch.zeros(n_rays, D).index_add_(0, torch.from_numpy(ri), cw[:, None] * cv)
+        ref.backward(torch.from_numpy(g))
+        hw, hv = _cu(w).requires_grad_(True), _cu(v).requires_grad_(True)
+        out = NA.accumulate_along_rays(hw, hv, _cu(ri), n_rays)
+        out.backward(_cu(g))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(hw.grad.cpu().numpy(), cw.grad.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(hv.grad.cpu().numpy(), cv.grad.numpy(), rtol=1e-5, atol=1e-6)
+    acc = torch.ones(n_rays, 1, device=DEV)
+    NA.accumulate_along_rays_(_cu(w), None, _cu(ri), acc)
+    np.testing.assert_allclose(acc.cpu().numpy()[:, 0], 1.0 + np.bincount(ri, w, n_rays), rtol=1e-4, atol=1e-4)
+    # batched branch (no ray indices): plain sums, as the reference
+    wb, vb = torch.rand(4, 7, device=DEV), torch.rand(4, 7, 3, device=DEV)
+    np.testing.assert_allclose(NA.accumulate_along_rays(wb, vb).cpu().numpy(), (wb[..., None] * vb).sum(-2).cpu().numpy(), rtol=1e-6)
