@@ -21,6 +21,11 @@ class FieldConfig(ctypes.Structure):
                 ("log2_hashmap_size", c_int32), ("base_resolution", c_int32), ("max_resolution", c_int32)]
 
 
+class VanillaConfig(ctypes.Structure):
+    _fields_ = [("net_depth", c_int32), ("net_width", c_int32), ("skip_layer", c_int32), ("net_depth_condition", c_int32),
+                ("net_width_condition", c_int32)]
+
+
 class RenderOpts(ctypes.Structure):
     _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float),
                 ("cone_angle", c_float), ("alpha_thre", c_float), ("early_stop_eps", c_float),
@@ -79,6 +84,15 @@ SIGNATURES = {
     "mnf_field_density": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_field_forward_samples": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_vanilla_create": (c_int32, [POINTER(VanillaConfig), POINTER(c_void_p)]),
+    "mnf_vanilla_destroy": (c_int32, [c_void_p]),
+    "mnf_vanilla_param_count": (c_int64, [c_void_p]),
+    "mnf_vanilla_param_layout_host": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_vanilla_set_params": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "mnf_vanilla_train_workspace_bytes": (c_int64, [c_void_p, c_int64]),
+    "mnf_vanilla_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_vanilla_density": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mnf_vanilla_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_field_train_workspace_bytes": (c_int64, [c_void_p, c_int64]),
     "mnf_field_forward_train": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_field_backward": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -21,6 +21,7 @@ SOURCES = {
     "train.hip": [],
     "composite_train.hip": [],
     "occupancy.hip": ["-ffp-contract=off"],
+    "vanilla.hip": [],
 }
 
 

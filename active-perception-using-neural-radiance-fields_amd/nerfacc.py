@@ -335,6 +335,81 @@ def accumulate_along_rays_(weights: Tensor, values: Optional[Tensor] = None, ray
     _Accumulate.apply(weights, values, ray_indices, outputs)
 
 
+# ------------------------------------------------------------------ fused compositing (utils.py:362-461, volrend.py:20-161)
+class _CompositeTrain(torch.autograd.Function):
+    """Semantic volume rendering of packed samples after the field query (perception/models/utils.py:362-461; also
+    `rendering`, volrend.py:20-161, with zero classes): weights (volrend.py:213-267), the accumulate_along_rays sums,
+    background blend and depth normalisation as one HIP launch, with a hand-written adjoint in place of the autograd
+    graph the reference records (csrc/composite_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, bkgd):
+        dev, R, N, C = sigmas.device, chunk_cnts.shape[0], sigmas.shape[0], sems.shape[-1]
+        t_starts, t_ends = t_starts.contiguous().float(), t_ends.contiguous().float()
+        sigmas, rgbs, sems = sigmas.contiguous().float(), rgbs.contiguous().float(), sems.contiguous().float()
+        colors, semantics = torch.empty((R, 3), device=dev), torch.empty((R, C), device=dev)
+        opacities, depths = torch.empty((R, 1), device=dev), torch.empty((R, 1), device=dev)
+        weights, trans, alphas = torch.empty((N,), device=dev), torch.empty((N,), device=dev), torch.empty((N,), device=dev)
+        L.launch(L.load_library().mnf_composite_train_forward, 
+            L.ptr(chunk_starts), L.ptr(chunk_cnts), R, L.ptr(t_starts), L.ptr(t_ends), L.ptr(sigmas), L.ptr(rgbs), L.ptr(sems), C, N,
+            L.ptr(bkgd), L.ptr(colors), L.ptr(opacities), L.ptr(depths), L.ptr(semantics), L.ptr(weights), L.ptr(trans),
+            L.ptr(alphas))
+        ctx.save_for_backward(chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, weights, trans, opacities, depths)
+        ctx.bkgd = bkgd
+        ctx.mark_non_differentiable(weights, trans, alphas)
+        return colors, opacities, depths, semantics, weights, trans, alphas
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_acc, g_dep, g_sem, _gw, _gt, _ga):
+        chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, weights, trans, opacities, depths = ctx.saved_tensors
+        R, N, C = chunk_cnts.shape[0], sigmas.shape[0], sems.shape[-1]
+        d_sig, d_rgb, d_sem = torch.empty_like(sigmas), torch.empty_like(rgbs), torch.empty_like(sems)
+        g = [None if t is None else t.contiguous().float() for t in (g_rgb, g_acc, g_dep, g_sem)]
+        L.launch(L.load_library().mnf_composite_train_backward, 
+            L.ptr(chunk_starts), L.ptr(chunk_cnts), R, L.ptr(t_starts), L.ptr(t_ends), L.ptr(sigmas), L.ptr(rgbs), L.ptr(sems), C, N,
+            L.ptr(ctx.bkgd), L.ptr(weights), L.ptr(trans), L.ptr(opacities), L.ptr(depths), L.ptr(g[0]), L.ptr(g[1]), L.ptr(g[2]),
+            L.ptr(g[3]), L.ptr(d_sig), L.ptr(d_rgb), L.ptr(d_sem))
+        return None, None, None, None, d_sig, d_rgb, d_sem, None
+
+
+def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Optional[Tensor] = None, n_rays: Optional[int] = None,
+              rgb_sigma_fn: Optional[Callable] = None, rgb_alpha_fn: Optional[Callable] = None,
+              render_bkgd: Optional[Tensor] = None):
+    """volrend.py:20-161 -> (colors [R,3], opacities [R,1], depths [R,1], extras), differentiable with respect to what
+    `rgb_sigma_fn` returns.  Batched [R,S] samples (the BASELINE config-1 path) and packed samples grouped by ray both go
+    through the fused compositing kernel; `rgb_alpha_fn` is not reachable from scripts/pipeline.py."""
+    if ray_indices is not None:
+        assert t_starts.shape == t_ends.shape == ray_indices.shape, \
+            "Since nerfacc 0.5.0, t_starts, t_ends and ray_indices must have the same shape (N,). "
+    if rgb_sigma_fn is None and rgb_alpha_fn is None:
+        raise ValueError("At least one of `rgb_sigma_fn` and `rgb_alpha_fn` should be specified.")
+    if rgb_sigma_fn is None:
+        raise NotImplementedError("rendering(rgb_alpha_fn=...) is outside the hot path (pipeline.py only renders from densities)")
+    L.require_gpu(t_starts, t_ends)
+    dev = t_starts.device
+    if t_starts.shape[0] != 0:
+        rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
+    else:
+        rgbs, sigmas = torch.empty((0, 3), device=dev), torch.empty((0,), device=dev)
+    assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
+    assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+    if ray_indices is None:                      # [R,S]: ray r owns the S consecutive samples r*S ..
+        R, S = t_starts.shape
+        starts = torch.arange(R, device=dev, dtype=torch.int64) * S
+        cnts = torch.full((R,), S, device=dev, dtype=torch.int64)
+    else:
+        assert n_rays is not None, "n_rays must be provided"
+        packed = pack_info_grouped(ray_indices, n_rays)
+        starts, cnts = packed[:, 0].contiguous(), packed[:, 1].contiguous()
+    bk = None if render_bkgd is None else render_bkgd.to(device=dev, dtype=torch.float32).reshape(3).contiguous()
+    flat = sigmas.reshape(-1)
+    colors, opacities, depths, _, weights, trans, alphas = _CompositeTrain.apply(
+        starts, cnts, t_starts.reshape(-1), t_ends.reshape(-1), flat, rgbs.reshape(-1, 3), flat.new_empty((flat.shape[0], 0)), bk)
+    shape = t_starts.shape
+    extras = {"weights": weights.view(shape), "alphas": alphas.view(shape), "trans": trans.view(shape), "sigmas": sigmas, "rgbs": rgbs}
+    return colors, opacities, depths, extras
+
+
 # ------------------------------------------------------------------ estimators/occ_grid.py
 class FieldDensityOcc:
     """The `occ_eval_fn` that scripts/pipeline.py:376-378 builds: `radiance_field.query_density(x) * render_step_size`.

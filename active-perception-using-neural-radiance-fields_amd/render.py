@@ -157,39 +157,7 @@ def render_views(radiance_field, estimator, rays_o, rays_d, rays_per_view, max_s
 
 
 # ------------------------------------------------------------------ train-mode forward (utils.py:63-219, :362-461)
-class _CompositeTrain(torch.autograd.Function):
-    """utils.py:362-461 after the field query: weights (volrend.py:213-267), the four accumulate_along_rays
-    (volrend.py:27-66), background blend and depth normalisation as one HIP launch, with a hand-written adjoint in place
-    of the autograd graph the reference records (csrc/composite_train.hip)."""
-
-    @staticmethod
-    def forward(ctx, chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, bkgd):
-        dev, R, N, C = sigmas.device, chunk_cnts.shape[0], sigmas.shape[0], sems.shape[-1]
-        t_starts, t_ends = t_starts.contiguous().float(), t_ends.contiguous().float()
-        sigmas, rgbs, sems = sigmas.contiguous().float(), rgbs.contiguous().float(), sems.contiguous().float()
-        colors, semantics = torch.empty((R, 3), device=dev), torch.empty((R, C), device=dev)
-        opacities, depths = torch.empty((R, 1), device=dev), torch.empty((R, 1), device=dev)
-        weights, trans, alphas = torch.empty((N,), device=dev), torch.empty((N,), device=dev), torch.empty((N,), device=dev)
-        L.launch(L.load_library().mnf_composite_train_forward, 
-            L.ptr(chunk_starts), L.ptr(chunk_cnts), R, L.ptr(t_starts), L.ptr(t_ends), L.ptr(sigmas), L.ptr(rgbs), L.ptr(sems), C, N,
-            L.ptr(bkgd), L.ptr(colors), L.ptr(opacities), L.ptr(depths), L.ptr(semantics), L.ptr(weights), L.ptr(trans),
-            L.ptr(alphas))
-        ctx.save_for_backward(chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, weights, trans, opacities, depths)
-        ctx.bkgd = bkgd
-        ctx.mark_non_differentiable(weights, trans, alphas)
-        return colors, opacities, depths, semantics, weights, trans, alphas
-
-    @staticmethod
-    def backward(ctx, g_rgb, g_acc, g_dep, g_sem, _gw, _gt, _ga):
-        chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, weights, trans, opacities, depths = ctx.saved_tensors
-        R, N, C = chunk_cnts.shape[0], sigmas.shape[0], sems.shape[-1]
-        d_sig, d_rgb, d_sem = torch.empty_like(sigmas), torch.empty_like(rgbs), torch.empty_like(sems)
-        g = [None if t is None else t.contiguous().float() for t in (g_rgb, g_acc, g_dep, g_sem)]
-        L.launch(L.load_library().mnf_composite_train_backward, 
-            L.ptr(chunk_starts), L.ptr(chunk_cnts), R, L.ptr(t_starts), L.ptr(t_ends), L.ptr(sigmas), L.ptr(rgbs), L.ptr(sems), C, N,
-            L.ptr(ctx.bkgd), L.ptr(weights), L.ptr(trans), L.ptr(opacities), L.ptr(depths), L.ptr(g[0]), L.ptr(g[1]), L.ptr(g[2]),
-            L.ptr(g[3]), L.ptr(d_sig), L.ptr(d_rgb), L.ptr(d_sem))
-        return None, None, None, None, d_sig, d_rgb, d_sem, None
+_CompositeTrain = NA._CompositeTrain     # csrc/composite_train.hip behind autograd (defined next to `rendering`)
 
 
 def sem_rendering(radiance_field, rays: Rays, t_starts, t_ends, ray_indices, n_rays, render_bkgd=None):

@@ -231,6 +231,43 @@ int mnf_field_forward_samples(mnf_field_t f, const float *rays_o, const float *r
                               const int64_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                               float *rgb, float *density, float *sem, mnf_stream_t stream);
 
+/* ---------------------------------------------------------------- frequency-encoded MLP field (BASELINE config 1)
+ * perception/models/radiance_fields/mlp.py: `VanillaNeRFRadianceField` (:206-245) = `SinusoidalEncoder` (:168-203, 10 degrees
+ * on positions, 4 on directions, identity included) + `NerfMLP` (:113-165) of biased Linear + ReLU layers (:14-101), in
+ * exact fp32 on the matrix cores.  Parameters cross the boundary as ONE flat fp32 vector in the order of the reference's
+ * `named_parameters()`: per Linear its weight [out][in] then its bias — base hidden layers, sigma layer, bottleneck layer,
+ * rgb hidden layers, rgb output layer (mnf_vanilla_param_layout_host lists the tensors). */
+typedef struct mnf_vanilla_s *mnf_vanilla_t;
+typedef struct {
+    int32_t net_depth;            /* mlp.py:209 */
+    int32_t net_width;            /* mlp.py:210 (multiple of 32) */
+    int32_t skip_layer;           /* mlp.py:211; <= 0 = None */
+    int32_t net_depth_condition;  /* mlp.py:212 (>= 1) */
+    int32_t net_width_condition;  /* mlp.py:213 (multiple of 32) */
+} mnf_vanilla_config;
+int mnf_vanilla_create(const mnf_vanilla_config *cfg, mnf_vanilla_t *out);
+int mnf_vanilla_destroy(mnf_vanilla_t v);
+int64_t mnf_vanilla_param_count(mnf_vanilla_t v);
+/* offsets / rows / cols of the parameter tensors inside the flat vector, in named_parameters() order (host arrays of
+ * max_tensors entries; *n_tensors_host receives the count) */
+int mnf_vanilla_param_layout_host(mnf_vanilla_t v, int32_t max_tensors, int32_t *n_tensors_host, int64_t *offsets_host,
+                                  int32_t *rows_host, int32_t *cols_host);
+int mnf_vanilla_set_params(mnf_vanilla_t v, const float *flat_params, mnf_stream_t stream);
+int64_t mnf_vanilla_train_workspace_bytes(mnf_vanilla_t v, int64_t n);
+/* VanillaNeRFRadianceField.forward (mlp.py:238-243): positions [n,3]; directions [ceil(n / samples_per_direction),3] (the
+ * reference broadcasts a per-ray condition over the ray's samples, mlp.py:154-160; 1 = one direction per sample);
+ * rgb [n,3] = sigmoid, sigma [n] = relu.  workspace non-NULL (mnf_vanilla_train_workspace_bytes) keeps the activations for
+ * mnf_vanilla_backward. */
+int mnf_vanilla_forward(mnf_vanilla_t v, const float *positions, const float *directions, int64_t n,
+                        int32_t samples_per_direction, float *rgb, float *sigma, void *workspace, int64_t workspace_bytes,
+                        mnf_stream_t stream);
+/* VanillaNeRFRadianceField.query_density (mlp.py:233-236) */
+int mnf_vanilla_density(mnf_vanilla_t v, const float *positions, int64_t n, float *sigma, mnf_stream_t stream);
+/* gradients of all parameters (flat, overwritten) from dL/d(rgb) [n,3] and dL/d(sigma) [n]; rgb / sigma are the forward
+ * outputs, workspace the one the forward filled */
+int mnf_vanilla_backward(mnf_vanilla_t v, const float *d_rgb, const float *d_sigma, const float *rgb, const float *sigma,
+                         int64_t n, void *workspace, int64_t workspace_bytes, float *grad_flat, mnf_stream_t stream);
+
 /* ---------------------------------------------------------------- training: differentiable field
  * What `loss.backward()` reaches inside tiny-cuda-nn in the reference (scripts/pipeline.py:518): the forward
  * that keeps activations and the backward to the flat parameter vectors.  Compositing, the loss and the optimizer

@@ -943,3 +943,101 @@ def test_pack_info_and_accumulate_kernels():
     # batched branch (no ray indices): plain sums, as the reference
     wb, vb = torch.rand(4, 7, device=DEV), torch.rand(4, 7, 3, device=DEV)
     np.testing.assert_allclose(NA.accumulate_along_rays(wb, vb).cpu().numpy(), (wb[..., None] * vb).sum(-2).cpu().numpy(), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ a20: frequency-PE + biased-MLP field, pinned to the reference's own outputs
+def _vanilla_from_golden(g, **kw):
+    from apnrf_amd.mlp import VanillaNeRFRadianceField
+    field = VanillaNeRFRadianceField(**kw)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    field.load_state_dict(sd, strict=True)                        # same keys as the reference's state_dict
+    return field.to(DEV)
+
+
+def test_vanilla_field_matches_reference_golden(golden):
+    """BASELINE config 1 end to end on the HIP path against tests/golden/vanilla.npz, which was captured from the
+    reference's own `VanillaNeRFRadianceField` + `nerfacc.rendering` (CPU, fp32): 64x64 rays x 32 samples, forward values,
+    the smooth-L1 loss and the gradient of EVERY parameter.  Tolerance 1e-5 (fp32 on both sides; only the summation order
+    and the last ulp of sin / exp differ)."""
+    import torch.nn.functional as F
+    from apnrf_amd import nerfacc as NA
+    g = golden("vanilla")
+    field = _vanilla_from_golden(g, net_depth=2, net_width=64, skip_layer=None, net_depth_condition=1, net_width_condition=64)
+    # the encoder alone (mlp.py:184-203), through the first layer's saved inputs: enc(x) rows are what the kernel feeds the MLP
+    rays_o, rays_d = _cu(g["rays_o"]), _cu(g["rays_d"])
+    edges = _cu(g["t_edges"])
+    R, S = rays_o.shape[0], edges.shape[0] - 1
+    t_starts, t_ends = edges[:-1].expand(R, S).contiguous(), edges[1:].expand(R, S).contiguous()
+
+    def rgb_sigma_fn(ts, te, ri):
+        pos = rays_o[:, None, :] + rays_d[:, None, :] * ((ts + te) / 2.0)[..., None]
+        rgb, sigma = field(pos, rays_d)                           # [R,S,3] positions, [R,3] condition (mlp.py:154-160 broadcast)
+        return rgb, sigma.squeeze(-1)
+
+    colors, opac, depths, extras = NA.rendering(t_starts, t_ends, rgb_sigma_fn=rgb_sigma_fn, render_bkgd=torch.zeros(3, device=DEV))
+    np.testing.assert_allclose(colors.detach().cpu().numpy(), g["colors"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(opac.detach().cpu().numpy(), g["opacities"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(depths.detach().cpu().numpy(), g["depths"], atol=1e-5, rtol=1e-5)
+    loss = F.smooth_l1_loss(colors, _cu(g["target"]))
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
+    loss.backward()
+    for name, p in field.named_parameters():
+        want = g["grad." + name]
+        got = p.grad.cpu().numpy()
+        assert got.shape == want.shape, name
+        # 1e-5 of the gradient's scale per tensor (the loss is a mean over 12 288 values: the gradients themselves are ~1e-3)
+        np.testing.assert_allclose(got, want, atol=1e-5 * max(float(np.abs(want).max()), 1e-30) + 1e-9, rtol=1e-4, err_msg=name)
+        assert np.abs(want).max() > 0, name
+    # inference path (no autograd) and query_density agree with the training forward
+    with torch.no_grad():
+        pos = rays_o[:, None, :] + rays_d[:, None, :] * ((t_starts + t_ends) / 2.0)[..., None]
+        rgb2, sig2 = field(pos, rays_d)
+        rgb3, sig3 = field(pos[:100], rays_d[:100, None, :].expand(100, S, 3))      # per-sample condition form
+    np.testing.assert_array_equal(sig2.squeeze(-1).cpu().numpy(), extras["sigmas"].detach().cpu().numpy())
+    np.testing.assert_array_equal(rgb3.cpu().numpy(), rgb2[:100].cpu().numpy())
+    np.testing.assert_array_equal(field.query_density(pos).cpu().numpy(), sig2.cpu().numpy())
+
+
+def test_vanilla_field_general_shapes_match_cpu_autograd():
+    """The reference's default-like shape family (skip connection, deeper condition MLP, ragged sample count) against the
+    same network evaluated by plain torch on the CPU (the definition in mlp.py:86-101, :153-165, :184-203, :238-243)."""
+    from apnrf_amd.mlp import VanillaNeRFRadianceField
+    torch.manual_seed(3)
+    for kw in (dict(net_depth=6, net_width=64, skip_layer=4, net_depth_condition=2, net_width_condition=32),
+               dict(net_depth=1, net_width=128, skip_layer=None, net_depth_condition=1, net_width_condition=64)):
+        field = VanillaNeRFRadianceField(**kw)
+        for p in field.parameters():
+            if p.dim() == 1:
+                torch.nn.init.uniform_(p, -0.1, 0.1)              # non-zero biases
+        n = 1000 + 13
+        x, d = torch.randn(n, 3) * 1.5, torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+        g_rgb, g_sig = torch.randn(n, 3), torch.randn(n, 1)
+        cpu = {k: v.detach().clone().requires_grad_(True) for k, v in field.named_parameters()}
+
+        def enc(v, deg):
+            xb = (v[:, None, :] * torch.tensor([2.0 ** i for i in range(deg)])[:, None]).reshape(v.shape[0], -1)
+            return torch.cat([v, torch.sin(torch.cat([xb, xb + 0.5 * np.pi], -1))], -1)
+
+        def lin(h, name):
+            return h @ cpu[name + ".weight"].t() + cpu[name + ".bias"]
+
+        e = enc(x, 10)
+        h = e
+        for i in range(kw["net_depth"]):
+            h = torch.relu(lin(h, f"mlp.base.hidden_layers.{i}"))
+            if kw["skip_layer"] is not None and i % kw["skip_layer"] == 0 and i > 0:
+                h = torch.cat([h, e], -1)
+        raw_sigma = lin(h, "mlp.sigma_layer.output_layer")
+        z = torch.cat([lin(h, "mlp.bottleneck_layer.output_layer"), enc(d, 4)], -1)
+        for i in range(kw["net_depth_condition"]):
+            z = torch.relu(lin(z, f"mlp.rgb_layer.hidden_layers.{i}"))
+        r_rgb, r_sig = torch.sigmoid(lin(z, "mlp.rgb_layer.output_layer")), torch.relu(raw_sigma)
+        torch.autograd.backward([r_rgb, r_sig], [g_rgb, g_sig])
+        field = field.to(DEV)
+        rgb, sig = field(x.to(DEV), d.to(DEV))
+        torch.autograd.backward([rgb, sig], [g_rgb.to(DEV), g_sig.to(DEV)])
+        np.testing.assert_allclose(rgb.detach().cpu().numpy(), r_rgb.detach().numpy(), atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(sig.detach().cpu().numpy(), r_sig.detach().numpy(), atol=2e-6, rtol=1e-5)
+        for name, p in field.named_parameters():
+            want = cpu[name].grad.numpy()
+            np.testing.assert_allclose(p.grad.cpu().numpy(), want, atol=2e-5 * float(np.abs(want).max()) + 1e-9, rtol=1e-4, err_msg=name)

@@ -83,3 +83,19 @@ def test_mark_invisible_cells_known_answer(golden):
     gold = golden("occgrid")
     assert int((g.occs == -1).sum()) == 77660 == int(gold["mark_invisible_neg1"])
     assert int((g.occs == 0).sum()) == 53412 == int(gold["mark_invisible_zero"])
+
+
+def test_vanilla_field_state_dict_matches_reference(golden):
+    """The frequency-PE MLP mirror holds its parameters under the reference's own state_dict keys and shapes
+    (tests/golden/vanilla.npz was captured from the reference module), in `named_parameters()` order."""
+    from apnrf_amd.mlp import VanillaNeRFRadianceField
+    g = golden("vanilla")
+    f = VanillaNeRFRadianceField(net_depth=2, net_width=64, skip_layer=None, net_depth_condition=1, net_width_condition=64)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    f.load_state_dict(sd, strict=True)
+    assert [n for n, _ in f.named_parameters()] == [k[5:] for k in g.files if k.startswith("grad.")]
+    assert sum(p.numel() for p in f.parameters()) == 18564          # SURVEY 8a row a20
+    with pytest.raises(L.MnfError):
+        f(torch.zeros(4, 3), torch.zeros(4, 3))                     # no CPU fallback
+    dflt = VanillaNeRFRadianceField()                                # reference defaults: depth 8, width 256, skip 4
+    assert dflt.mlp.base.hidden_layers[5].in_features == 256 + 63 and dflt.mlp.rgb_layer.hidden_layers[0].in_features == 256 + 27
