@@ -104,6 +104,7 @@ SIGNATURES = {
     "mnf_planner_map": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mnf_profile_begin": (c_int32, []),
     "mnf_profile_end": (c_int32, [POINTER(c_double), POINTER(c_int64)]),
+    "mnf_profile_query": (c_int32, [c_char_p, POINTER(c_double), POINTER(c_int64)]),
     "mnf_score_views": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
 }
 

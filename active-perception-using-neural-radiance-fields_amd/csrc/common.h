@@ -42,4 +42,14 @@ inline hipStream_t as_stream(mnf_stream_t s) { return reinterpret_cast<hipStream
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// per-kernel timing for bench.py (api.cpp): a no-op unless mnf_profile_begin() was called on this thread
+bool prof_on();
+int prof_start(const char *label, hipStream_t s);
+void prof_stop(int id, hipStream_t s);
+struct ProfScope {
+    int id; hipStream_t s;
+    ProfScope(const char *label, hipStream_t stream) : id(prof_start(label, stream)), s(stream) {}
+    ~ProfScope() { prof_stop(id, s); }
+};
+
 }  // namespace mnf

@@ -192,6 +192,7 @@ extern "C" int mnf_composite_train_forward(const int64_t *chunk_starts, const in
                 "composite_train_forward: null pointer");
     MNF_REQUIRE(n_samples == 0 || (t_starts && t_ends && sigmas && rgbs && weights && (sems || n_classes == 0)),
                 "composite_train_forward: null sample pointer");
+    ProfScope ps("composite_train_forward", as_stream(stream));
     hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_rays), dim3(64), lds_bytes(n_classes), as_stream(stream), chunk_starts,
                        chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, n_classes, bkgd, out_rgb, out_acc, out_depth, out_sem,
                        weights, trans, alphas);
@@ -211,6 +212,7 @@ extern "C" int mnf_composite_train_backward(const int64_t *chunk_starts, const i
     MNF_REQUIRE(chunk_starts && chunk_cnts && t_starts && t_ends && sigmas && rgbs && weights && trans && out_acc && out_depth &&
                     d_sigmas && d_rgbs && ((sems && d_sems) || n_classes == 0),
                 "composite_train_backward: null pointer");
+    ProfScope ps("composite_train_backward", as_stream(stream));
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_rays), dim3(64), lds_bytes(n_classes), as_stream(stream), chunk_starts,
                        chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, n_classes, bkgd, weights, trans, out_acc, out_depth, g_rgb, g_acc,
                        g_depth, g_sem, d_sigmas, d_rgbs, d_sems);

@@ -560,6 +560,7 @@ int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_
         if (wgs < grid) grid = (int)wgs;
     }
     const int W = f->cfg.neurons, NH = f->cfg.layers;
+    ProfScope ps(io.mode == 2 ? nullptr : (train ? "field_train_forward" : (density_only ? "field_density" : "field_forward")), stream);   // mode 2: timed by its caller
 #define MNF_CASE(w, nh) if (W == w && NH == nh) return launch_variant<w, nh>(f, io, density_only, grid, stream, train)
 #ifdef MNF_DEV_ONLY_128x2
     MNF_CASE(128, 2);

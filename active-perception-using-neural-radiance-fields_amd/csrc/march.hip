@@ -446,6 +446,7 @@ extern "C" int mnf_sample_rays(const float *rays_o, const float *rays_d, int32_t
     MNF_REQUIRE(res_x > 0 && res_y > 0 && res_z > 0 && cap > 0 && step_size > 0.f, "sample_rays: bad sizes");
     const I3 res = {res_x, res_y, res_z};
     const float *ab = aabb_host;
+    ProfScope ps("sample_rays", as_stream(stream));
     const bool lds = (int64_t)res_x * res_y * res_z <= (int64_t)kSamplerGridWords * 32;
     const int grid = grid_for(n_rays, 256);
     if (lds)

@@ -360,51 +360,9 @@ __global__ void __launch_bounds__(256) score_kernel(const float *__restrict__ rg
     }
 }
 
-// ------------------------------------------------------------------ optional field-kernel timing (bench.py roofline)
-struct Profile {
-    bool on = false;
-    std::vector<hipEvent_t> ev;   // pairs: start, stop
-    size_t used = 0;
-};
-static thread_local Profile g_prof;
-
-static void profile_mark(hipStream_t s, bool start) {
-    if (!g_prof.on) return;
-    if (g_prof.used == g_prof.ev.size()) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return;
-        g_prof.ev.push_back(e);
-    }
-    (void)start;
-    (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
-}
-
 }  // namespace mnf
 
 using namespace mnf;
-
-extern "C" int mnf_profile_begin(void) {
-    g_prof.on = true;
-    g_prof.used = 0;
-    return MNF_OK;
-}
-
-extern "C" int mnf_profile_end(double *field_ms_host, int64_t *launches_host) {
-    g_prof.on = false;
-    double ms = 0.0;
-    int64_t n = 0;
-    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-        MNF_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
-        float t = 0.f;
-        MNF_HIP(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
-        ms += t;
-        ++n;
-    }
-    g_prof.used = 0;
-    if (field_ms_host) *field_ms_host = ms;
-    if (launches_host) *launches_host = n;
-    return MNF_OK;
-}
 
 extern "C" int64_t mnf_render_workspace_bytes(int64_t n_rays, int32_t rays_per_view) {
     if (n_rays <= 0 || rays_per_view <= 0 || n_rays % rays_per_view) return -1;
@@ -491,9 +449,10 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
             hipLaunchKernelGGL(round_march_kernel<false>, dim3(march_grid), dim3(kMarchThreads), 0, s, n_rays,
                                opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
                                opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order, bpv);
-        profile_mark(s, true);
-        rc = launch_field(f, io, false, s);   // field evaluation + compositing + ray retirement of this round
-        profile_mark(s, false);
+        {
+            ProfScope ps("field_render", s);
+            rc = launch_field(f, io, false, s);   // field evaluation + compositing + ray retirement of this round
+        }
         if (rc) return rc;
     }
     hipLaunchKernelGGL(finalize_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,

@@ -48,6 +48,10 @@ struct BwdArgs {
     TrainBuf train;
 };
 
+// fp32 -> fp16 with saturation at the largest finite half: a loss-scaled gradient that leaves the fp16 range is clipped
+// instead of becoming Inf (which would poison every weight gradient of the step)
+__device__ __forceinline__ half_t sat_half(float v) { return (half_t)(v != v ? v : fminf(fmaxf(v, -65504.0f), 65504.0f)); }   // NaN stays NaN
+
 // acc[ct] = sum_ks A(rt, ks) * b[ct][ks] for one 32-row tile
 template <int KS>
 __device__ __forceinline__ void dense_tile(const half8 *__restrict__ w_lds, int lane, const half8 (&b)[CT][KS], f32x16 (&acc)[CT]) {
@@ -120,7 +124,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float y = args.rgb[3 * col + k];
-                    dyr[ct][0][k] = (half_t)(args.d_rgb[3 * col + k] * y * (1.0f - y) * ls);   // sigmoid'
+                    dyr[ct][0][k] = sat_half(args.d_rgb[3 * col + k] * y * (1.0f - y) * ls);   // sigmoid'
                 }
             }
 #pragma unroll
@@ -128,7 +132,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int row = 16 * s + 8 * h + j;
-                    dys[ct][s][j] = (ok && row < args.C) ? (half_t)(args.d_sem[col * args.C + row] * ls) : (half_t)0.0f;
+                    dys[ct][s][j] = (ok && row < args.C) ? sat_half(args.d_sem[col * args.C + row] * ls) : (half_t)0.0f;
                 }
             // trunc_exp backward (ngp.py:34-39): g * exp(min(x, 15)) with exp(x) = sigma (0 outside the aabb)
             dlogit[ct] = ok ? args.d_sigma[col] * fminf(args.sigma[col], 3269017.3724721107f) * ls : 0.0f;
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
         for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) dbo[ct][0][j] = (half_t)(dgeo_r[ct][j] + dgeo_s[ct][j]);
-            if (h == 0) dbo[ct][0][0] = (half_t)dlogit[ct];
+            if (h == 0) dbo[ct][0][0] = sat_half(dlogit[ct]);
             save_rows<true>(args.train, tile, T::rdBO, so[ct], dbo[ct][0]);
         }
         // ---- base MLP ----
@@ -616,7 +620,9 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
 
 __global__ void __launch_bounds__(256) count_nan_kernel(const float *__restrict__ g, int64_t n, int32_t *__restrict__ count) {
     int local = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) local += g[i] != g[i];
+    // NaN as the reference's guard (pipeline.py:520-529), and +-Inf as well: an overflowed fp16 activation gradient shows up
+    // as Inf, which Adam would turn into NaN parameters one step later
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) local += !(fabsf(g[i]) <= 3.4028234664e38f);
     if (__ballot(local != 0) != 0ull && local) atomicAdd(count, local);
 }
 
@@ -722,6 +728,7 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     if (wgs < grid) grid = (int)wgs;
     const int W = f->cfg.neurons, NH = f->cfg.layers;
     bool ok = false;
+    const int prof_dgrad = prof_start("dgrad", s);
 #define MNF_CASE(w, nh) if (W == w && NH == nh) { launch_dgrad<w, nh>(a, grid, s); ok = true; }
 #ifdef MNF_DEV_ONLY_128x2
     MNF_CASE(128, 2)
@@ -730,6 +737,7 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     MNF_CASE(64, 1) MNF_CASE(64, 2) MNF_CASE(64, 3) MNF_CASE(64, 4)
 #endif
 #undef MNF_CASE
+    prof_stop(prof_dgrad, s);
     MNF_REQUIRE(ok, "field_backward: unsupported shape");
     rc = launch_status("dgrad_kernel");
     if (rc) return rc;
@@ -741,8 +749,11 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     int split = (int)(256 * 12 / n_groups);
     if (split > n_tiles / 16) split = (int)(n_tiles / 16);
     if (split < 1) split = 1;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * split, 4)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
-                       split, v.act, n_tiles, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem);
+    {
+        ProfScope ps("wgrad", s);
+        hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * split, 4)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
+                           split, v.act, n_tiles, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem);
+    }
     rc = launch_status("wgrad_kernel");
     if (rc) return rc;
     // hash-table gradient
@@ -766,6 +777,7 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     hb.repl = reinterpret_cast<float *>(v.act);
     const size_t repl_bytes = (size_t)kReplicas * hb.repl_floats * sizeof(float);
     if ((size_t)ts->tt.rows * v.Np * 2 < repl_bytes) { hb.repl_levels = 0; hb.repl_floats = 0; }
+    const int prof_scatter = prof_start("hash_scatter", s);
     if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.repl, 0, repl_bytes, s));
     static const bool simple = getenv("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane, corner and feature
     if (simple) hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, s, hb);
@@ -774,6 +786,7 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     if (rc) return rc;
     if (hb.repl_levels)
         hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, s, hb.repl, hb.repl_floats, hb.g_table);
+    prof_stop(prof_scatter, s);
     return launch_status("fold_replicas_kernel");
 }
 

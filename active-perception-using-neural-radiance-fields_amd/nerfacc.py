@@ -519,6 +519,7 @@ class OccGridEstimator(torch.nn.Module):
             t_ends = intervals.vals[intervals.is_right]
             ray_indices = samples.ray_indices
             packed_info = samples.packed_info
+        self.last_sampling = {"n_marched": int(t_starts.shape[0])}     # samples the density pre-pass sees (measurement only)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             alpha_thre = min(alpha_thre, self.occs.mean().item())
             if sigma_fn is not None:

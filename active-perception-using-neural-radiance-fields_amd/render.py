@@ -399,7 +399,7 @@ def score_views(radiance_fields, estimators, poses, width, height, focal, near_p
     poses = np.asarray(poses)
     V = poses.shape[0]
     world, rank = 1, 0
-    if dist.is_available() and dist.is_initialized():
+    if group is not False and dist.is_available() and dist.is_initialized():       # group=False: all views on this rank, no exchange
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi, per = shard_views(V, world, rank)
     terms_local = torch.zeros(per, 4, dtype=torch.float64, device=device)
@@ -413,5 +413,5 @@ def score_views(radiance_fields, estimators, poses, width, height, focal, near_p
             rv.append(r["rgb_var"].reshape(n, h * w, 3)); dv.append(r["depth_var"].reshape(n, h * w))
             ac.append(r["acc"].reshape(n, h * w)); sm.append(r["sem"].reshape(n, h * w, -1))
         terms_local[:n] = score_view_terms(torch.stack(rv), torch.stack(dv), torch.stack(ac), torch.stack(sm))
-    terms = gather_view_terms(terms_local, V, group)
+    terms = terms_local[:V] if group is False else gather_view_terms(terms_local, V, group)
     return terms, trajectory_score(terms)

@@ -1,0 +1,137 @@
+"""Trained stand-in scenes for measurement: there are no Habitat captures or checkpoints on the GPU box,
+so bench.py trains the field itself — `render.train_step` (the product path) for a few thousand iterations on an ANALYTIC
+target built from the procedural "rooms" occupancy grid of `synthetic.py`:
+
+    density   opaque (sigma ~ 50 / m: termination ~2 cm behind the first occupied cell a ray meets)
+    colour    fract(xyz) at the termination point
+    class     hash of the 0.2 m cell there, mod 29
+    depth     distance to the termination point
+
+The result has what a trained scene has and a random initialisation lacks: empty space is empty, surfaces are opaque,
+the occupancy grid comes out of `OccGridEstimator.update_every_n_steps`, and rays terminate after tens of samples.
+Weights and grid are cached under `cache_dir` so that repeated bench invocations on one box train once.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import nerfacc as NA
+from . import render as RD
+from . import synthetic as S
+
+
+def _procedural_estimator(scene, device):
+    """The target geometry: the procedural grid with its outer faces closed (a Habitat apartment has no open sides: every
+    ray ends on a surface, so no target has zero opacity)."""
+    occ = scene["occ"].copy()
+    occ[:, 0, :, :] = occ[:, -1, :, :] = True
+    occ[:, :, :, 0] = occ[:, :, :, -1] = True
+    est = NA.OccGridEstimator(torch.from_numpy(scene["aabb"]), resolution=scene["res"], levels=1)
+    est.binaries = torch.from_numpy(occ)
+    return est.to(device).eval()
+
+
+@torch.no_grad()
+def analytic_targets(proc_est, aabb, rays_o, rays_d, near=0.1, step=1e-3, cone=0.004):
+    """First occupied cell along every ray of the PROCEDURAL grid (the library's own marcher) -> (pixels [R,3], depth [R],
+    label [R] int64); rays that leave the box without meeting an occupied cell get black / depth 0 / class 0."""
+    n = rays_o.shape[0]
+    nearp = torch.full((n,), near, device=rays_o.device)
+    farp = torch.full((n,), 1e10, device=rays_o.device)
+    packed = proc_est._sample_single_pass(rays_o, rays_d, nearp, farp, step, cone)
+    if packed is None:
+        iv, sm, _ = NA.traverse_grids(rays_o, rays_d, proc_est.binaries, proc_est.aabbs, near_planes=nearp, far_planes=farp,
+                                      step_size=step, cone_angle=cone)
+        ts, info = iv.vals[iv.is_left], sm.packed_info
+    else:
+        _, ts, _, info = packed
+    hit = info[:, 1] > 0
+    first = info[:, 0].clamp(max=max(ts.shape[0] - 1, 0))
+    t_hit = torch.where(hit, ts[first] if ts.shape[0] else torch.zeros_like(nearp), torch.zeros_like(nearp)) + 0.02
+    p = rays_o + rays_d * t_hit[:, None]
+    pixels = torch.where(hit[:, None], p - torch.floor(p), torch.zeros_like(p))
+    a = torch.as_tensor(aabb, device=p.device, dtype=torch.float32)
+    cell = torch.floor((p - a[:3]) / 0.2).to(torch.int64)
+    label = ((cell[:, 0] * 73856093) ^ (cell[:, 1] * 19349663) ^ (cell[:, 2] * 83492791)) % 29
+    return pixels, torch.where(hit, t_hit, torch.zeros_like(t_hit)), torch.where(hit, label, torch.zeros_like(label))
+
+
+def _free_space_poses(scene, n, seed):
+    """n camera poses (xyz + quaternion xyzw) at eye height inside free cells of the procedural grid, random yaw."""
+    rng = np.random.default_rng(seed)
+    occ, a = scene["occ"][0], scene["aabb"]
+    X, Y, Z = occ.shape
+    y_eye = min(int((1.5 - a[1]) / 0.2), Y - 2)
+    free = np.argwhere(~occ[:, y_eye, :])
+    # keep cells whose 3x3 neighbourhood is free too (the camera is not inside a wall's first sample)
+    ok = [c for c in free if 1 <= c[0] < X - 1 and 1 <= c[1] < Z - 1 and not occ[c[0] - 1:c[0] + 2, y_eye, c[1] - 1:c[1] + 2].any()]
+    pick = rng.choice(len(ok), size=n, replace=len(ok) < n)
+    out = np.zeros((n, 7))
+    for i, k in enumerate(pick):
+        cx, cz = ok[k]
+        yaw = rng.uniform(0, 2 * np.pi)
+        out[i, :3] = [a[0] + (cx + 0.5) * 0.2, 1.5, a[2] + (cz + 0.5) * 0.2]
+        out[i, 3:] = [0.0, np.sin(yaw / 2), 0.0, np.cos(yaw / 2)]
+    return out
+
+
+def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 21, lr=2e-3, seed=9, cache_dir="/tmp",
+                  n_poses=64, verbose=False):
+    """-> (NGPRadianceField, OccGridEstimator, info dict), trained as described in the module docstring with
+    `render.train_step` + `optim.FusedAdam`.  `scene` is `tests/helpers.make_scene`-shaped (aabb, res, occ, neurons, layers, C,
+    log2_hashmap_size)."""
+    from .ngp import NGPRadianceField
+    from .optim import FusedAdam
+    tag = f"{tuple(np.round(scene['aabb'], 3))}_{scene['neurons']}x{scene['layers']}_C{scene['C']}_T{scene['log2_hashmap_size']}_s{steps}_r{max_rays}_seed{seed}"
+    import hashlib
+    path = os.path.join(cache_dir, "mnf_standin_" + hashlib.md5(tag.encode()).hexdigest()[:16] + ".pt")
+    field = NGPRadianceField(aabb=torch.from_numpy(scene["aabb"]), neurons=scene["neurons"], layers=scene["layers"],
+                             num_semantic_classes=scene["C"], log2_hashmap_size=scene["log2_hashmap_size"], seed=seed).to(device)
+    est = NA.OccGridEstimator(torch.from_numpy(scene["aabb"]), resolution=scene["res"], levels=1).to(device)
+    if os.path.exists(path):
+        ck = torch.load(path, map_location=device)
+        if ck.get("tag") == tag:
+            field.load_state_dict(ck["model"])
+            est.occs.copy_(ck["occs"]); est.binaries = ck["binaries"].to(device)
+            return field.eval(), est.eval(), dict(ck["info"], cached=True)
+    proc = _procedural_estimator(scene, device)
+    # the captures of the reference's first phase (a yaw sweep about the start pose, pipeline.py:252-264) plus views from
+    # elsewhere in the free space, so that the trained region is the one the benchmark's views look at
+    sweep = S.camera_poses(S.SCENES[scene["name"]]["origin"], 40) if scene.get("name") in S.SCENES else np.zeros((0, 7))
+    poses = np.concatenate([sweep, _free_space_poses(scene, max(n_poses - len(sweep), 8), seed)])
+    n_poses = len(poses)
+    c2w = np.stack([RD.pose_to_c2w(p) for p in poses]).astype(np.float32)
+    K = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
+    opt = FusedAdam(field.parameters(), lr=lr, eps=1e-15)
+    gen = torch.Generator().manual_seed(seed)
+    n_rays, t0, losses, skipped, n_samp = 1024, time.perf_counter(), [], 0, 0
+    bk = torch.zeros(3, device=device)
+    for step in range(steps):
+        idx = torch.randint(0, 640 * 640, (n_rays,), generator=gen).numpy()
+        ys, xs = idx // 640, idx % 640
+        idx = idx[np.argsort((ys // 32) * 20 + xs // 32, kind="stable")]      # grouped by 32x32 image block (dataset.fetch_data)
+        k = step % n_poses
+        rays = RD.generate_image_rays(torch.from_numpy(c2w[k:k + 1]), 640, 640, K, device, idx)
+        pix, dep, lab = analytic_targets(proc, scene["aabb"], rays.origins, rays.viewdirs)
+        out = RD.train_step(field, est, opt, rays, pix, dep, lab, bk, step=step, near_plane=0.1, render_step_size=1e-3,
+                            cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-2)
+        n_samp = out["n_rendering_samples"]
+        skipped += int(out["skipped"])
+        if n_samp > 0:                                                         # pipeline.py:494-504: keep the sample batch near the target
+            n_rays = int(min(max_rays, max(256, n_rays * target_samples / n_samp)))
+        if out.get("loss") is not None and (step % 100 == 0 or step == steps - 1):
+            losses.append(float(out["loss"]))
+            if verbose:
+                print(f"[standin] step {step}: loss {losses[-1]:.4f}, rays {n_rays}, samples {n_samp}, "
+                      f"occupied {int(est.binaries.sum())}", flush=True)
+    torch.cuda.synchronize(device)
+    info = dict(steps=steps, seconds=time.perf_counter() - t0, loss_first=losses[0] if losses else None,
+                loss_last=losses[-1] if losses else None, skipped_steps=skipped, final_rays=n_rays, final_samples=n_samp,
+                occupied_cells=int(est.binaries.sum()), cells=int(est.binaries.numel()), cached=False)
+    try:
+        torch.save({"tag": tag, "model": field.state_dict(), "occs": est.occs, "binaries": est.binaries, "info": info}, path)
+    except OSError:
+        pass
+    return field.eval(), est.eval(), info

@@ -340,12 +340,15 @@ int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32
 int mnf_planner_map(const uint8_t *binaries, int32_t n_members, int32_t res_x, int32_t res_y, int32_t res_z,
                     int32_t y_slice, int32_t *out_map, mnf_stream_t stream);
 
-/* Optional in-library timing of the dominant kernel (the fused field kernel) for bench.py's roofline line:
- * between begin and end every field-kernel launch made by mnf_render_test on this thread is bracketed by a
- * hipEvent pair on the launch stream.  mnf_profile_end synchronises those events and returns the summed
- * kernel milliseconds and the number of launches.  Not part of the reference surface. */
+/* Optional in-library kernel timing for bench.py's roofline figures: between begin and end the library brackets its main
+ * launches with hipEvent pairs on the launch stream, grouped by label: "field_render" (the fused field kernel of
+ * mnf_render_test), "field_density", "field_forward", "field_train_forward", "dgrad", "wgrad", "hash_scatter",
+ * "composite_train_forward", "composite_train_backward", "sample_rays".  mnf_profile_end synchronises the events, sums
+ * the milliseconds per label and returns the "field_render" totals; mnf_profile_query reads any label afterwards.
+ * Process-wide (backward passes run on torch's autograd thread).  Not part of the reference surface. */
 int mnf_profile_begin(void);
 int mnf_profile_end(double *field_ms_host, int64_t *launches_host);
+int mnf_profile_query(const char *label_host, double *ms_host, int64_t *launches_host);
 
 /* ---------------------------------------------------------------- predictive-information scorer */
 

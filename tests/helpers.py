@@ -15,7 +15,7 @@ def make_scene(scene="102344250", neurons=128, layers=2, C=29, seed=0, log2_hash
     poses = S.camera_poses(sc["origin"], n_poses)
     occ = S.make_occupancy(res, aabb=sc["aabb"], free_at=[sc["origin"]])
     params = S.make_field_params(neurons, layers, C, seed=seed, log2_hashmap_size=log2_hashmap_size, head_gain=head_gain)
-    return dict(aabb=np.asarray(sc["aabb"], np.float32), res=res, occ=occ, params=params, poses=poses,
+    return dict(name=scene, aabb=np.asarray(sc["aabb"], np.float32), res=res, occ=occ, params=params, poses=poses,
                 neurons=neurons, layers=layers, C=C, log2_hashmap_size=log2_hashmap_size)
 
 

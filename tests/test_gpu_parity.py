@@ -441,8 +441,7 @@ def test_render_baseline_config2_model_matches_oracle():
 
 def test_render_batched_views_equal_single_calls(scene, fields):
     """Each group of rays_per_view rays must behave as its own reference call (own round schedule); sync_every must
-    not change results.  Batched and single calls pack rays into different 64-column tiles, so per-ray sums are
-    associated differently: equality is to fp32 rounding (1e-6 relative), not bitwise."""
+    not change results; batched == single calls bit for bit."""
     from apnrf_amd import render as RD
     hip, _ = fields
     est = H.hip_estimator(scene)
@@ -454,8 +453,10 @@ def test_render_batched_views_equal_single_calls(scene, fields):
         single = RD.render_views(hip, est, o[k * 256:(k + 1) * 256], d[k * 256:(k + 1) * 256], 256, 1024, render_bkgd=bk,
                                  probabilistic=True, sync_every=3, **H.RENDER_KW)
         for key in ("rgb", "acc", "depth", "sem", "rgb_var", "depth_var"):
-            np.testing.assert_allclose(batched[key][k * 256:(k + 1) * 256].cpu().numpy(), single[key].cpu().numpy(),
-                                       rtol=2e-6, atol=1e-7, err_msg=key)
+            # a view is marched by its own workgroups and packed into its own tiles, so its rays see the same lane
+            # positions (= the same summation trees) whether the view is rendered alone or inside a batch: bit-identical.
+            # This is what makes view-sharded scoring on N GPUs reproduce the 1-GPU terms exactly (bench.py score256).
+            np.testing.assert_array_equal(batched[key][k * 256:(k + 1) * 256].cpu().numpy(), single[key].cpu().numpy(), err_msg=key)
         assert int(batched["total"][0]) > 0
     # marching a view's rays in 8x8 pixel blocks (mnf_render_opts.view_order) changes tile composition, not results
     ordered = RD.render_views(hip, est, o, d, 256, 1024, render_bkgd=bk, probabilistic=True, image_hw=(16, 16), **H.RENDER_KW)
