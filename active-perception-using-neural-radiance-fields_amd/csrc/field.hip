@@ -303,6 +303,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         }
         f32x16 bo[CT];
         dense_out<L::KSW>(s_w + L::o_b_out * 64, lane, hb, bo);
+        if (args.out_fp16) round_outputs_fp16(bo);     // tcnn hands its network outputs over in fp16 (ngp.py:181-200 casts them back)
 
         // Results come back in MFMA layout: lane (c, h) holds rows {8g + 4h + i} of column c of tile ct.
         // The density logit (row 0) of this lane's OWN sample sits in lane (lane&31) register 0 of tile h.
@@ -355,12 +356,14 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         dense_relu<L::RTh, L::KSh>(s_w + L::o_h_hid * 64, lane, h1, h2);
         if (SAVE) save_hidden(h2, T::rHH2, T::mHH2);
         dense_out<L::KSh>(s_w + L::o_h_out * 64, lane, h2, out_rgb);
+        if (args.out_fp16) round_outputs_fp16(out_rgb);
         // semantic head (ngp.py:158-169, :215-220)
         dense_relu<L::RTh, 1>(s_w + L::o_s_in * 64, lane, bgeo, h1);
         if (SAVE) save_hidden(h1, T::rHS1, T::mHS1);
         dense_relu<L::RTh, L::KSh>(s_w + L::o_s_hid * 64, lane, h1, h2);
         if (SAVE) save_hidden(h2, T::rHS2, T::mHS2);
         dense_out<L::KSh>(s_w + L::o_s_out * 64, lane, h2, out_sem);
+        if (args.out_fp16) round_outputs_fp16(out_sem);
 
         // ---- write out ----
         // rgb rows 0..2 of this lane's own sample: lane (lane&31), registers 0..2 of tile h
@@ -518,6 +521,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     a.frags = reinterpret_cast<const half8 *>(f->d_frags);
     std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));
     a.C = f->cfg.num_semantic_classes;
+    a.out_fp16 = f->cfg.output_fp16 ? 1 : 0;
     static const int active_waves = getenv("MNF_FIELD_ACTIVE_WAVES") ? atoi(getenv("MNF_FIELD_ACTIVE_WAVES")) : kWavesPerBlock;
     a.active_waves = active_waves >= 1 && active_waves <= kWavesPerBlock ? active_waves : kWavesPerBlock;
     a.levels = reinterpret_cast<const LevelMeta *>(reinterpret_cast<const char *>(f->d_frags) + (size_t)f->shape.blocks_total * 1024);

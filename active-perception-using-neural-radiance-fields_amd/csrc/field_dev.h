@@ -95,6 +95,7 @@ struct KernelArgs {
     const half8 *frags;
     float aabb[6];
     int C;
+    int out_fp16;           // mnf_field_config.output_fp16: round every network output to fp16 (tcnn's hand-over precision)
     int active_waves;       // experiment knob (MNF_FIELD_ACTIVE_WAVES): waves per workgroup that take tiles, default 8
     const LevelMeta *levels;   // [16] in device memory, wave-uniform: read with scalar loads where a batch needs them
                                // (as a by-value kernarg array the 112 dwords were all loaded up front and lived in
@@ -188,6 +189,14 @@ __device__ __forceinline__ void dense_out(const half8 *__restrict__ w_lds, int l
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) o[ct] = mfma(a, b[ct][ks], o[ct]);
     }
+}
+
+// tcnn-faithful hand-over: the three networks' outputs rounded to fp16 and widened again (`.to(x)` in ngp.py:181-220)
+__device__ __forceinline__ void round_outputs_fp16(f32x16 (&o)[CT]) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[ct][i] = (float)(half_t)o[ct][i];
 }
 
 // Lane l (sample A = column l of tile 0) and lane l+32 (sample B = column l of tile 1) each hold all 16

@@ -82,7 +82,8 @@ class NGPRadianceField(torch.nn.Module):
     def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
                  neurons: int = 128, layers: int = 4, density_activation=None, unbounded: bool = False,
                  base_resolution: int = 16, max_resolution: int = 4096, geo_feat_dim: int = 15, n_levels: int = 16,
-                 log2_hashmap_size: int = 19, num_semantic_classes: int = 0, seed: int = 0) -> None:
+                 log2_hashmap_size: int = 19, num_semantic_classes: int = 0, seed: int = 0,
+                 tcnn_output_rounding: bool = False) -> None:
         super().__init__()
         if not isinstance(aabb, torch.Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
@@ -106,6 +107,9 @@ class NGPRadianceField(torch.nn.Module):
         cfg.neurons, cfg.layers, cfg.num_semantic_classes = neurons, layers, num_semantic_classes
         cfg.n_levels, cfg.n_features, cfg.log2_hashmap_size = n_levels, 4, log2_hashmap_size
         cfg.base_resolution, cfg.max_resolution = base_resolution, max_resolution
+        # tiny-cuda-nn returns fp16 network outputs which ngp.py:181-220 widen with `.to(x)`; True reproduces that rounding
+        # (default False: fp32 outputs, the more precise of the two; DESIGN.md §2 quantifies the difference)
+        cfg.output_fp16 = 1 if tcnn_output_rounding else 0
         self._cfg = cfg
         self._handle = ctypes.c_void_p()
         self._handle_device = None

@@ -203,6 +203,9 @@ typedef struct {
     int32_t log2_hashmap_size;     /* ngp.py:85 */
     int32_t base_resolution;       /* ngp.py:81 */
     int32_t max_resolution;        /* ngp.py:82 */
+    int32_t output_fp16;           /* 0 (default): network outputs stay fp32.  1: every output of the three networks is rounded
+                                      to fp16 before it is used, as tiny-cuda-nn hands them over (ngp.py:181-200, :210-220 cast
+                                      tcnn's fp16 outputs back with `.to(x)`) — the tcnn-faithful mode of DESIGN.md §2 */
 } mnf_field_config;
 
 /* tcnn.NetworkWithInputEncoding / tcnn.Network / tcnn.Encoding construction, ngp.py:108-169 */

@@ -26,8 +26,10 @@ Oct 2023):
 Precision model (``precision="f16"``, the product default, mirrors tcnn's fp16 storage):
 parameters are rounded to fp16; hash features, SH values and every hidden activation are
 rounded to fp16 where they enter a matrix product; products accumulate in fp32; network
-outputs stay fp32 (tcnn rounds them to fp16 too and accumulates in fp16 — a documented
-deviation: ours is the more precise of the two).  ``precision="f32"`` does no rounding.
+outputs stay fp32.  ``precision="tcnn"`` additionally rounds every network output to fp16, which is
+what tiny-cuda-nn hands back (the product's `tcnn_output_rounding=True` / `mnf_field_config.output_fp16`);
+tcnn's fp16 ACCUMULATION inside a layer is not emulated (its summation order is not part of any published
+contract).  ``precision="f32"`` does no rounding.
 """
 import math
 from dataclasses import dataclass, field as dc_field
@@ -123,7 +125,7 @@ def init_params(cfg: FieldConfig, seed: int = 0) -> Dict[str, np.ndarray]:
 def _q(x: torch.Tensor, precision: str) -> torch.Tensor:
     """fp16 rounding with a straight-through gradient (d round(x)/dx := 1), so that torch autograd through this
     oracle yields the fp32 gradient of the fp16-rounded forward — the reference the HIP backward is checked against."""
-    if precision != "f16":
+    if precision not in ("f16", "tcnn"):
         return x
     if x.requires_grad:
         return x + (x.detach().half().float() - x.detach())
@@ -227,7 +229,9 @@ class OracleField:
         h = _q(h, self.precision)
         for w in ws[:-1]:
             h = _q(torch.relu(h @ w.t()), self.precision)
-        return h @ ws[-1].t()
+        out = h @ ws[-1].t()
+        # "tcnn": the network hands its outputs over in fp16 (ngp.py:181-200, :210-220 widen them with `.to(x)`)
+        return _q(out, "f16") if self.precision == "tcnn" else out
 
     # ---- ngp.py call surface ---------------------------------------------------------
     def _base(self, positions: torch.Tensor):

@@ -22,7 +22,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_LIB_FMAD_PATH = os.path.join(_HERE, "_build", "liboracle_fmad.so")
 _lib = None
+_lib_fmad = None
 
 
 class _Segments(ctypes.Structure):
@@ -40,19 +42,30 @@ class _Segments(ctypes.Structure):
 def build(force: bool = False) -> str:
     """Compile oracle/nerfacc_grid.c -> oracle/_build/liboracle.so (gcc, seconds)."""
     src = os.path.join(_HERE, "nerfacc_grid.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    if force or any(not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src) for p in (_LIB_PATH, _LIB_FMAD_PATH)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     return _LIB_PATH
 
 
-def lib():
-    global _lib
+def _load(path):
+    build()
+    l = ctypes.CDLL(path)
+    l.orc_ray_aabb_intersect.restype = None
+    l.orc_traverse_grids.restype = None
+    l.orc_exclusive_sum.restype = None
+    return l
+
+
+def lib(fmad: bool = False):
+    """The restatement built with FMA contraction off (the parity reference), or — `fmad=True` — the variant in which every
+    product feeding an addition is fused as nvcc's default -fmad=true may do (an exposure estimate, never the reference)."""
+    global _lib, _lib_fmad
+    if fmad:
+        if _lib_fmad is None:
+            _lib_fmad = _load(_LIB_FMAD_PATH)
+        return _lib_fmad
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(_LIB_PATH)
-        _lib.orc_ray_aabb_intersect.restype = None
-        _lib.orc_traverse_grids.restype = None
-        _lib.orc_exclusive_sum.restype = None
+        _lib = _load(_LIB_PATH)
     return _lib
 
 
@@ -109,7 +122,7 @@ def _alloc(cnts: np.ndarray, masks: bool, valid: bool):
 
 def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes=None, far_planes=None,
                    step_size=1e-3, cone_angle=0.0, traverse_steps_limit=None, over_allocate=False,
-                   rays_mask=None, t_sorted=None, t_indices=None, hits=None
+                   rays_mask=None, t_sorted=None, t_indices=None, hits=None, fmad=False
                    ) -> Tuple[RayIntervals, RaySamples, np.ndarray]:
     rays_o, rays_d, aabbs = _f32(rays_o), _f32(rays_d), _f32(aabbs)
     binaries = np.ascontiguousarray(binaries).astype(np.uint8)
@@ -133,7 +146,7 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes=None, far_planes
     term = np.empty(n, np.float32)
 
     def call(first_pass, iv, sm, use_mask, term_arr):
-        lib().orc_traverse_grids(
+        lib(fmad).orc_traverse_grids(
             ctypes.c_int32(n), _p(rays_o), _p(rays_d), _p(mask) if use_mask else None,
             ctypes.c_int32(n_grids), _p(res), _p(binaries), _p(aabbs),
             _p(hits_u8), _p(t_sorted), _p(t_indices), _p(near_planes), _p(far_planes),

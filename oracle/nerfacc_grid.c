@@ -34,6 +34,17 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* Second build of this file (liboracle_fmad.so, -DORC_FMAD): every product that feeds an addition inside ONE expression of
+ * the reference source is fused, which is what nvcc's default -fmad=true is allowed to do to utils_grid.cuh:67-68, :90-92
+ * (ray.origin + ray.dir * t, the tmax_xyz chain) and grid.cu:158-161, :199-203 (t_last + dt * 0.5f).  nvcc's actual choice
+ * is compiler-internal; this variant bounds how far a contracted CUDA build can move from the contraction-off one
+ * (tests/test_oracle_golden.py::test_marcher_fmad_exposure reports the sample / mask differences). */
+#ifdef ORC_FMAD
+#define ORC_MADD(a, b, c) fmaf((a), (b), (c))
+#else
+#define ORC_MADD(a, b, c) ((a) * (b) + (c))
+#endif
+
 typedef struct { float x, y, z; } f3;
 typedef struct { int x, y, z; } i3;
 
@@ -160,7 +171,7 @@ void orc_traverse_grids(int32_t n_rays, const float *rays_o, const float *rays_d
                 } else {
                     float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
                     for (;;) {
-                        if (t_last + dt * 0.5f >= this_tmin) break;
+                        if (ORC_MADD(dt, 0.5f, t_last) >= this_tmin) break;
                         t_last += dt;
                     }
                 }
@@ -172,8 +183,8 @@ void orc_traverse_grids(int32_t n_rays, const float *rays_o, const float *rays_d
             const f3 resf = { (float)res.x, (float)res.y, (float)res.z };
             const f3 vox = { (amax.x - amin.x) / resf.x, (amax.y - amin.y) / resf.y, (amax.z - amin.z) / resf.z };
             const float ts = this_tmin + eps, te = this_tmax - eps;
-            const f3 rs = { org.x + dir.x * ts, org.y + dir.y * ts, org.z + dir.z * ts };
-            const f3 re = { org.x + dir.x * te, org.y + dir.y * te, org.z + dir.z * te };
+            const f3 rs = { ORC_MADD(dir.x, ts, org.x), ORC_MADD(dir.y, ts, org.y), ORC_MADD(dir.z, ts, org.z) };
+            const f3 re = { ORC_MADD(dir.x, te, org.x), ORC_MADD(dir.y, te, org.y), ORC_MADD(dir.z, te, org.z) };
             i3 cur = { (int)(((rs.x - amin.x) / (amax.x - amin.x)) * resf.x),
                        (int)(((rs.y - amin.y) / (amax.y - amin.y)) * resf.y),
                        (int)(((rs.z - amin.z) / (amax.z - amin.z)) * resf.z) };
@@ -184,9 +195,9 @@ void orc_traverse_grids(int32_t n_rays, const float *rays_o, const float *rays_d
             fin.x = clampi(fin.x, 0, res.x - 1); fin.y = clampi(fin.y, 0, res.y - 1); fin.z = clampi(fin.z, 0, res.z - 1);
 
             const i3 start = { cur.x + (dir.x > 0 ? 1 : 0), cur.y + (dir.y > 0 ? 1 : 0), cur.z + (dir.z > 0 ? 1 : 0) };
-            const f3 tmx = { ((amin.x + (((float)start.x * vox.x) - rs.x)) * inv.x) + this_tmin,
-                             ((amin.y + (((float)start.y * vox.y) - rs.y)) * inv.y) + this_tmin,
-                             ((amin.z + (((float)start.z * vox.z) - rs.z)) * inv.z) + this_tmin };
+            const f3 tmx = { ORC_MADD(amin.x + ORC_MADD((float)start.x, vox.x, -rs.x), inv.x, this_tmin),
+                             ORC_MADD(amin.y + ORC_MADD((float)start.y, vox.y, -rs.y), inv.y, this_tmin),
+                             ORC_MADD(amin.z + ORC_MADD((float)start.z, vox.z, -rs.z), inv.z, this_tmin) };
             f3 tdist = { dir.x == 0.0f ? this_tmax : tmx.x, dir.y == 0.0f ? this_tmax : tmx.y, dir.z == 0.0f ? this_tmax : tmx.z };
             const f3 stepf = { dir.x == 0.0f ? 0.0f : (dir.x > 0.0f ? 1.0f : -1.0f),
                                dir.y == 0.0f ? 0.0f : (dir.y > 0.0f ? 1.0f : -1.0f),
@@ -207,7 +218,7 @@ void orc_traverse_grids(int32_t n_rays, const float *rays_o, const float *rays_d
                     } else {
                         float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
                         for (;;) {
-                            if (t_last + dt * 0.5f >= t_traverse) break;
+                            if (ORC_MADD(dt, 0.5f, t_last) >= t_traverse) break;
                             t_last += dt;
                         }
                     }
@@ -219,7 +230,7 @@ void orc_traverse_grids(int32_t n_rays, const float *rays_o, const float *rays_d
                             t_next = t_traverse;
                         } else {
                             float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                            if (t_last + dt * 0.5f >= t_traverse) break;
+                            if (ORC_MADD(dt, 0.5f, t_last) >= t_traverse) break;
                             t_next = t_last + dt;
                         }
                         if (has_iv) {

@@ -1042,3 +1042,147 @@ def test_vanilla_field_general_shapes_match_cpu_autograd():
         for name, p in field.named_parameters():
             want = cpu[name].grad.numpy()
             np.testing.assert_allclose(p.grad.cpu().numpy(), want, atol=2e-5 * float(np.abs(want).max()) + 1e-9, rtol=1e-4, err_msg=name)
+
+
+# ------------------------------------------------------------------ tcnn-faithful output rounding, remaining BASELINE configs, per-pose drivers
+def test_field_tcnn_output_rounding_matches_oracle():
+    """`tcnn_output_rounding=True` (mnf_field_config.output_fp16): every network output is rounded to fp16 where tiny-cuda-nn
+    hands it over (ngp.py:181-200, :210-220) — against the oracle's precision="tcnn".  The two roundings agree except where
+    an fp32 pre-image sits within the HIP/CPU summation-order difference of a rounding boundary, which moves the value by one
+    fp16 ulp (2^-10 relative): hence the relative term."""
+    sc = H.make_scene(neurons=128, layers=2, C=29, log2_hashmap_size=14, head_gain=4.0)
+    hip, orc = H.hip_field(sc, tcnn_output_rounding=True), H.oracle_field(sc, precision="tcnn")
+    hip32 = H.hip_field(sc)
+    rng = np.random.default_rng(1)
+    n = 4000 + 11
+    a = sc["aabb"]
+    pos = (a[:3] + rng.random((n, 3)) * (a[3:] - a[:3])).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    with torch.no_grad():
+        rgb, sigma, sem = hip(_cu(pos), _cu(d))
+        rgb32, sigma32, sem32 = hip32(_cu(pos), _cu(d))
+    r_rgb, r_sigma, r_sem = orc(torch.from_numpy(pos), torch.from_numpy(d))
+    np.testing.assert_allclose(sem.cpu().numpy(), r_sem.numpy(), atol=1e-3, rtol=2e-3)
+    np.testing.assert_allclose(rgb.cpu().numpy(), r_rgb.numpy(), atol=1e-3)
+    # density = exp(fp16 logit - 1): a boundary flip of the logit (3 of 4000 samples) is one fp16 ulp = 2^-8 at |logit| in [4,8),
+    # i.e. 0.4 % of the density; everything else agrees to 2e-3 as in the fp32-output mode
+    sg, rsg = sigma.cpu().numpy(), r_sigma.numpy()
+    np.testing.assert_allclose(sg, rsg, rtol=9e-3, atol=1e-6)
+    assert (np.abs(sg - rsg) > 2e-3 * np.abs(rsg) + 1e-6).mean() < 5e-3
+    # the outputs ARE fp16 values, and the mode differs from the fp32-output default by at most half an fp16 ulp
+    s_np = sem.cpu().numpy()
+    np.testing.assert_array_equal(s_np, s_np.astype(np.float16).astype(np.float32))
+    np.testing.assert_allclose(s_np, sem32.cpu().numpy(), rtol=2 ** -11 * 1.01, atol=1e-7)
+    assert np.abs(s_np - sem32.cpu().numpy()).max() > 0
+
+
+@pytest.mark.parametrize("prob", [False, True])
+def test_render_baseline_config2_29_classes(prob):
+    """BASELINE config 2 as written: scene 102344250, 256x256 view geometry, 4 x 64 base MLP, 29 classes."""
+    from apnrf_amd import render as RD
+    from oracle import render as R
+    sc = H.make_scene("102344250", neurons=64, layers=4, C=29, seed=5)
+    hip, orc, est = H.hip_field(sc), H.oracle_field(sc), H.hip_estimator(sc)
+    o, d = H.view_rays(sc, 2, width=256, height=256, h=20, w=20)
+    bk = torch.tensor([0.2, 0.7, 0.4])
+    fn = R.render_prob_test if prob else R.render_test
+    ref = fn(1024, orc, sc["occ"], sc["aabb"][None], o, d, render_bkgd=bk, **H.RENDER_KW)
+    out = RD.render_views(hip, est, o.to(DEV), d.to(DEV), o.shape[0], 1024, render_bkgd=bk, probabilistic=prob, **H.RENDER_KW)
+    assert out["sem"].shape == (400, 29) and ref["total_samples"] > 4000
+    _check_render(out, ref, prob, max_tie_rays=2)
+
+
+def test_render_from_pose_drivers_match_oracle(scene, fields):
+    """`Dataset.render_image_from_pose` / `render_probablistic_image_from_pose` (habitat_to_data.py:304-549) called
+    directly: float64 host arrays of the reference's shapes, values equal to the oracle's per-pose renders."""
+    from apnrf_amd import render as RD
+    from apnrf_amd.dataset import Dataset
+    from oracle import render as R
+    hip, orc = fields
+    est = H.hip_estimator(scene)
+    poses = scene["poses"][[2, 5]]
+    W = Hh = 640
+    focal = 0.5 * W / np.tan(np.pi / 4)
+    scale = 0.025                                     # 16 x 16 rays per pose
+    args = (hip, est, poses, W, Hh, focal, 0.1, 1e-3, scale, 0.004, 0.01, None, DEV)
+    images, depths, accs, sems = RD.render_image_from_pose(*args)
+    p_images, p_var, p_depths, p_dvar, p_accs, p_sems = RD.render_probablistic_image_from_pose(*args)
+    for arr, shp in ((images, (2, 16, 16, 3)), (depths, (2, 16, 16)), (accs, (2, 16, 16)), (sems, (2, 16, 16, 29)),
+                     (p_var, (2, 16, 16, 3)), (p_dvar, (2, 16, 16))):
+        assert isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.shape == shp, (arr.dtype, arr.shape, shp)
+    assert Dataset.render_image_from_pose is not None         # the static methods of the reference class resolve to the same drivers
+    idx = R.subsample_indices(W * Hh, 256)
+    for k, p in enumerate(poses):
+        o, d = R.generate_image_rays(R.pose_to_c2w(p), W, Hh, focal, idx)
+        ref = R.render_prob_test(1024, orc, scene["occ"], scene["aabb"][None], o, d, render_bkgd=torch.zeros(3), **H.RENDER_KW)
+        np.testing.assert_allclose(p_images[k].reshape(-1, 3), ref["rgb"].numpy(), atol=1e-3)
+        np.testing.assert_allclose(p_depths[k].reshape(-1), ref["depth"].numpy()[:, 0], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(p_accs[k].reshape(-1), ref["acc"].numpy()[:, 0], atol=1e-3)
+        np.testing.assert_allclose(p_sems[k].reshape(-1, 29), ref["sem"].numpy(), atol=1e-3)
+        np.testing.assert_allclose(p_var[k].reshape(-1, 3), ref["rgb_var"].numpy(), atol=1e-3)
+        np.testing.assert_allclose(p_dvar[k].reshape(-1), ref["depth_var"].numpy()[:, 0], atol=2e-3, rtol=2e-3)
+        # deterministic driver == probabilistic driver on the shared outputs
+        np.testing.assert_allclose(images[k], p_images[k], atol=1e-6)
+        np.testing.assert_allclose(sems[k], p_sems[k], atol=1e-5)
+
+
+def test_train_step_baseline_config5():
+    """BASELINE config 5: scene 102344280, 8192-ray train batches.  (1) a 256-ray subset of the batch through the
+    differentiable train render + loss + backward against the oracle under CPU autograd; (2) the full 8192-ray step through
+    `render.train_step`: size-independent properties (finite loss, every ray's opacity in [0,1], sample accounting, gradients
+    only on touched table entries, parameters move, a second identical call after the update lowers the loss on the same batch)."""
+    import torch.nn.functional as F
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    from oracle import render as R
+    sc = H.make_scene("102344280", log2_hashmap_size=16, seed=2, n_poses=8)
+    hip, orc, est = H.hip_field(sc), H.oracle_field(sc, requires_grad=True), H.hip_estimator(sc)
+    c2w = RD.pose_to_c2w(sc["poses"][1]).astype(np.float32)[None]
+    K = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
+    rng = np.random.default_rng(4)
+    idx = rng.integers(0, 640 * 640, 8192)
+    rays = RD.generate_image_rays(torch.from_numpy(c2w), 640, 640, K, DEV, idx)
+    pix = torch.from_numpy(rng.random((8192, 3)).astype(np.float32)).to(DEV)
+    dep = torch.from_numpy(rng.uniform(0.5, 4.0, 8192).astype(np.float32)).to(DEV)
+    lab = torch.from_numpy(rng.integers(0, 29, 8192)).to(DEV)
+    bk = torch.tensor([0.1, 0.6, 0.3], device=DEV)
+
+    def loss_fn(rgb, depth, sem, pix_, dep_, lab_):
+        return F.smooth_l1_loss(rgb, pix_) * 10 + F.smooth_l1_loss(depth, dep_.unsqueeze(1)) / 5 + F.cross_entropy(sem, lab_) / 2
+
+    # (1) 256-ray subset vs the oracle
+    sub = torch.arange(0, 8192, 32, device=DEV)
+    hip.eval()                                                     # no stratified jitter; gradients still flow
+    o_s, d_s = rays.origins[sub].contiguous(), rays.viewdirs[sub].contiguous()
+    rgb, acc, depth, sem, n = RD.render_image_with_occgrid_with_depth_guide(hip, est, RD.Rays(o_s, d_s), render_bkgd=bk, **H.RENDER_KW)
+    loss = loss_fn(rgb, depth, sem, pix[sub], dep[sub], lab[sub])
+    hip.zero_grad(); loss.backward()
+    ref = R.render_train(orc, sc["occ"], sc["aabb"][None], float(est.occs.mean().item()), o_s.cpu(), d_s.cpu(), torch.full((256,), 0.1),
+                         render_bkgd=bk.cpu(), render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01)
+    r_loss = loss_fn(ref[0], ref[2], ref[3], pix[sub].cpu(), dep[sub].cpu(), lab[sub].cpu())
+    r_loss.backward()
+    assert n > 5000 and abs(n - ref[4]) <= max(3, 0.002 * ref[4])
+    np.testing.assert_allclose(loss.item(), r_loss.item(), rtol=2e-4)
+    n_mlp = sum(o_ * i_ for o_, i_ in orc.shapes["base"])
+    _grad_close(hip.mlp_base.params.grad[:n_mlp], orc.p_base.grad[:n_mlp], "base mlp", rel=3e-2, cos=0.999)
+    _grad_close(hip.mlp_base.params.grad[n_mlp:], orc.p_base.grad[n_mlp:], "hash table", rel=3e-2, cos=0.999)
+    _grad_close(hip.mlp_head.params.grad, orc.p_head.grad, "rgb head", rel=3e-2, cos=0.999)
+    _grad_close(hip.mlp_sem.params.grad, orc.p_sem.grad, "sem head", rel=3e-2, cos=0.999)
+    # (2) the full batch through train_step
+    hip.zero_grad()
+    opt = FusedAdam(hip.parameters(), lr=1e-3, eps=1e-15)
+    before = [p.detach().clone() for p in hip.parameters()]
+    out1 = RD.train_step(hip, est, opt, rays, pix, dep, lab, bk, step=1, **H.RENDER_KW)      # step 1: no occupancy refresh
+    assert not out1["skipped"] and np.isfinite(float(out1["loss"])) and out1["n_rendering_samples"] > 8192 * 10
+    assert est.last_sampling["n_marched"] >= out1["n_rendering_samples"]
+    g_tab = hip.mlp_base.params.grad[n_mlp:]
+    assert 0 < int((g_tab != 0).sum()) < g_tab.numel() and torch.isfinite(g_tab).all()
+    assert all((p.detach() != b).any() for p, b in zip(hip.parameters(), before) if p.numel())
+    hip.eval()
+    with torch.no_grad():
+        rgb_a, acc_a, _, _, _ = RD.render_image_with_occgrid_with_depth_guide(hip, est, rays, render_bkgd=bk, **H.RENDER_KW)
+    assert float(acc_a.min()) >= 0 and float(acc_a.max()) <= 1 + 1e-5 and rgb_a.shape == (8192, 3)
+    losses = [float(out1["loss"])]
+    for s_ in range(2, 8):
+        losses.append(float(RD.train_step(hip, est, opt, rays, pix, dep, lab, bk, step=s_, **H.RENDER_KW)["loss"]))
+    assert losses[-1] < losses[0], losses
