@@ -7,7 +7,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uin
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_FILE = os.path.join(_HERE, "libmi355nerf.so")
+_LIB_FILE = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmi355nerf.so")     # MNF_LIB_PATH: experiment builds (tools/)
 _lib = None
 
 

@@ -37,12 +37,14 @@ def _deps_mtime():
 def _compile(item):
     src, extra = item
     obj = os.path.join(OBJ, src + ".o")
-    cmd = ["hipcc"] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = ["hipcc"] + COMMON + extra + os.environ.get("MNF_EXTRA_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
     subprocess.check_call(cmd)
     return obj
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    if os.environ.get("MNF_LIB_PATH"):          # an experiment build is in use: leave it alone
+        return os.environ["MNF_LIB_PATH"]
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
         return LIB
     os.makedirs(OBJ, exist_ok=True)

@@ -277,7 +277,13 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
     }
 }
 
-__device__ __forceinline__ void hash_load(const half4 *__restrict__ table, const LevelPrep &p, half4 (&v)[8]) {
+__device__ __forceinline__ void hash_load(const half4 *__restrict__ table, const LevelPrep &p, half4 (&v)[8], bool stream = false) {
+    if (stream) {   // wave-uniform: a level whose lines are not worth keeping in L2 (experiment: MNF_NT_FROM)
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner)
+            v[corner] = __builtin_nontemporal_load(reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + p.off[corner]));
+        return;
+    }
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner)
         v[corner] = *reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + p.off[corner]);

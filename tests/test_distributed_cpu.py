@@ -103,3 +103,60 @@ def test_ray_data_parallel_gradient_average_two_ranks_gloo(tmp_path):
     g0, g1 = np.load(tmp_path / "grads_0.npy"), np.load(tmp_path / "grads_1.npy")
     np.testing.assert_array_equal(g0, g1)
     np.testing.assert_allclose(g0, mean, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ §8e rows 2-3: sharded rendering exchange, weight broadcast, placement
+def _worker_helpers(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import apnrf_amd  # noqa: F401
+    from apnrf_amd import distributed as DD
+    from apnrf_amd.nerfacc import OccGridEstimator
+    from apnrf_amd.ngp import NGPRadianceField
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # the all-gather of packed per-ray rows: 5 views x 7 rays, D = 9; rank-local rows are a deterministic function of the ray id
+    V, R, D = 5, 7, 9
+    sh = DD.shard_rays(V, R, world, rank)
+    r0, r1 = sh["lo"] * sh["unit_rays"], sh["hi"] * sh["unit_rays"]
+    ids = torch.arange(r0, r1, dtype=torch.float32)
+    local = ids[:, None] * 10 + torch.arange(D, dtype=torch.float32)[None]
+    full = DD.gather_rows(local, sh["per"] * sh["unit_rays"], V * R)
+    np.save(os.path.join(out_dir, f"rows_{rank}.npy"), full.numpy())
+    # weights + occupancy broadcast from rank 1 (the rank that "trained")
+    f = NGPRadianceField([0.0, 0, 0, 1, 1, 1], neurons=64, layers=1, num_semantic_classes=5, log2_hashmap_size=8, seed=rank)
+    e = OccGridEstimator([0.0, 0, 0, 1, 1, 1], resolution=[4, 3, 5])
+    e.occs.fill_(float(rank)); e.binaries[:] = bool(rank)
+    v0 = f.mlp_head.params._version
+    DD.broadcast_model(f, e, src=1)
+    assert f.mlp_head.params._version > v0            # the field handle will reload its fp16 copies
+    np.save(os.path.join(out_dir, f"head_{rank}.npy"), f.mlp_head.params.detach().numpy())
+    np.save(os.path.join(out_dir, f"occ_{rank}.npy"), np.concatenate([e.occs.numpy(), e.binaries.numpy().reshape(-1).astype(np.float32)]))
+    np.save(os.path.join(out_dir, f"members_{rank}.npy"), np.asarray(DD.my_members(5)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_render_exchange_broadcast_and_placement_gloo(tmp_path):
+    sys.path.insert(0, REPO)
+    import apnrf_amd  # noqa: F401
+    from apnrf_amd import distributed as DD
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_helpers, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = np.arange(35, dtype=np.float32)[:, None] * 10 + np.arange(9, dtype=np.float32)[None]
+    for r in (0, 1):
+        np.testing.assert_array_equal(np.load(tmp_path / f"rows_{r}.npy"), want)            # every rank holds every ray's row
+    np.testing.assert_array_equal(np.load(tmp_path / "head_0.npy"), np.load(tmp_path / "head_1.npy"))
+    occ = np.load(tmp_path / "occ_0.npy")
+    assert (occ == 1.0).all() and (np.load(tmp_path / "occ_1.npy") == 1.0).all()            # rank 1's grid everywhere
+    assert np.load(tmp_path / "members_0.npy").tolist() == [0, 2, 4] and np.load(tmp_path / "members_1.npy").tolist() == [1, 3]
+    # sharding arithmetic (pure): whole views when there are enough of them, row tiles otherwise; every ray exactly once
+    for V, R, W in ((8, 640000, 8), (5, 7, 2), (1, 640000, 8), (3, 4096, 8), (2, 150, 4)):
+        covered = []
+        for rank in range(W):
+            sh = DD.shard_rays(V, R, W, rank)
+            assert R % sh["tiles_per_view"] == 0 and sh["unit_rays"] * sh["tiles_per_view"] == R
+            covered += list(range(sh["lo"] * sh["unit_rays"], sh["hi"] * sh["unit_rays"]))
+            assert (sh["tiles_per_view"] == 1) == (V >= W)
+        assert covered == list(range(V * R))
+    assert DD.ensemble_placement(2, 8) == [0, 1] and DD.ensemble_placement(5, 2) == [0, 1, 0, 1, 0]

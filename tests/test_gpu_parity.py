@@ -1186,3 +1186,23 @@ def test_train_step_baseline_config5():
     for s_ in range(2, 8):
         losses.append(float(RD.train_step(hip, est, opt, rays, pix, dep, lab, bk, step=s_, **H.RENDER_KW)["loss"]))
     assert losses[-1] < losses[0], losses
+
+
+def test_render_views_sharded_single_rank_and_row_tiles(scene, fields):
+    """`distributed.render_views_sharded` without a process group is `render_views`; its row-tile mode (fewer views than
+    ranks) renders each tile as a reference call of its own, which is what calling `render_views` on the tile gives."""
+    from apnrf_amd import distributed as DD
+    from apnrf_amd import render as RD
+    hip, _ = fields
+    est = H.hip_estimator(scene)
+    o, d = H.view_rays(scene, 1, h=16, w=16)
+    o, d = o.to(DEV), d.to(DEV)
+    bk = torch.zeros(3)
+    a = DD.render_views_sharded(hip, est, o, d, 256, probabilistic=True, max_samples=1024, render_bkgd=bk, **H.RENDER_KW)
+    b = RD.render_views(hip, est, o, d, 256, 1024, render_bkgd=bk, probabilistic=True, **H.RENDER_KW)
+    for k in ("rgb", "acc", "depth", "sem", "rgb_var", "depth_var", "total"):
+        assert torch.equal(a[k], b[k]), k
+    sh = DD.shard_rays(1, 256, 4, 2)                       # one view over four ranks: rank 2 renders rays 128..191 as its own call
+    assert (sh["tiles_per_view"], sh["lo"], sh["hi"], sh["unit_rays"]) == (4, 2, 3, 64)
+    tile = RD.render_views(hip, est, o[128:192].contiguous(), d[128:192].contiguous(), 64, 1024, render_bkgd=bk, **H.RENDER_KW)
+    np.testing.assert_allclose(tile["rgb"].cpu().numpy(), b["rgb"][128:192].cpu().numpy(), atol=2e-3)   # schedule differs, values agree

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Experiment builds of libmi355nerf.so: tools/build_variants.sh "<name> <extra hipcc flags>" ...   -> gpurun_exp/lib_<name>.so
+# (only the 128x2 field shape is compiled: MNF_DEV_ONLY_128x2).  Run them with MNF_LIB_PATH=<file>.
+set -e
+cd "$(dirname "$0")/.."
+PKG=active-perception-using-neural-radiance-fields_amd
+mkdir -p gpurun_exp
+for spec in "$@"; do
+  set -- $spec; name=$1; shift
+  MNF_EXTRA_FLAGS="-DMNF_DEV_ONLY_128x2 $*" python - <<PY
+import importlib.util, os, shutil
+spec = importlib.util.spec_from_file_location("b", "$PKG/build.py"); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+m.LIB = os.path.abspath("gpurun_exp/lib_$name.so"); m.OBJ = os.path.abspath("gpurun_exp/obj_$name"); m.build(force=True)
+print("built", m.LIB)
+PY
+done
