@@ -92,12 +92,12 @@ def broadcast_model(radiance_field, estimator=None, src: int = 0, group=None) ->
     world, _ = _world(group)
     if world == 1:
         return
-    tensors: List[torch.Tensor] = [p.data for p in radiance_field.parameters() if p.numel()]
+    tensors: List[torch.Tensor] = [p for p in radiance_field.parameters() if p.numel()]
     if estimator is not None:
         tensors += [estimator.occs]
     for t in tensors:
-        dist.broadcast(t, src=src, group=group)
-        torch.autograd.graph.increment_version(t)          # the field handle reloads its fp16 copies on next use
+        dist.broadcast(t.data, src=src, group=group)
+        torch.autograd.graph.increment_version(t)          # (`.data` has its own counter) the field handle reloads its fp16 copies on next use
     if estimator is not None:
         b = estimator.binaries.to(torch.uint8)               # bool tensors are not a collective dtype
         dist.broadcast(b, src=src, group=group)
