@@ -76,6 +76,8 @@ SIGNATURES = {
     "mnf_update_occupancy": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_float,
                                        c_float, c_float, c_uint64, c_void_p, c_int64, c_void_p]),
     "mnf_generate_rays": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mnf_gather_pixels": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
     "mnf_field_create": (c_int32, [POINTER(FieldConfig), POINTER(c_void_p)]),
     "mnf_field_destroy": (c_int32, [c_void_p]),
     "mnf_field_param_count": (c_int64, [c_void_p, c_int32]),

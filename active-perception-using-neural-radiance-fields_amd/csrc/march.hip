@@ -369,6 +369,23 @@ __global__ void __launch_bounds__(256) raygen_kernel(const float *__restrict__ c
     }
 }
 
+// ------------------------------------------------------------------ dataset ingest: pixel gather
+// habitat_to_data.py:229-232: rgb = images[id, y, x] / 255.0, dep = depths[id, y, x], sem = semantics[id, y, x] for the pixels
+// of one image, from the reference's storage dtypes (u8 / f32 / i64) or the packed on-device layout (u8 / f16 / u8).
+__global__ void __launch_bounds__(256) gather_pixels_kernel(const uint8_t *__restrict__ images, const void *__restrict__ depths, int depth_f16,
+                                                            const void *__restrict__ sems, int sem_u8, int64_t pixels_per_image,
+                                                            const int64_t *__restrict__ image_id, const int64_t *__restrict__ pix, int64_t n,
+                                                            float *__restrict__ rgb, float *__restrict__ dep, int64_t *__restrict__ sem) {
+    const int64_t base = image_id[0] * pixels_per_image;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t p = base + pix[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rgb[3 * i + k] = (float)images[3 * p + k] / 255.0f;
+        dep[i] = depth_f16 ? (float)reinterpret_cast<const _Float16 *>(depths)[p] : reinterpret_cast<const float *>(depths)[p];
+        sem[i] = sem_u8 ? (int64_t)reinterpret_cast<const uint8_t *>(sems)[p] : reinterpret_cast<const int64_t *>(sems)[p];
+    }
+}
+
 // ------------------------------------------------------------------ planner hand-off
 // scripts/pipeline.py:1043-1049 + planning/planning_funcs.py:243-261: slice the occupancy grids of the ensemble at
 // height index `y_slice`, merge (any member occupied), dilate with a 3x3 box ("symm" boundary == clamped neighbours)
@@ -561,6 +578,16 @@ extern "C" int mnf_generate_rays(const float *c2w, int32_t n_views, int32_t widt
     hipLaunchKernelGGL(raygen_kernel, dim3(grid_for((int64_t)n_views * n_pix, 256)), dim3(256), 0, as_stream(stream), c2w,
                        n_views, width, height, focal, pix_idx, n_pix, origins, viewdirs);
     return launch_status("raygen_kernel");
+}
+
+extern "C" int mnf_gather_pixels(const uint8_t *images, const void *depths, int32_t depth_is_f16, const void *semantics, int32_t sem_is_u8,
+                                 int64_t pixels_per_image, const int64_t *image_id, const int64_t *pix_idx, int64_t n_pix, float *rgb,
+                                 float *dep, int64_t *sem, mnf_stream_t stream) {
+    if (n_pix == 0) return MNF_OK;
+    MNF_REQUIRE(images && depths && semantics && image_id && pix_idx && rgb && dep && sem && pixels_per_image > 0, "gather_pixels: bad arguments");
+    hipLaunchKernelGGL(gather_pixels_kernel, dim3(grid_for(n_pix, 256)), dim3(256), 0, as_stream(stream), images, depths, depth_is_f16, semantics,
+                       sem_is_u8, pixels_per_image, image_id, pix_idx, n_pix, rgb, dep, sem);
+    return launch_status("gather_pixels_kernel");
 }
 
 extern "C" int mnf_planner_map(const uint8_t *binaries, int32_t n_members, int32_t res_x, int32_t res_y, int32_t res_z,

@@ -19,8 +19,15 @@ class Dataset(torch.utils.data.Dataset):
     """Gathered dataset (habitat_to_data.py:30-302)."""
 
     def __init__(self, training: bool, save_fp: str, num_rays: int = None, batch_over_images: bool = True,
-                 num_models: int = 1, device: str = "cpu"):
+                 num_models: int = 1, device: str = "cpu", packed: bool = False, use_bootstrap_index: bool = False):
+        """`packed=True` keeps depths as fp16 and class ids as uint8 on the device (3 + 2 + 1 = 6 B per pixel instead of
+        3 + 4 + 8 = 15 B; Habitat class ids are < 256 and depths are metres with ~1e-3 relative fp16 error) — the batches it
+        hands out keep the reference dtypes (f32 / f32 / i64).  `use_bootstrap_index=True` makes a TRAINING fetch use the
+        image `index` it is given (what scripts/pipeline.py:423-434 computes from the member's bootstrap set) instead of
+        drawing an image from the whole set, which is what the reference does and which makes its bootstrap sets
+        ineffective (habitat_to_data.py:209-215); default False = reference behaviour."""
         super().__init__()
+        self.packed, self.use_bootstrap_index = packed, use_bootstrap_index
         self.num_rays = num_rays
         self.batch_over_images = batch_over_images
         self.num_models = num_models
@@ -40,8 +47,11 @@ class Dataset(torch.utils.data.Dataset):
     def update_data(self, images, depths, semantics, camtoworlds):
         """habitat_to_data.py:89-153 (uint8 images [N,H,W,C], f32 depths, int64 semantics, f32 poses, on device)."""
         new_images = torch.from_numpy(np.asarray(images)).to(torch.uint8).to(self.device)
-        new_depths = torch.from_numpy(np.asarray(depths)).to(torch.float32).to(self.device)
-        new_sems = torch.from_numpy(np.asarray(semantics).astype(np.int64)).to(self.device)
+        new_depths = torch.from_numpy(np.asarray(depths)).to(torch.float16 if self.packed else torch.float32).to(self.device)
+        sem_np = np.asarray(semantics)
+        if self.packed and (sem_np.min() < 0 or sem_np.max() > 255):
+            raise ValueError("packed dataset layout stores class ids as uint8: ids must be in [0, 255]")
+        new_sems = torch.from_numpy(sem_np.astype(np.uint8 if self.packed else np.int64)).to(self.device)
         new_c2w = torch.from_numpy(np.asarray(camtoworlds)).to(torch.float32).to(self.device)
         for i, arr in enumerate(self.bootstrap_indices):
             ids = np.random.choice(len(images), size=(int(len(images) * self.boot_scale),), replace=True)
@@ -93,6 +103,8 @@ class Dataset(torch.utils.data.Dataset):
         if self.training:
             num_rays = self.num_rays
             image_id = torch.randint(0, self.size, size=(1,), device=self.device)
+            if self.use_bootstrap_index:
+                image_id = torch.tensor([int(index)], device=self.device)
             x = torch.randint(0, W, size=(num_rays,), device=self.device)
             y = torch.randint(0, H, size=(num_rays,), device=self.device)
             # same random pixels, grouped by 32x32 image block: the batch is a set (every loss is a mean over rays), and
@@ -103,12 +115,17 @@ class Dataset(torch.utils.data.Dataset):
             image_id = torch.tensor([index], device=self.device)
             x, y = torch.meshgrid(torch.arange(W, device=self.device), torch.arange(H, device=self.device), indexing="xy")
             x, y = x.flatten(), y.flatten()
-        rgb = self.images[image_id, y, x] / 255.0
-        dep = self.depths[image_id, y, x]
-        sem = self.semantics[image_id, y, x]
         c2w = self.camtoworlds[image_id][:, :3, :4].contiguous()
         pix = (y * W + x).to(torch.int64).contiguous()
         n = pix.shape[0]
+        # pixel gather (habitat_to_data.py:229-232) in one kernel, from either storage layout
+        L.require_gpu(self.images, self.depths, self.semantics)
+        rgb = torch.empty(n, 3, device=self.device)
+        dep = torch.empty(n, device=self.device)
+        sem = torch.empty(n, dtype=torch.int64, device=self.device)
+        L.launch(L.load_library().mnf_gather_pixels, L.ptr(self.images), L.ptr(self.depths), int(self.depths.dtype == torch.float16),
+                 L.ptr(self.semantics), int(self.semantics.dtype == torch.uint8), H * W, L.ptr(image_id.to(torch.int64)), L.ptr(pix), n,
+                 L.ptr(rgb), L.ptr(dep), L.ptr(sem))
         origins = torch.empty(1, n, 3, device=self.device)
         viewdirs = torch.empty(1, n, 3, device=self.device)
         L.require_gpu(c2w, pix)

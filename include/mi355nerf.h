@@ -191,6 +191,14 @@ int mnf_generate_rays(const float *c2w, int32_t n_views, int32_t width, int32_t 
                       const int64_t *pix_idx, int64_t n_pix, float *origins, float *viewdirs,
                       mnf_stream_t stream);
 
+/* Dataset.fetch_data's pixel gather (habitat_to_data.py:229-232) for ONE image: rgb [n,3] f32 = images[id, pix] / 255.0,
+ * dep [n] f32, sem [n] i64 at the flat pixel indices pix_idx (y * W + x).  images [N,H,W,3] u8; depths [N,H,W] f32
+ * (reference storage) or f16 (packed layout, depth_is_f16 = 1); semantics [N,H,W] i64 or u8 (sem_is_u8 = 1); image_id:
+ * ONE int64 on the device (the reference draws it with torch.randint on the device). */
+int mnf_gather_pixels(const uint8_t *images, const void *depths, int32_t depth_is_f16, const void *semantics, int32_t sem_is_u8,
+                      int64_t pixels_per_image, const int64_t *image_id, const int64_t *pix_idx, int64_t n_pix, float *rgb,
+                      float *dep, int64_t *sem, mnf_stream_t stream);
+
 /* ---------------------------------------------------------------- radiance field (tinycudann replacement) */
 
 typedef struct {

@@ -718,9 +718,7 @@ def test_dataset_matches_reference(golden, tmp_path):
     np.testing.assert_array_equal(ds.bootstrap(0), g["boot0"])
     np.testing.assert_array_equal(ds.bootstrap(1), g["boot1"])         # same np.random stream as the reference
     d = ds[2]                                                           # evaluation branch: image 2, all pixels
-    # uint8 / 255.0 is a torch op on the storage device: the GPU kernel multiplies by the reciprocal (1 ulp from the
-    # CPU golden's true division); the reference itself runs this on its CUDA device
-    np.testing.assert_allclose(d["pixels"].cpu().numpy(), g["pixels"], rtol=2e-7, atol=0)
+    np.testing.assert_array_equal(d["pixels"].cpu().numpy(), g["pixels"])      # mnf_gather_pixels divides by 255.0f exactly as the CPU golden
     np.testing.assert_array_equal(d["dep"].cpu().numpy(), g["dep"])
     np.testing.assert_array_equal(d["sem"].cpu().numpy(), g["sem"])
     np.testing.assert_array_equal(d["rays"].origins.cpu().numpy(), g["origins"])
@@ -732,12 +730,24 @@ def test_dataset_matches_reference(golden, tmp_path):
     t = ds[0]
     iid, x, y = int(t["image_id"].item()), t["x"].cpu().numpy(), t["y"].cpu().numpy()
     assert t["pixels"].shape == (500, 3) and t["rays"].origins.shape == (500, 3) and t["color_bkgd"].shape == (3,)
-    np.testing.assert_allclose(t["pixels"].cpu().numpy(), g["images"][iid, y, x].astype(np.float32) / 255.0, rtol=2e-7, atol=0)
+    np.testing.assert_array_equal(t["pixels"].cpu().numpy(), g["images"][iid, y, x].astype(np.float32) / np.float32(255.0))
     np.testing.assert_array_equal(t["dep"].cpu().numpy(), g["depths"][iid, y, x])
     np.testing.assert_array_equal(t["sem"].cpu().numpy(), g["sems"][iid, y, x])
     ds.training = False
     full = ds[iid]
     np.testing.assert_array_equal(t["rays"].viewdirs.cpu().numpy(), full["rays"].viewdirs.cpu().numpy()[y, x])
+    # packed on-device layout (u8 rgb / f16 depth / u8 class): same batches in the reference dtypes, depths to fp16
+    pk = Dataset(training=False, save_fp=str(tmp_path), num_models=2, device=DEV, packed=True)
+    pk.update_data(g["images"], g["depths"], g["sems"], g["c2w"])
+    assert pk.depths.dtype == torch.float16 and pk.semantics.dtype == torch.uint8 and pk.images.dtype == torch.uint8
+    dp = pk[2]
+    np.testing.assert_array_equal(dp["pixels"].cpu().numpy(), g["pixels"])
+    np.testing.assert_array_equal(dp["sem"].cpu().numpy(), g["sem"]); assert dp["sem"].dtype == torch.int64
+    np.testing.assert_array_equal(dp["dep"].cpu().numpy(), g["dep"].astype(np.float16).astype(np.float32)); assert dp["dep"].dtype == torch.float32
+    # bootstrap fix-forward flag: a training fetch uses the image it is asked for (default: a random one, as the reference)
+    bs = Dataset(training=True, save_fp=str(tmp_path), num_rays=64, num_models=2, device=DEV, use_bootstrap_index=True)
+    bs.update_data(g["images"], g["depths"], g["sems"], g["c2w"])
+    assert all(int(bs[k]["image_id"].item()) == k for k in (2, 0, 1, 2))
 
 
 def test_checkpoint_roundtrip_and_planner_map(scene, tmp_path):
@@ -1206,3 +1216,34 @@ def test_render_views_sharded_single_rank_and_row_tiles(scene, fields):
     assert (sh["tiles_per_view"], sh["lo"], sh["hi"], sh["unit_rays"]) == (4, 2, 3, 64)
     tile = RD.render_views(hip, est, o[128:192].contiguous(), d[128:192].contiguous(), 64, 1024, render_bkgd=bk, **H.RENDER_KW)
     np.testing.assert_allclose(tile["rgb"].cpu().numpy(), b["rgb"][128:192].cpu().numpy(), atol=2e-3)   # schedule differs, values agree
+
+
+def test_checkpoint_fixture_hand_computed_density():
+    """f2: a checkpoint in the reference's key layout written by tests/golden/make_checkpoint_fixture.py (which imports neither
+    the product nor the oracle) loads through `dataset.load_checkpoint`, and the density it yields is the HAND-COMPUTED one
+    (exp(-0.5) inside the box, 0 outside): pins the in-vector layout the library assumes for tcnn's flat `params`
+    (network before table, [out][in] row-major, density = output row 0) against an independent statement of it."""
+    import os
+    from apnrf_amd import dataset as DS
+    from apnrf_amd.nerfacc import OccGridEstimator
+    from apnrf_amd.ngp import NGPRadianceField
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint_fixture.pth")
+    ck = torch.load(path, map_location="cpu")
+    assert {"occ_grid", "model", "optimizer_state_dict"} <= set(ck)
+    cfg = ck["expected"]["config"]
+    field = NGPRadianceField(aabb=ck["model"]["aabb"], **cfg).to(DEV)
+    est = OccGridEstimator(ck["model"]["aabb"], resolution=list(ck["occ_grid"].shape[1:])).to(DEV)
+    opt = torch.optim.Adam(field.parameters(), lr=1e-3, eps=1e-15)
+    DS.load_checkpoint(path, est, field, opt, map_location=DEV)
+    assert torch.equal(est.binaries.cpu(), ck["occ_grid"]) and int(est.binaries.sum()) == 6
+    dens = field.query_density(ck["expected"]["points"].to(DEV)).cpu()[:, 0]
+    np.testing.assert_allclose(dens.numpy(), ck["expected"]["density"].numpy(), rtol=2e-3, atol=1e-7)     # 1/(j+1) is rounded to fp16
+    with torch.no_grad():
+        rgb, sigma, sem = field(ck["expected"]["points"].to(DEV), torch.tensor([[0.0, 0.0, 1.0]] * 3, device=DEV))
+    np.testing.assert_allclose(sigma.cpu().numpy()[:, 0], ck["expected"]["density"].numpy(), rtol=2e-3, atol=1e-7)
+    assert sem.shape == (3, 5) and bool(torch.isfinite(rgb).all())
+    # the oracle's reading of the same vectors agrees (it is the other consumer of this layout)
+    sc = dict(aabb=ck["model"]["aabb"].numpy(), params={k.split(".")[0]: v.numpy() for k, v in ck["model"].items() if k.endswith("params") and v.numel()},
+              C=cfg["num_semantic_classes"], **{k: cfg[k] for k in ("neurons", "layers", "log2_hashmap_size")})
+    o_d = H.oracle_field(sc).query_density(ck["expected"]["points"])[:, 0]
+    np.testing.assert_allclose(o_d.numpy(), ck["expected"]["density"].numpy(), rtol=2e-3, atol=1e-7)
