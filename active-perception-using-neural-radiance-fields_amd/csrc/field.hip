@@ -192,10 +192,12 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     using T = TrainLayout<W, NH>;
     constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
     __shared__ half8 s_w[kBlocks * 64];
+    __shared__ half_t s_stage[SAVE ? kWavesPerBlock * kStageHalves : 1];   // training: per-wave transpose tile of the activation dump
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
+    half_t *stage = s_stage + (SAVE ? wave * kStageHalves : 0);
 
     int64_t n = args.io.n;
     if (MODE == 2) { n = *args.io.n_dev; if (n > args.io.n_cap) n = args.io.n_cap; }
@@ -300,18 +302,11 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #endif
         }
 
-        // column of tile ct held by this lane in MFMA layout, and the mask-dump base of this tile
-        SaveOff so[CT];
-        if (SAVE) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(h, (lane & 31) + 32 * ct);
-        }
+        // the mask-dump base of this tile
         uint8_t *mdump = SAVE ? args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
         if (SAVE) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) save_rows<false>(args.train, tile, T::rX + 16 * ks, so[ct], bfeat[ct][ks]);
+            for (int ks = 0; ks < 4; ++ks) save_pair<false>(args.train, tile, T::rX + 16 * ks, lane, stage, bfeat[0][ks], bfeat[1][ks]);
         }
 
         // ---- base MLP ----
@@ -319,12 +314,11 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         dense_relu<L::RT, 4>(s_w + L::o_b_in * 64, lane, bfeat, hb);
         if (SAVE) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int k = 0; k < L::KSW; ++k) {
+                save_pair<true>(args.train, tile, T::rH0 + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
-                for (int k = 0; k < L::KSW; ++k) {
-                    save_rows<true>(args.train, tile, T::rH0 + 16 * k, so[ct], hb[ct][k]);
-                    mdump[((T::mH0 + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
-                }
+                for (int ct = 0; ct < CT; ++ct) mdump[((T::mH0 + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
+            }
         }
 #pragma unroll
         for (int l = 0; l < NH - 1; ++l) {
@@ -336,12 +330,11 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 for (int k = 0; k < L::KSW; ++k) hb[ct][k] = hn[ct][k];
             if (SAVE) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
+                for (int k = 0; k < L::KSW; ++k) {
+                    save_pair<true>(args.train, tile, T::rH0 + (l + 1) * W + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
-                    for (int k = 0; k < L::KSW; ++k) {
-                        save_rows<true>(args.train, tile, T::rH0 + (l + 1) * W + 16 * k, so[ct], hb[ct][k]);
-                        mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
-                    }
+                    for (int ct = 0; ct < CT; ++ct) mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
+                }
             }
         }
         f32x16 bo[CT];
@@ -376,22 +369,18 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             hin[0][1] = bgeo[0][0]; hin[1][1] = bgeo[1][0];
         }
         if (SAVE) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                save_rows<false>(args.train, tile, T::rS, so[ct], hin[ct][0]);
-                save_rows<true>(args.train, tile, T::rG, so[ct], hin[ct][1]);
-            }
+            save_pair<false>(args.train, tile, T::rS, lane, stage, hin[0][0], hin[1][0]);
+            save_pair<true>(args.train, tile, T::rG, lane, stage, hin[0][1], hin[1][1]);
         }
         half8 h1[CT][L::KSh], h2[CT][L::KSh];
         f32x16 out_rgb[CT], out_sem[CT];
         auto save_hidden = [&](const half8 (&a)[CT][L::KSh], int row0, int mblk) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int k = 0; k < L::KSh; ++k) {
+                save_pair<true>(args.train, tile, row0 + 16 * k, lane, stage, a[0][k], a[1][k]);
 #pragma unroll
-                for (int k = 0; k < L::KSh; ++k) {
-                    save_rows<true>(args.train, tile, row0 + 16 * k, so[ct], a[ct][k]);
-                    mdump[((mblk + k) * CT + ct) * 64] = frag_mask(a[ct][k]);
-                }
+                for (int ct = 0; ct < CT; ++ct) mdump[((mblk + k) * CT + ct) * 64] = frag_mask(a[ct][k]);
+            }
         };
         // rgb head (ngp.py:143-156, :202-213)
         dense_relu<L::RTh, 2>(s_w + L::o_h_in * 64, lane, hin, h1);

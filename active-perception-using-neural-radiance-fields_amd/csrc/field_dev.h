@@ -108,28 +108,50 @@ struct KernelArgs {
 __device__ __forceinline__ int feat_natural(int h, int j) { return 8 * h + j; }
 __device__ __forceinline__ int feat_acc(int h, int j) { return 8 * (j >> 2) + 4 * h + (j & 3); }
 
-// Store one B fragment into the activation matrix.  Layout (tile-major): ACT[tile][row][64 samples] fp16, i.e. for
-// one 64-sample tile all `rows` feature rows are contiguous 128-byte lines — the weight-gradient GEMM then reads the
-// 32 rows of an operand tile as one contiguous 4 KB block.  The part of the address that does not depend on the lane
-// (tile, and row0 + 8*(j>>2) + (j&3) or row0 + j) is a scalar base; the lane part (column within the tile and the
-// 4h / 8h row offset of the lane half) is one 32-bit byte offset, so every store is
-// `global_store_short v_off, v_data, s[base]` with no 64-bit VGPR address.
-struct SaveOff {
-    uint32_t acc, nat;   // byte offsets for accumulator-order and natural-order fragments
-};
-__device__ __forceinline__ SaveOff save_offsets(int h, int col_in_tile) {
-    SaveOff o;
-    o.acc = (uint32_t)((col_in_tile + 4 * h * 64) * 2);
-    o.nat = (uint32_t)((col_in_tile + 8 * h * 64) * 2);
-    return o;
-}
+// Store the two column-tile fragments of one 16-row group (16 features x 64 samples) into the activation matrix.
+// Layout (tile-major): ACT[tile][row][64 samples] fp16, i.e. for one 64-sample tile all `rows` feature rows are contiguous
+// 128-byte lines — the weight-gradient GEMM then reads the 32 rows of an operand tile as one contiguous 4 KB block.
+// A lane holds 8 FEATURES of one sample, the matrix wants 8 SAMPLES of one feature next to each other, so the group is
+// transposed on the way out: neighbouring lanes (samples c, c+1) first trade one half of every register (one DPP move and
+// one byte permute), so that each lane owns a (row, 2 adjacent samples) dword; those go into this wave's 2 KB LDS tile
+// [16 rows][64 samples], which is read back as 16-byte pieces and leaves as two `global_store_dwordx4` per lane (2 KB
+// contiguous per group).  Before: 16 `global_store_short` per group — the stores, not the bytes, cost 0.6 ms of the 1.3 ms
+// training forward and 0.5 ms of the backward-data kernel (MNF_EXP_SAVE experiments).
+constexpr int kStageHalves = 8 * 64;     // per-wave staging tile: 8 rows x 64 samples (the 16-row group goes out in two passes)
+
+#ifndef MNF_EXP_SAVE
+#define MNF_EXP_SAVE 0      /* timing experiment only (results invalid): 1 = no activation stores */
+#endif
 template <bool ACC_ORDER>
-__device__ __forceinline__ void save_rows(const TrainBuf &tb, int64_t tile, int row0, const SaveOff &so, const half8 &frag) {
+__device__ __forceinline__ void save_pair(const TrainBuf &tb, int64_t tile, int row0, int lane, half_t *stage, const half8 &f0, const half8 &f1) {
+#if MNF_EXP_SAVE == 1
+    return;
+#endif
+    const int c = lane & 31, h = lane >> 5, odd = c & 1;
+    uint32_t *st32 = reinterpret_cast<uint32_t *>(stage);
+    const uint32_t sel = odd ? 0x03020706u : 0x05040100u;   // even lane: {own.lo, partner.lo}; odd lane: {partner.hi, own.hi}
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(stage);
+    char *gbase = reinterpret_cast<char *>(tb.act) + ((tile * tb.rows + row0) * 64) * 2;     // uniform: scalar base + lane offset
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int srow = row0 + (ACC_ORDER ? 8 * (j >> 2) + (j & 3) : j);   // uniform part of the row
-        char *base = reinterpret_cast<char *>(tb.act) + ((tile * tb.rows + srow) * 64) * 2;
-        *reinterpret_cast<half_t *>(base + (ACC_ORDER ? so.acc : so.nat)) = frag[j];
+    for (int q = 0; q < 2; ++q) {                           // rows 8q .. 8q+7 of the group
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const u32x4 d = __builtin_bit_cast(u32x4, ct ? f1 : f0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // accumulator order: register i holds rows 8 (i >> 1) + 4h + {2 (i & 1), 2 (i & 1) + 1}; natural order: rows 8h + {2i, 2i + 1}
+                if (ACC_ORDER && (i >> 1) != q) continue;
+                const uint32_t own = d[i];
+                const uint32_t partner = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                const uint32_t packed = __builtin_amdgcn_perm(partner, own, sel);
+                const int j = 2 * i + odd;                                // the element whose row this lane now owns
+                const int rowl = ACC_ORDER ? 4 * h + (j & 3) : j;         // row inside this pass
+                if (ACC_ORDER || h == q) st32[(rowl * 64 + 32 * ct + (c & ~1)) >> 1] = packed;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<u32x4 *>(gbase + (q * 64 + lane) * 16) = src[lane];
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -72,22 +72,23 @@ __device__ __forceinline__ void dense_tile(const half8 *__restrict__ w_lds, int 
 template <int RT_OUT, int KS>
 __device__ __forceinline__ void dense_mask(const half8 *__restrict__ w_lds, int lane, int h, const half8 (&b)[CT][KS],
                                            const uint8_t *__restrict__ masks, const TrainBuf &tb, int64_t tile, int row0,
-                                           const SaveOff (&so)[CT], half8 (&o)[CT][RT_OUT * 2]) {
+                                           half_t *stage, half8 (&o)[CT][RT_OUT * 2]) {
 #pragma unroll
     for (int rt = 0; rt < RT_OUT; ++rt) {
         f32x16 acc[CT];
         dense_tile<KS>(w_lds + rt * KS * 64, lane, b, acc);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int ct = 0; ct < CT; ++ct) {
                 const uint32_t m = masks[((rt * 2 + s) * CT + ct) * 64];
                 half8 v;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = ((m >> frag_mask_bit(j)) & 1u) ? (half_t)acc[ct][8 * s + j] : (half_t)0.0f;
                 o[ct][rt * 2 + s] = v;
-                save_rows<true>(tb, tile, row0 + 16 * (rt * 2 + s), so[ct], v);
             }
+            save_pair<true>(tb, tile, row0 + 16 * (rt * 2 + s), lane, stage, o[0][rt * 2 + s], o[1][rt * 2 + s]);
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep the row-tile iterations from interleaving (register pressure)
     }
 }
@@ -97,7 +98,9 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
     using L = LayoutT<W, NH>;
     using T = TrainLayout<W, NH>;
     __shared__ half8 s_w[L::blocks * 64];
+    __shared__ half_t s_stage[kWavesPerBlock * kStageHalves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+    half_t *stage = s_stage + wave * kStageHalves;
     const int64_t n = args.n;
     const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
     if ((int64_t)blockIdx.x * kWavesPerBlock >= n_tiles) return;
@@ -107,9 +110,6 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
 
     for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWavesPerBlock) {
         const int64_t fcol0 = tile * kWaveSamples + c;
-        SaveOff so[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) so[ct] = save_offsets(h, c + 32 * ct);
         const uint8_t *mdump = args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane;
         // ---- output-layer gradients, built directly as natural-order B fragments ----
         half8 dyr[CT][1], dys[CT][2];
@@ -136,18 +136,18 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
                 }
             // trunc_exp backward (ngp.py:34-39): g * exp(min(x, 15)) with exp(x) = sigma (0 outside the aabb)
             dlogit[ct] = ok ? args.d_sigma[col] * fminf(args.sigma[col], 3269017.3724721107f) * ls : 0.0f;
-            save_rows<false>(args.train, tile, T::rdYr, so[ct], dyr[ct][0]);
-            save_rows<false>(args.train, tile, T::rdYs, so[ct], dys[ct][0]);
-            save_rows<false>(args.train, tile, T::rdYs + 16, so[ct], dys[ct][1]);
         }
+        save_pair<false>(args.train, tile, T::rdYr, lane, stage, dyr[0][0], dyr[1][0]);
+        save_pair<false>(args.train, tile, T::rdYs, lane, stage, dys[0][0], dys[1][0]);
+        save_pair<false>(args.train, tile, T::rdYs + 16, lane, stage, dys[0][1], dys[1][1]);
         // ---- heads ----
         half8 dz2[CT][L::KSh], dz1[CT][L::KSh];
         f32x16 dgeo_r[CT], dgeo_s[CT];
-        dense_mask<L::RTh, 1>(s_w + L::o_r3 * 64, lane, h, dyr, mdump + T::mHH2 * CT * 64, args.train, tile, T::rdZr2, so, dz2);
-        dense_mask<L::RTh, L::KSh>(s_w + L::o_r2 * 64, lane, h, dz2, mdump + T::mHH1 * CT * 64, args.train, tile, T::rdZr1, so, dz1);
+        dense_mask<L::RTh, 1>(s_w + L::o_r3 * 64, lane, h, dyr, mdump + T::mHH2 * CT * 64, args.train, tile, T::rdZr2, stage, dz2);
+        dense_mask<L::RTh, L::KSh>(s_w + L::o_r2 * 64, lane, h, dz2, mdump + T::mHH1 * CT * 64, args.train, tile, T::rdZr1, stage, dz1);
         dense_tile<L::KSh>(s_w + L::o_r1 * 64, lane, dz1, dgeo_r);
-        dense_mask<L::RTh, 2>(s_w + L::o_s3 * 64, lane, h, dys, mdump + T::mHS2 * CT * 64, args.train, tile, T::rdZs2, so, dz2);
-        dense_mask<L::RTh, L::KSh>(s_w + L::o_s2 * 64, lane, h, dz2, mdump + T::mHS1 * CT * 64, args.train, tile, T::rdZs1, so, dz1);
+        dense_mask<L::RTh, 2>(s_w + L::o_s3 * 64, lane, h, dys, mdump + T::mHS2 * CT * 64, args.train, tile, T::rdZs2, stage, dz2);
+        dense_mask<L::RTh, L::KSh>(s_w + L::o_s2 * 64, lane, h, dz2, mdump + T::mHS1 * CT * 64, args.train, tile, T::rdZs1, stage, dz1);
         dense_tile<L::KSh>(s_w + L::o_s1 * 64, lane, dz1, dgeo_s);
         // ---- base output gradient: geo rows from both heads, row 0 = density logit ----
         half8 dbo[CT][1];
@@ -156,17 +156,17 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
 #pragma unroll
             for (int j = 0; j < 8; ++j) dbo[ct][0][j] = (half_t)(dgeo_r[ct][j] + dgeo_s[ct][j]);
             if (h == 0) dbo[ct][0][0] = sat_half(dlogit[ct]);
-            save_rows<true>(args.train, tile, T::rdBO, so[ct], dbo[ct][0]);
         }
+        save_pair<true>(args.train, tile, T::rdBO, lane, stage, dbo[0][0], dbo[1][0]);
         // ---- base MLP ----
         half8 dz[CT][L::KSW];
         dense_mask<L::RT, 1>(s_w + L::o_bo * 64, lane, h, dbo, mdump + (T::mH0 + (NH - 1) * L::KSW) * CT * 64, args.train, tile,
-                             T::rdZ0 + (NH - 1) * W, so, dz);
+                             T::rdZ0 + (NH - 1) * W, stage, dz);
 #pragma unroll
         for (int l = NH - 2; l >= 0; --l) {
             half8 dn[CT][L::KSW];
             dense_mask<L::RT, L::KSW>(s_w + (L::o_bh + l * L::RT * L::KSW) * 64, lane, h, dz, mdump + (T::mH0 + l * L::KSW) * CT * 64,
-                                      args.train, tile, T::rdZ0 + l * W, so, dn);
+                                      args.train, tile, T::rdZ0 + l * W, stage, dn);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
