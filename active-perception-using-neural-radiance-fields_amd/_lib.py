@@ -87,6 +87,8 @@ SIGNATURES = {
     "mnf_field_density": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_field_forward_samples": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_field_density_rays": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
+                                         c_float, c_void_p, c_void_p]),
     "mnf_vanilla_create": (c_int32, [POINTER(VanillaConfig), POINTER(c_void_p)]),
     "mnf_vanilla_destroy": (c_int32, [c_void_p]),
     "mnf_vanilla_param_count": (c_int64, [c_void_p]),

@@ -34,6 +34,7 @@ struct mnf_field_s {
     void *d_table;       // fp16 [table_entries][4]
     void *d_frags;       // fp16 fragment-ordered MLP weights, blocks_total KiB
     int32_t *d_frag_src; // gather table: (buffer << 28) | index, or -1 for a structural zero
+    int32_t *d_counter;  // work counter of the ray-major density pass (lazily allocated)
     bool params_loaded;
     std::vector<int32_t> frag_src_host;   // host copy of the gather table (train.hip inverts it: parameter -> fragment slot)
     void *train_state;        // lazily built by train.hip (transposed fragments, weight-gradient job table)
@@ -55,7 +56,7 @@ struct FusedRender {
 };
 
 // What the fused kernel reads / writes.  mode 0: explicit positions+directions; mode 1: packed samples
-// with int64 ray indices; mode 2: renderer columns (int32 ray id, -1 = unused column).
+// with int64 ray indices; mode 2: renderer columns (int32 ray id, -1 = unused column); mode 3: mode 1 walked ray-major.
 struct FieldIO {
     int mode;
     const float *positions, *directions;     // mode 0
@@ -66,6 +67,11 @@ struct FieldIO {
     int64_t n;                               // modes 0, 1
     const int32_t *n_dev;                    // mode 2: number of columns (device)
     int64_t n_cap;                           // mode 2: capacity of the column arrays (the device count is clamped to it)
+    // mode 3: packed samples walked ray by ray (ray_idx64 / t_starts / t_ends as mode 1) with early termination
+    const int64_t *chunk_starts, *chunk_cnts;
+    int32_t n_rays;
+    int32_t *ray_counter;
+    float sdt_stop;                          // stop a ray once its accumulated sigma * dt exceeds this
     const void *enc;                         // optional [ceil(n/64)][8][64] x 16 B feature scratch: non-null selects the
                                              // two-launch path (encode_kernel, then the MLP kernel on its output)
     // outputs: user layout (modes 0,1) ...

@@ -73,12 +73,13 @@ __device__ __forceinline__ void fetch_sample(const KernelArgs &args, const ColDa
 #pragma unroll
                 for (int d = 0; d < 3; ++d) dir[d] = args.io.directions[3 * col + d];
         }
-    } else if (MODE == 1) {
+    } else if (MODE == 1 || MODE == 3) {
         int64_t ray = -1;
         if (valid) ray = args.io.ray_idx64[col];
         valid = ray >= 0;
         if (valid) {
-            const float tsum = args.io.t_starts[col] + args.io.t_ends[col];
+            tsm.ts = args.io.t_starts[col]; tsm.te = args.io.t_ends[col];
+            const float tsum = tsm.ts + tsm.te;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 dir[d] = args.io.rays_d[3 * ray + d];
@@ -203,10 +204,10 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     if (MODE == 2) { n = *args.io.n_dev; if (n > args.io.n_cap) n = args.io.n_cap; }
     const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
     if (n_tiles == 0) return;
-    const int wpb = args.active_waves;
+    const int wpb = MODE == 3 ? kWavesPerBlock : args.active_waves;
     const int64_t n_groups = (n_tiles + wpb - 1) / wpb;
-    int64_t g_first, g_end, g_step;
-    group_range(n_groups, g_first, g_end, g_step);
+    int64_t g_first = 0, g_end = 1, g_step = 1;
+    if (MODE != 3) group_range(n_groups, g_first, g_end, g_step);
     if (g_first >= g_end) return;   // uniform per block: nothing to do
 
     for (int i = threadIdx.x; i < kBlocks * 64; i += kThreads) s_w[i] = args.frags[i];
@@ -219,17 +220,36 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #endif
 
     WaveCounters wc;
-    for (int64_t grp = g_first; grp < g_end; grp += g_step) {
-        const int64_t tile = grp * wpb + wave;
-        if (tile >= n_tiles) break;
+    // MODE 3 (ray-major density pass, `mnf_field_density_rays`): a wave takes whole rays (dynamically, one atomic per ray)
+    // and walks a ray's samples front to back in 64-sample steps; once the optical depth accumulated so far makes every
+    // later sample invisible (transmittance below early_stop_eps / 2) the rest of the ray is skipped — its densities stay
+    // at the zeros the entry point filled in, which leaves the visibility mask (volrend.py:424-483) unchanged.
+    int64_t ray_start = 0, ray_cnt = 0, ray_base = 0;
+    float ray_sdt = 0.0f;
+    for (int64_t grp = g_first; MODE == 3 || grp < g_end; grp += g_step) {
+        int64_t tile = grp * wpb + wave, col, n_eff = n;
+        if (MODE == 3) {
+            if (ray_base >= ray_cnt || ray_sdt > args.io.sdt_stop) {
+                int r = 0;
+                if (lane == 0) r = atomicAdd(args.io.ray_counter, 1);
+                r = __builtin_amdgcn_readfirstlane(r);
+                if (r >= args.io.n_rays) break;
+                ray_start = args.io.chunk_starts[r]; ray_cnt = args.io.chunk_cnts[r]; ray_base = 0; ray_sdt = 0.0f;
+                if (ray_cnt == 0) continue;
+            }
+            col = ray_start + ray_base + lane; n_eff = ray_start + ray_cnt; ray_base += kWaveSamples;
+            tile = 0;
+        } else {
+            if (tile >= n_tiles) break;
+            col = tile * kWaveSamples + lane;
+        }
         // ---- this lane's sample ----
-        const int64_t col = tile * kWaveSamples + lane;
         ColData cd = {-1, 64, 0.f, 0.f};
         if (MODE == 2) cd = load_cols(args, tile, lane);
         float xn[3], dir[3];
         TileSample tsm;
         bool valid, selector;
-        fetch_sample<MODE, !DENSITY_ONLY>(args, cd, col, n, xn, dir, tsm, valid, selector);
+        fetch_sample<MODE, !DENSITY_ONLY>(args, cd, col, n_eff, xn, dir, tsm, valid, selector);
         const LevelMeta *lv = levels_here(args.levels);
         const bool in_box = __ballot(valid && !selector) == 0ull;   // wave-uniform: the cheap dense-level wrap applies
 
@@ -348,7 +368,13 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         const float sigma = selector ? expf((h ? logit_t1 : logit_t0) - 1.0f) : 0.0f;   // ngp.py:79, :193-195
 
         if (DENSITY_ONLY) {
-            if (col < n && args.io.density) args.io.density[col] = sigma;
+            if (col < n_eff && args.io.density) args.io.density[col] = sigma;
+            if (MODE == 3) {
+                float sdt = valid ? sigma * (tsm.te - tsm.ts) : 0.0f;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) sdt += __shfl_xor(sdt, d, 64);
+                ray_sdt += sdt;
+            }
             continue;
         }
 
@@ -578,7 +604,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
             else hipLaunchKernelGGL((field_kernel<W, NH, 2, false, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
         }
     } else if (density_only) {
-        if (io.mode == 0) MNF_LAUNCH(0, true); else if (io.mode == 1) MNF_LAUNCH(1, true); else MNF_LAUNCH(2, true);
+        if (io.mode == 0) MNF_LAUNCH(0, true); else if (io.mode == 1) MNF_LAUNCH(1, true); else if (io.mode == 3) MNF_LAUNCH(3, true); else MNF_LAUNCH(2, true);
     } else {
         if (io.mode == 0) MNF_LAUNCH(0, false); else if (io.mode == 1) MNF_LAUNCH(1, false); else MNF_LAUNCH(2, false);
     }
@@ -589,7 +615,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
 int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train) {
     MNF_REQUIRE(f && f->params_loaded, "field: parameters not loaded (call mnf_field_set_params first)");
     int grid = 256;  // one persistent workgroup per CU (LDS-limited), grid-stride over 64-sample tiles
-    if (io.mode != 2) {
+    if (io.mode != 2 && io.mode != 3) {
         const int64_t tiles = ceil_div(io.n, kWaveSamples);
         if (tiles == 0) return MNF_OK;
         const int64_t wgs = ceil_div(tiles, kWavesPerBlock);
@@ -633,7 +659,7 @@ extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
     std::vector<int32_t> table = build_frag_table(*cfg);
     f->shape = {W, NH, Wh, cfg->num_semantic_classes, (int)(table.size() / 512)};
     f->frag_src_host = table;
-    f->d_table = nullptr; f->d_frags = nullptr; f->d_frag_src = nullptr; f->params_loaded = false;
+    f->d_table = nullptr; f->d_frags = nullptr; f->d_frag_src = nullptr; f->params_loaded = false; f->d_counter = nullptr;
     f->train_state = nullptr;
     hipError_t e = hipMalloc(&f->d_table, (size_t)f->table_entries * 4 * sizeof(uint16_t) );
     if (e == hipSuccess) e = hipMalloc(&f->d_frags, table.size() * sizeof(uint16_t) + sizeof(LevelMeta) * 16);
@@ -655,6 +681,7 @@ extern "C" int mnf_field_destroy(mnf_field_t f) {
     if (f->d_table) (void)hipFree(f->d_table);
     if (f->d_frags) (void)hipFree(f->d_frags);
     if (f->d_frag_src) (void)hipFree(f->d_frag_src);
+    if (f->d_counter) (void)hipFree(f->d_counter);
     delete f;
     return MNF_OK;
 }
@@ -727,4 +754,24 @@ extern "C" int mnf_field_forward_samples(mnf_field_t f, const float *rays_o, con
     io.rgb = rgb; io.density = density; io.sem = sem;
     const bool density_only = (rgb == nullptr && sem == nullptr);
     return launch_field(f, io, density_only, as_stream(stream));
+}
+
+extern "C" int mnf_field_density_rays(mnf_field_t f, const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                                      const float *t_starts, const float *t_ends, const int64_t *chunk_starts, const int64_t *chunk_cnts,
+                                      int32_t n_rays, int64_t n_samples, float early_stop_eps, float *density, mnf_stream_t stream) {
+    MNF_REQUIRE(f, "field_density_rays: null handle");
+    MNF_REQUIRE(n_rays >= 0 && n_samples >= 0, "field_density_rays: negative size");
+    if (n_samples == 0 || n_rays == 0) return MNF_OK;
+    MNF_REQUIRE(rays_o && rays_d && ray_indices && t_starts && t_ends && chunk_starts && chunk_cnts && density, "field_density_rays: null pointer");
+    hipStream_t s = as_stream(stream);
+    if (!f->d_counter) MNF_HIP(hipMalloc((void **)&f->d_counter, 256));
+    MNF_HIP(hipMemsetAsync(f->d_counter, 0, sizeof(int32_t), s));
+    MNF_HIP(hipMemsetAsync(density, 0, (size_t)n_samples * sizeof(float), s));
+    FieldIO io = {};
+    io.mode = 3; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = ray_indices; io.t_starts = t_starts; io.t_ends = t_ends; io.n = n_samples;
+    io.chunk_starts = chunk_starts; io.chunk_cnts = chunk_cnts; io.n_rays = n_rays; io.ray_counter = f->d_counter;
+    // skip what lies behind T < eps / 2: the factor 2 keeps the decision clear of the rounding of any other summation order
+    io.sdt_stop = early_stop_eps > 0.0f ? -logf(early_stop_eps) + 0.6931472f : INFINITY;
+    io.density = density;
+    return launch_field(f, io, true, s);
 }

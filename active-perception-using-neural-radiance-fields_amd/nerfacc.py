@@ -523,7 +523,13 @@ class OccGridEstimator(torch.nn.Module):
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             alpha_thre = min(alpha_thre, self.occs.mean().item())
             if sigma_fn is not None:
-                sigmas = sigma_fn(t_starts, t_ends, ray_indices) if t_starts.shape[0] != 0 else torch.empty((0,), device=t_starts.device)
+                if t_starts.shape[0] == 0:
+                    sigmas = torch.empty((0,), device=t_starts.device)
+                elif hasattr(sigma_fn, "ray_major") and early_stop_eps > 0.0:
+                    # the field's own density pass, ray by ray, without the samples behind T < early_stop_eps / 2 (same mask)
+                    sigmas = sigma_fn.ray_major(t_starts, t_ends, ray_indices, packed_info, early_stop_eps)
+                else:
+                    sigmas = sigma_fn(t_starts, t_ends, ray_indices)
                 assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
                 masks = render_visibility_from_density(t_starts=t_starts, t_ends=t_ends, sigmas=sigmas, packed_info=packed_info,
                                                        early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)

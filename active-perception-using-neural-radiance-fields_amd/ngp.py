@@ -76,6 +76,32 @@ class _FieldFunction(torch.autograd.Function):
         return None, None, None, g_base, g_head, g_s
 
 
+class RaySigmaFn:
+    """The `sigma_fn` closure of perception/models/utils.py:89-101 (`radiance_field.query_density(origins + dirs * t_mid)`) as
+    an object: called like the closure it evaluates every sample; `OccGridEstimator.sampling` recognises it and asks for the
+    ray-major form instead (`mnf_field_density_rays`), which leaves out the samples behind opaque surfaces — they cannot
+    pass the visibility test, so the returned sample set is the same."""
+
+    def __init__(self, radiance_field, rays_o, rays_d):
+        self.field, self.rays_o, self.rays_d = radiance_field, rays_o, rays_d
+
+    def __call__(self, t_starts, t_ends, ray_indices):
+        return self.field.forward_samples(self.rays_o, self.rays_d, ray_indices, t_starts, t_ends, density_only=True)[0]
+
+    @torch.no_grad()
+    def ray_major(self, t_starts, t_ends, ray_indices, packed_info, early_stop_eps: float):
+        f = self.field
+        h = f._ensure_handle()
+        L.require_gpu(self.rays_o, self.rays_d, ray_indices, t_starts, t_ends, packed_info)
+        o, d = L.contig(self.rays_o, torch.float32), L.contig(self.rays_d, torch.float32)
+        ri, ts, te = L.contig(ray_indices, torch.int64), L.contig(t_starts, torch.float32), L.contig(t_ends, torch.float32)
+        starts, cnts = (L.contig(x, torch.int64) for x in packed_info.unbind(-1))
+        sigma = torch.empty(ts.shape[0], device=o.device, dtype=torch.float32)
+        L.launch(L.load_library().mnf_field_density_rays, h, L.ptr(o), L.ptr(d), L.ptr(ri), L.ptr(ts), L.ptr(te), L.ptr(starts), L.ptr(cnts),
+                 starts.shape[0], ts.shape[0], float(early_stop_eps), L.ptr(sigma))
+        return sigma
+
+
 class NGPRadianceField(torch.nn.Module):
     """Instant-NGP radiance field with a semantic head (ngp.py:69-169)."""
 

@@ -201,8 +201,8 @@ def render_image_with_occgrid_with_depth_guide(radiance_field, estimator, rays: 
     for i in range(0, num_rays, chunk):
         co, cd = o[i:i + chunk], d[i:i + chunk]
 
-        def sigma_fn(t_starts, t_ends, ray_indices):
-            return radiance_field.forward_samples(co, cd, ray_indices, t_starts, t_ends, density_only=True)[0]
+        from .ngp import RaySigmaFn
+        sigma_fn = RaySigmaFn(radiance_field, co, cd)      # utils.py:89-101; lets `sampling` skip what lies behind opaque surfaces
 
         ray_indices, t_starts, t_ends = estimator.sampling(co, cd, sigma_fn=sigma_fn, near_plane=near_plane, far_plane=far_plane,
                                                            render_step_size=render_step_size, stratified=radiance_field.training,

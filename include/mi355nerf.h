@@ -242,6 +242,15 @@ int mnf_field_forward_samples(mnf_field_t f, const float *rays_o, const float *r
                               const int64_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                               float *rgb, float *density, float *sem, mnf_stream_t stream);
 
+/* The density pre-pass of `OccGridEstimator.sampling` (occ_grid.py:196-233: sigma_fn on every marched sample, then
+ * render_visibility_from_density) with the work behind opaque surfaces left out: samples are packed by ray
+ * (chunk_starts / chunk_cnts [n_rays] int64, as traverse_grids returns them); a ray is evaluated front to back and the
+ * rest of it is skipped once its transmittance has fallen below early_stop_eps / 2 — those samples fail the visibility
+ * test whatever their density, so `density` (zero there) yields the same mask.  early_stop_eps <= 0 evaluates everything. */
+int mnf_field_density_rays(mnf_field_t f, const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                           const float *t_starts, const float *t_ends, const int64_t *chunk_starts, const int64_t *chunk_cnts,
+                           int32_t n_rays, int64_t n_samples, float early_stop_eps, float *density, mnf_stream_t stream);
+
 /* ---------------------------------------------------------------- frequency-encoded MLP field (BASELINE config 1)
  * perception/models/radiance_fields/mlp.py: `VanillaNeRFRadianceField` (:206-245) = `SinusoidalEncoder` (:168-203, 10 degrees
  * on positions, 4 on directions, identity included) + `NerfMLP` (:113-165) of biased Linear + ReLU layers (:14-101), in

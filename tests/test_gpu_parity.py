@@ -1247,3 +1247,33 @@ def test_checkpoint_fixture_hand_computed_density():
               C=cfg["num_semantic_classes"], **{k: cfg[k] for k in ("neurons", "layers", "log2_hashmap_size")})
     o_d = H.oracle_field(sc).query_density(ck["expected"]["points"])[:, 0]
     np.testing.assert_allclose(o_d.numpy(), ck["expected"]["density"].numpy(), rtol=2e-3, atol=1e-7)
+
+
+def test_ray_major_density_prepass_gives_same_samples(scene):
+    """`OccGridEstimator.sampling` with the ray-major density pass (mnf_field_density_rays: the part of a ray behind
+    T < early_stop_eps / 2 is never evaluated) returns exactly the sample set of the reference formulation (sigma_fn on
+    every marched sample, then render_visibility_from_density), on a field dense enough that most rays saturate."""
+    from apnrf_amd.ngp import RaySigmaFn
+    sc = H.make_scene(log2_hashmap_size=15, seed=3)
+    sc["params"] = H.S.make_field_params(seed=3, log2_hashmap_size=15, density_gain=24.0)      # opaque quickly: long invisible tails
+    hip, est = H.hip_field(sc), H.hip_estimator(sc)
+    o, d = H.view_rays(sc, 2, h=40, w=40)
+    o, d = o.to(DEV), d.to(DEV)
+    fast = RaySigmaFn(hip, o, d)
+    plain = lambda ts, te, ri: hip.forward_samples(o, d, ri, ts, te, density_only=True)[0]
+    for eps, thre in ((1e-4, 0.01), (1e-2, 0.0), (1e-4, 0.0)):
+        a = est.sampling(o, d, sigma_fn=fast, near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=thre, early_stop_eps=eps)
+        b = est.sampling(o, d, sigma_fn=plain, near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=thre, early_stop_eps=eps)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+        assert a[0].shape[0] > 1000
+    # the pass really skips: densities behind the cut are the zeros of the initial fill, and there are many of them
+    n = o.shape[0]
+    near, far = torch.full((n,), 0.1, device=DEV), torch.full((n,), 1e10, device=DEV)
+    ri, ts, te, info = est._sample_single_pass(o, d, near, far, 1e-3, 0.004)
+    s_fast, s_all = fast.ray_major(ts, te, ri, info, 1e-4), plain(ts, te, ri)
+    skipped = (s_fast == 0) & (s_all > 0)
+    assert 0.03 < float(skipped.float().mean()) < 0.99
+    np.testing.assert_array_equal(s_fast[~skipped].cpu().numpy(), s_all[~skipped].cpu().numpy())
+    # early_stop_eps = 0 disables the cut
+    np.testing.assert_array_equal(fast.ray_major(ts, te, ri, info, 0.0).cpu().numpy(), s_all.cpu().numpy())
