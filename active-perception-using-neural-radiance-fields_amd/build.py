@@ -13,6 +13,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC]
 # march.hip / render.hip hold the bit-exact marcher: no FMA contraction (see csrc/march_dev.h)
+# value: (source file, extra flags); field / train are built twice: fp16 and bf16 matrix-core operands (csrc/common.h)
 SOURCES = {
     "api.cpp": [],
     "march.hip": ["-ffp-contract=off"],
@@ -22,6 +23,8 @@ SOURCES = {
     "composite_train.hip": [],
     "occupancy.hip": ["-ffp-contract=off"],
     "vanilla.hip": [],
+    "field.hip@bf16": ["-DMNF_BF16"],
+    "train.hip@bf16": ["-DMNF_BF16"],
 }
 
 
@@ -35,8 +38,9 @@ def _deps_mtime():
 
 
 def _compile(item):
-    src, extra = item
-    obj = os.path.join(OBJ, src + ".o")
+    key, extra = item
+    src = key.split("@")[0]
+    obj = os.path.join(OBJ, key.replace("@", "_") + ".o")
     cmd = ["hipcc"] + COMMON + extra + os.environ.get("MNF_EXTRA_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
     subprocess.check_call(cmd)
     return obj

@@ -8,6 +8,17 @@
 
 #include "mi355nerf.h"
 
+// The fused field kernels exist twice, once per matrix-core operand type: field.hip / train.hip are compiled as two
+// translation units (plain: fp16 operands, the reference's tcnn arithmetic; -DMNF_BF16: bf16 operands, BASELINE config 5) and
+// everything type-dependent lives in mnf::f16 / mnf::bf16.  The C entry points are compiled once and dispatch on the handle.
+#ifdef MNF_BF16
+#define MNF_DT bf16
+#else
+#define MNF_DT f16
+#endif
+#define MNF_DT_BEGIN namespace mnf { namespace MNF_DT {
+#define MNF_DT_END }}
+
 namespace mnf {
 
 void set_error(const char *fmt, ...);

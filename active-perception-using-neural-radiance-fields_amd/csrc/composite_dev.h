@@ -11,7 +11,7 @@
 #pragma once
 #include "field_dev.h"
 
-namespace mnf {
+MNF_DT_BEGIN
 
 // inclusive segmented scan over the 64 lanes of a wave; `head` marks the first lane of every segment
 // (`maxlen` = wave-uniform upper bound of the segment length: only ceil(log2(maxlen)) steps are needed)
@@ -274,4 +274,4 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
     }
 }
 
-}  // namespace mnf
+MNF_DT_END

@@ -80,8 +80,31 @@ struct FieldIO {
     FusedRender fr;
 };
 
-struct TrainBuf;
+// Training-time activation storage handed to the forward kernel (layout: field_dev.h, TrainLayout)
+struct TrainBuf {
+    void *act;        // [tiles][rows][64] 16-bit elements
+    uint8_t *masks;   // [tiles][mask_blocks][CT][64]
+    int64_t Np;
+    int32_t rows;
+};
+
+// dispatchers on the handle's operand type (defined once, in the fp16 translation units)
 void free_train_state(mnf_field_t f);
 int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train = nullptr);
+
+#define MNF_DECLARE_DT_IMPL(ns)                                                                                                      \
+    namespace ns {                                                                                                                   \
+    int launch_field_impl(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train);           \
+    int set_params_impl(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, hipStream_t stream);      \
+    void free_train_state_impl(mnf_field_t f);                                                                                       \
+    int64_t train_workspace_bytes_impl(mnf_field_t f, int64_t n);                                                                    \
+    int forward_train_impl(mnf_field_t f, const float *positions, const float *directions, int64_t n, float *rgb, float *density,   \
+                           float *sem, void *workspace, int64_t workspace_bytes, hipStream_t stream);                               \
+    int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float *d_rgb, const float *d_density,                 \
+                      const float *d_sem, const float *rgb, const float *density, void *workspace, int64_t workspace_bytes,         \
+                      float loss_scale, float *g_base, float *g_head, float *g_sem, hipStream_t stream);                            \
+    }
+MNF_DECLARE_DT_IMPL(f16)
+MNF_DECLARE_DT_IMPL(bf16)
 
 }  // namespace mnf

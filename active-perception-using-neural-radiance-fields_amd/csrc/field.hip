@@ -37,7 +37,7 @@
 #define MNF_NT_FROM 99      /* experiment: hash levels >= this are fetched with non-temporal loads */
 #endif
 
-namespace mnf {
+MNF_DT_BEGIN
 
 // ------------------------------------------------------------------ sample fetch (shared by the kernels below)
 // Position / direction of column `col`: mode 0 explicit arrays, mode 1 packed samples with int64 ray ids, mode 2 renderer
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
 #pragma unroll
         for (int l0 = 0; l0 < 16; l0 += LPB) {
             LevelPrep prep[LPB];
-            half4 v[LPB][8];
+            tab4 v[LPB][8];
 #pragma unroll
             for (int q = 0; q < LPB; ++q) {
                 hash_prep(lv[l0 + q], xn, prep[q], in_box);
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         } else {
             // double-buffered: the loads of batch kb+1 are issued before batch kb is blended
             LevelPrep prep[2][4];
-            half4 v[2][4][8];
+            tab4 v[2][4][8];
 #if MNF_EXP == 1
             __builtin_amdgcn_s_setprio(1);
 #elif MNF_EXP == 2 || MNF_EXP == 6 || MNF_EXP == 7
@@ -459,8 +459,8 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 }
 
 // ------------------------------------------------------------------ parameter preparation kernels
-__global__ void __launch_bounds__(256) table_to_half_kernel(const float *__restrict__ src, half_t *__restrict__ dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) dst[i] = (half_t)src[i];
+__global__ void __launch_bounds__(256) table_to_half_kernel(const float *__restrict__ src, tab_t *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) dst[i] = (tab_t)src[i];
 }
 
 __global__ void __launch_bounds__(256) gather_frags_kernel(const int32_t *__restrict__ src_idx, const float *__restrict__ p0,
@@ -575,7 +575,7 @@ template <int W, int NH>
 static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, int grid, hipStream_t stream, const TrainBuf *train) {
     KernelArgs a;
     a.train = train ? *train : TrainBuf{nullptr, nullptr, 0, 0};
-    a.table = reinterpret_cast<const half4 *>(f->d_table);
+    a.table = reinterpret_cast<const tab4 *>(f->d_table);
     a.frags = reinterpret_cast<const half8 *>(f->d_frags);
     std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));
     a.C = f->cfg.num_semantic_classes;
@@ -612,7 +612,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     return launch_status("field_kernel");
 }
 
-int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train) {
+int launch_field_impl(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train) {
     MNF_REQUIRE(f && f->params_loaded, "field: parameters not loaded (call mnf_field_set_params first)");
     int grid = 256;  // one persistent workgroup per CU (LDS-limited), grid-stride over 64-sample tiles
     if (io.mode != 2 && io.mode != 3) {
@@ -635,9 +635,38 @@ int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_
     return MNF_ERR_UNSUPPORTED;
 }
 
+int set_params_impl(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, hipStream_t s) {
+    const int64_t n_tab = f->table_entries * 4;
+    hipLaunchKernelGGL(table_to_half_kernel, dim3(2048), dim3(256), 0, s, mlp_base + f->n_base_mlp, (tab_t *)f->d_table, n_tab);
+    int rc = launch_status("table_to_half_kernel");
+    if (rc) return rc;
+    const int64_t n_frag = (int64_t)f->shape.blocks_total * 512;
+    hipLaunchKernelGGL(gather_frags_kernel, dim3((unsigned)ceil_div(n_frag, 256)), dim3(256), 0, s, f->d_frag_src, mlp_base, mlp_head,
+                       mlp_sem, (half_t *)f->d_frags, n_frag);
+    rc = launch_status("gather_frags_kernel");
+    if (rc) return rc;
+    f->params_loaded = true;   // the handle keeps no pointer into the caller's vectors: everything it needs later is in d_table / d_frags
+    return MNF_OK;
+}
+
+MNF_DT_END
+
+#ifndef MNF_BF16   // ---- everything below is operand-type independent and compiled once
+namespace mnf {
+int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train) {
+    MNF_REQUIRE(f, "field: null handle");
+    return f->cfg.mfma_bf16 ? bf16::launch_field_impl(f, io, density_only, stream, train) : f16::launch_field_impl(f, io, density_only, stream, train);
+}
 }  // namespace mnf
 
 using namespace mnf;
+using namespace mnf::f16;    // host-side table builders (identical in both translation units)
+
+extern "C" int mnf_field_set_params(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, mnf_stream_t stream) {
+    MNF_REQUIRE(f && mlp_base && mlp_head && mlp_sem, "field_set_params: null argument");
+    return f->cfg.mfma_bf16 ? bf16::set_params_impl(f, mlp_base, mlp_head, mlp_sem, as_stream(stream))
+                            : f16::set_params_impl(f, mlp_base, mlp_head, mlp_sem, as_stream(stream));
+}
 
 extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
     MNF_REQUIRE(cfg && out, "field_create: null argument");
@@ -704,22 +733,6 @@ extern "C" int mnf_field_grid_meta_host(mnf_field_t f, float *scale_host, int32_
     return MNF_OK;
 }
 
-extern "C" int mnf_field_set_params(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, mnf_stream_t stream) {
-    MNF_REQUIRE(f && mlp_base && mlp_head && mlp_sem, "field_set_params: null argument");
-    hipStream_t s = as_stream(stream);
-    const int64_t n_tab = f->table_entries * 4;
-    hipLaunchKernelGGL(table_to_half_kernel, dim3(2048), dim3(256), 0, s, mlp_base + f->n_base_mlp, (half_t *)f->d_table, n_tab);
-    int rc = launch_status("table_to_half_kernel");
-    if (rc) return rc;
-    const int64_t n_frag = (int64_t)f->shape.blocks_total * 512;
-    hipLaunchKernelGGL(gather_frags_kernel, dim3((unsigned)ceil_div(n_frag, 256)), dim3(256), 0, s, f->d_frag_src, mlp_base, mlp_head,
-                       mlp_sem, (half_t *)f->d_frags, n_frag);
-    rc = launch_status("gather_frags_kernel");
-    if (rc) return rc;
-    f->params_loaded = true;   // the handle keeps no pointer into the caller's vectors: everything it needs later is in d_table / d_frags
-    return MNF_OK;
-}
-
 extern "C" int mnf_field_forward(mnf_field_t f, const float *positions, const float *directions, int64_t n,
                                  float *rgb, float *density, float *sem, mnf_stream_t stream) {
     MNF_REQUIRE(f, "field_forward: null handle");
@@ -775,3 +788,4 @@ extern "C" int mnf_field_density_rays(mnf_field_t f, const float *rays_o, const 
     io.density = density;
     return launch_field(f, io, true, s);
 }
+#endif  // MNF_BF16

@@ -4,12 +4,21 @@
 #pragma once
 #include "field.h"
 
-namespace mnf {
+MNF_DT_BEGIN
 
+// `half_t` = the 16-bit type of the matrix-core operands (weights, hash features at the MLP input, activations and their
+// gradients): fp16 as tiny-cuda-nn, or bf16 (-DMNF_BF16).  The hash TABLE is fp16 in both builds (`tab_t`).
+typedef _Float16 tab_t;
+typedef _Float16 tab4 __attribute__((ext_vector_type(4)));
+#ifdef MNF_BF16
+typedef __bf16 half_t;
+typedef __bf16 half2 __attribute__((ext_vector_type(2)));
+typedef __bf16 half8 __attribute__((ext_vector_type(8)));
+#else
 typedef _Float16 half_t;
 typedef _Float16 half2 __attribute__((ext_vector_type(2)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -69,13 +78,6 @@ struct TrainLayout {
     static constexpr int mask_blocks = mHS2 + KSh;
 };
 
-struct TrainBuf {
-    half_t *act;      // [tiles][rows][64]
-    uint8_t *masks;   // [tiles][mask_blocks][CT][64]
-    int64_t Np;
-    int32_t rows;
-};
-
 // ReLU mask of a post-ReLU fp16 fragment as one byte: element j -> bit frag_mask_bit(j).  For non-negative halves
 // "non-zero" is "integer value >= 1": adding 0x7FFF carries into bit 15 of each half without crossing into the other.
 __device__ __forceinline__ constexpr int frag_mask_bit(int j) { return (j & 1) * 4 + (j >> 1); }
@@ -91,7 +93,7 @@ __device__ __forceinline__ uint8_t frag_mask(const half8 &f) {
 }
 
 struct KernelArgs {
-    const half4 *table;
+    const tab4 *table;
     const half8 *frags;
     float aabb[6];
     int C;
@@ -156,13 +158,21 @@ __device__ __forceinline__ void save_pair(const TrainBuf &tb, int64_t tile, int 
 }
 
 __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
+#ifdef MNF_BF16
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 // relu(round_to_fp16(x)) == round_to_fp16(relu(x)) (rounding is monotonic and sign-preserving), so pack first
 // (v_cvt_pk_f16_f32, two values per instruction) and clamp in packed fp16 (v_pk_max_f16).
 __device__ __forceinline__ half8 relu_pack8(const f32x16 &acc, int s) {
     half8 r;
+#ifdef MNF_BF16
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (half_t)fmaxf(acc[8 * s + j], 0.0f);     // no packed bf16 max: clamp in fp32, then v_cvt_pk_bf16_f32
+#else
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
         half2 p = {(half_t)acc[8 * s + j], (half_t)acc[8 * s + j + 1]};
@@ -170,6 +180,7 @@ __device__ __forceinline__ half8 relu_pack8(const f32x16 &acc, int s) {
         p = __builtin_elementwise_max(p, z);
         r[j] = p[0]; r[j + 1] = p[1];
     }
+#endif
     return r;
 }
 
@@ -299,16 +310,16 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
     }
 }
 
-__device__ __forceinline__ void hash_load(const half4 *__restrict__ table, const LevelPrep &p, half4 (&v)[8], bool stream = false) {
+__device__ __forceinline__ void hash_load(const tab4 *__restrict__ table, const LevelPrep &p, tab4 (&v)[8], bool stream = false) {
     if (stream) {   // wave-uniform: a level whose lines are not worth keeping in L2 (experiment: MNF_NT_FROM)
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner)
-            v[corner] = __builtin_nontemporal_load(reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + p.off[corner]));
+            v[corner] = __builtin_nontemporal_load(reinterpret_cast<const tab4 *>(reinterpret_cast<const char *>(table) + p.off[corner]));
         return;
     }
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner)
-        v[corner] = *reinterpret_cast<const half4 *>(reinterpret_cast<const char *>(table) + p.off[corner]);
+        v[corner] = *reinterpret_cast<const tab4 *>(reinterpret_cast<const char *>(table) + p.off[corner]);
 }
 
 // acc = fma((float)half, w, acc) in ONE instruction: v_fma_mix_f32 reads the fp16 operand straight from one half of a
@@ -321,7 +332,7 @@ __device__ __forceinline__ float fma_mix_half(uint32_t packed, float w, float ac
     return acc;
 }
 
-__device__ __forceinline__ void hash_blend(const LevelPrep &p, const half4 (&v)[8], float *f) {
+__device__ __forceinline__ void hash_blend(const LevelPrep &p, const tab4 (&v)[8], float *f) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
@@ -358,4 +369,4 @@ __device__ __forceinline__ void sh4(const float d[3], half8 &lo, half8 &hi) {
     hi[7] = (half_t)(0.59004358992664352f * x * (-x2 + 3.0f * y2));
 }
 
-}  // namespace mnf
+MNF_DT_END

@@ -19,7 +19,7 @@
 
 #include "field_dev.h"
 
-namespace mnf {
+MNF_DT_BEGIN
 
 // ------------------------------------------------------------------ transposed-fragment bookkeeping
 template <int W, int NH>
@@ -50,7 +50,11 @@ struct BwdArgs {
 
 // fp32 -> fp16 with saturation at the largest finite half: a loss-scaled gradient that leaves the fp16 range is clipped
 // instead of becoming Inf (which would poison every weight gradient of the step)
+#ifdef MNF_BF16
+__device__ __forceinline__ half_t sat_half(float v) { return (half_t)v; }   // bf16 has fp32's range
+#else
 __device__ __forceinline__ half_t sat_half(float v) { return (half_t)(v != v ? v : fminf(fmaxf(v, -65504.0f), 65504.0f)); }   // NaN stays NaN
+#endif
 
 // acc[ct] = sum_ks A(rt, ks) * b[ct][ks] for one 32-row tile
 template <int KS>
@@ -602,31 +606,7 @@ static int ensure_train_state(mnf_field_t f) {
     return MNF_OK;
 }
 
-// ------------------------------------------------------------------ optimizer step (pipeline.py:173-178, :531)
-// torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) on one flat parameter vector in a single pass
-// (torch's foreach implementation is six passes over the 25 M table entries): lerp of the first moment, addcmul of the
-// second, bias-corrected step.  `any_nan` counts NaN gradients (the reference skips the whole iteration then).
-__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                   float *__restrict__ v, int64_t n, float beta1, float beta2, float eps,
-                                                   float step_size, float bc2_sqrt) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) {
-        const float gi = g[i];
-        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
-        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
-    }
-}
-
-__global__ void __launch_bounds__(256) count_nan_kernel(const float *__restrict__ g, int64_t n, int32_t *__restrict__ count) {
-    int local = 0;
-    // NaN as the reference's guard (pipeline.py:520-529), and +-Inf as well: an overflowed fp16 activation gradient shows up
-    // as Inf, which Adam would turn into NaN parameters one step later
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) local += !(fabsf(g[i]) <= 3.4028234664e38f);
-    if (__ballot(local != 0) != 0ull && local) atomicAdd(count, local);
-}
-
-void free_train_state(mnf_field_t f) {
+void free_train_state_impl(mnf_field_t f) {
     TrainState *ts = reinterpret_cast<TrainState *>(f->train_state);
     if (!ts) return;
     if (ts->d_fragT_src) (void)hipFree(ts->d_fragT_src);
@@ -659,20 +639,15 @@ static void launch_dgrad(const BwdArgs &a, int grid, hipStream_t s) {
     hipLaunchKernelGGL((dgrad_kernel<W, NH>), dim3(grid), dim3(kThreads), 0, s, a);
 }
 
-}  // namespace mnf
-
-using namespace mnf;
-
-extern "C" int64_t mnf_field_train_workspace_bytes(mnf_field_t f, int64_t n) {
+int64_t train_workspace_bytes_impl(mnf_field_t f, int64_t n) {
     if (!f || n < 0) return -1;
     TrainTables tt;
     if (!tables_for(f->cfg.neurons, f->cfg.layers, f->cfg.num_semantic_classes, tt)) return -1;
     return carve_train(tt, nullptr, n).bytes;
 }
 
-extern "C" int mnf_field_forward_train(mnf_field_t f, const float *positions, const float *directions, int64_t n,
-                                       float *rgb, float *density, float *sem, void *workspace, int64_t workspace_bytes,
-                                       mnf_stream_t stream) {
+int forward_train_impl(mnf_field_t f, const float *positions, const float *directions, int64_t n, float *rgb, float *density,
+                       float *sem, void *workspace, int64_t workspace_bytes, hipStream_t stream) {
     MNF_REQUIRE(f && f->params_loaded, "field_forward_train: parameters not loaded");
     MNF_REQUIRE(n >= 0, "field_forward_train: negative n");
     if (n == 0) return MNF_OK;
@@ -689,18 +664,15 @@ extern "C" int mnf_field_forward_train(mnf_field_t f, const float *positions, co
     io.mode = 0; io.positions = positions; io.directions = directions; io.n = n;
     io.rgb = rgb; io.density = density; io.sem = sem;
     TrainBuf tb = {v.act, v.masks, v.Np, ts->tt.rows};
-    return launch_field(f, io, false, as_stream(stream), &tb);
+    return launch_field_impl(f, io, false, stream, &tb);
 }
 
-extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t n,
-                                  const float *d_rgb, const float *d_density, const float *d_sem,
-                                  const float *rgb, const float *density,
-                                  void *workspace, int64_t workspace_bytes, float loss_scale,
-                                  float *g_base, float *g_head, float *g_sem, mnf_stream_t stream) {
+int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float *d_rgb, const float *d_density, const float *d_sem,
+                  const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale, float *g_base,
+                  float *g_head, float *g_sem, hipStream_t s) {
     MNF_REQUIRE(f && f->params_loaded, "field_backward: parameters not loaded");
     MNF_REQUIRE(n >= 0 && loss_scale > 0.f, "field_backward: bad arguments");
     MNF_REQUIRE(g_base && g_head && g_sem, "field_backward: null gradient buffer");
-    hipStream_t s = as_stream(stream);
     MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));
     MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
     MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
@@ -790,6 +762,67 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
     return launch_status("fold_replicas_kernel");
 }
 
+MNF_DT_END
+
+#ifndef MNF_BF16   // ---- operand-type independent: compiled once
+namespace mnf {
+// ------------------------------------------------------------------ optimizer step (pipeline.py:173-178, :531)
+// torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) on one flat parameter vector in a single pass
+// (torch's foreach implementation is six passes over the 25 M table entries): lerp of the first moment, addcmul of the
+// second, bias-corrected step.  `any_nan` counts NaN gradients (the reference skips the whole iteration then).
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, float beta1, float beta2, float eps,
+                                                   float step_size, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
+__global__ void __launch_bounds__(256) count_nan_kernel(const float *__restrict__ g, int64_t n, int32_t *__restrict__ count) {
+    int local = 0;
+    // NaN as the reference's guard (pipeline.py:520-529), and +-Inf as well: an overflowed fp16 activation gradient shows up
+    // as Inf, which Adam would turn into NaN parameters one step later
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) local += !(fabsf(g[i]) <= 3.4028234664e38f);
+    if (__ballot(local != 0) != 0ull && local) atomicAdd(count, local);
+}
+
+
+void free_train_state(mnf_field_t f) {
+    if (f->cfg.mfma_bf16) bf16::free_train_state_impl(f); else f16::free_train_state_impl(f);
+}
+}  // namespace mnf
+
+using namespace mnf;
+
+extern "C" int64_t mnf_field_train_workspace_bytes(mnf_field_t f, int64_t n) {
+    if (!f) return -1;
+    return f->cfg.mfma_bf16 ? bf16::train_workspace_bytes_impl(f, n) : f16::train_workspace_bytes_impl(f, n);
+}
+
+extern "C" int mnf_field_forward_train(mnf_field_t f, const float *positions, const float *directions, int64_t n,
+                                       float *rgb, float *density, float *sem, void *workspace, int64_t workspace_bytes,
+                                       mnf_stream_t stream) {
+    MNF_REQUIRE(f, "field_forward_train: null handle");
+    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, positions, directions, n, rgb, density, sem, workspace, workspace_bytes, as_stream(stream))
+                            : f16::forward_train_impl(f, positions, directions, n, rgb, density, sem, workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t n,
+                                  const float *d_rgb, const float *d_density, const float *d_sem,
+                                  const float *rgb, const float *density,
+                                  void *workspace, int64_t workspace_bytes, float loss_scale,
+                                  float *g_base, float *g_head, float *g_sem, mnf_stream_t stream) {
+    MNF_REQUIRE(f, "field_backward: null handle");
+    return f->cfg.mfma_bf16 ? bf16::backward_impl(f, positions, n, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale,
+                                                  g_base, g_head, g_sem, as_stream(stream))
+                            : f16::backward_impl(f, positions, n, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale,
+                                                 g_base, g_head, g_sem, as_stream(stream));
+}
+
 extern "C" int mnf_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                              float beta2, float eps, int32_t step, mnf_stream_t stream) {
     if (n == 0) return MNF_OK;
@@ -809,3 +842,4 @@ extern "C" int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf
                        values, n, count);
     return launch_status("count_nan_kernel");
 }
+#endif  // MNF_BF16

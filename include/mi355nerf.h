@@ -214,6 +214,9 @@ typedef struct {
     int32_t output_fp16;           /* 0 (default): network outputs stay fp32.  1: every output of the three networks is rounded
                                       to fp16 before it is used, as tiny-cuda-nn hands them over (ngp.py:181-200, :210-220 cast
                                       tcnn's fp16 outputs back with `.to(x)`) — the tcnn-faithful mode of DESIGN.md §2 */
+    int32_t mfma_bf16;             /* 0 (default): fp16 matrix-core operands (weights, MLP inputs, activations and their gradients), the
+                                      reference's tiny-cuda-nn arithmetic.  1: bf16 operands (BASELINE config 5); the hash table stays
+                                      fp16, accumulation fp32 */
 } mnf_field_config;
 
 /* tcnn.NetworkWithInputEncoding / tcnn.Network / tcnn.Encoding construction, ngp.py:108-169 */

@@ -28,6 +28,8 @@ parameters are rounded to fp16; hash features, SH values and every hidden activa
 rounded to fp16 where they enter a matrix product; products accumulate in fp32; network
 outputs stay fp32.  ``precision="tcnn"`` additionally rounds every network output to fp16, which is
 what tiny-cuda-nn hands back (the product's `tcnn_output_rounding=True` / `mnf_field_config.output_fp16`);
+``precision="bf16"`` is the product's `mfma_bf16` mode (BASELINE config 5): weights, MLP inputs and hidden
+activations rounded to bfloat16 instead of fp16, hash table still fp16, fp32 accumulation and outputs.
 tcnn's fp16 ACCUMULATION inside a layer is not emulated (its summation order is not part of any published
 contract).  ``precision="f32"`` does no rounding.
 """
@@ -123,13 +125,15 @@ def init_params(cfg: FieldConfig, seed: int = 0) -> Dict[str, np.ndarray]:
 
 
 def _q(x: torch.Tensor, precision: str) -> torch.Tensor:
-    """fp16 rounding with a straight-through gradient (d round(x)/dx := 1), so that torch autograd through this
-    oracle yields the fp32 gradient of the fp16-rounded forward — the reference the HIP backward is checked against."""
-    if precision not in ("f16", "tcnn"):
+    """fp16 (or, precision="bf16", bfloat16) rounding with a straight-through gradient (d round(x)/dx := 1), so that torch
+    autograd through this oracle yields the fp32 gradient of the rounded forward — the reference the HIP backward is checked
+    against."""
+    if precision not in ("f16", "tcnn", "bf16"):
         return x
+    r = (lambda t: t.bfloat16().float()) if precision == "bf16" else (lambda t: t.half().float())
     if x.requires_grad:
-        return x + (x.detach().half().float() - x.detach())
-    return x.half().float()
+        return x + (r(x.detach()) - x.detach())
+    return r(x)
 
 
 def _split_mlp(flat: torch.Tensor, shapes) -> List[torch.Tensor]:
@@ -161,7 +165,8 @@ class OracleField:
         precision = self.precision
         n_mlp = sum(o * i for o, i in self.shapes["base"])
         self.w_base = [_q(w, precision) for w in _split_mlp(self.p_base[:n_mlp], self.shapes["base"])]
-        self.table = _q(self.p_base[n_mlp:].view(self.table_entries, self.cfg.n_features), precision)
+        # the hash table is stored in fp16 in every mode ("bf16" only changes the matrix-core operands)
+        self.table = _q(self.p_base[n_mlp:].view(self.table_entries, self.cfg.n_features), "f16" if precision == "bf16" else precision)
         self.w_head = [_q(w, precision) for w in _split_mlp(self.p_head, self.shapes["head"])]
         self.w_sem = [_q(w, precision) for w in _split_mlp(self.p_sem, self.shapes["sem"])]
 

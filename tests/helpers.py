@@ -26,11 +26,11 @@ def oracle_field(scene, precision="f16", requires_grad=False):
     return OracleField(cfg, scene["params"], precision, requires_grad)
 
 
-def hip_field(scene, device="cuda:0", tcnn_output_rounding=False):
+def hip_field(scene, device="cuda:0", tcnn_output_rounding=False, mfma_bf16=False):
     from apnrf_amd.ngp import NGPRadianceField
     f = NGPRadianceField(aabb=torch.from_numpy(scene["aabb"]), neurons=scene["neurons"], layers=scene["layers"],
                          num_semantic_classes=scene["C"], log2_hashmap_size=scene["log2_hashmap_size"],
-                         tcnn_output_rounding=tcnn_output_rounding)
+                         tcnn_output_rounding=tcnn_output_rounding, mfma_bf16=mfma_bf16)
     with torch.no_grad():
         f.mlp_base.params.copy_(torch.from_numpy(scene["params"]["mlp_base"]))
         f.mlp_head.params.copy_(torch.from_numpy(scene["params"]["mlp_head"]))

@@ -1277,3 +1277,78 @@ def test_ray_major_density_prepass_gives_same_samples(scene):
     np.testing.assert_array_equal(s_fast[~skipped].cpu().numpy(), s_all[~skipped].cpu().numpy())
     # early_stop_eps = 0 disables the cut
     np.testing.assert_array_equal(fast.ray_major(ts, te, ri, info, 0.0).cpu().numpy(), s_all.cpu().numpy())
+
+
+# ------------------------------------------------------------------ g1: bf16 matrix-core operands (BASELINE config 5)
+def test_bf16_field_forward_backward_and_render_match_oracle():
+    """`mfma_bf16=True`: the same kernels with v_mfma_f32_32x32x16_bf16 (weights, MLP inputs, hidden activations and the
+    backward's activation gradients in bfloat16; hash table fp16; fp32 accumulate) against the oracle's precision="bf16".
+    bf16 keeps 8 significand bits (fp16: 11), so one rounding flip moves a value by 2^-8 relative: tolerances are 8x the
+    fp16 mode's (outputs 8e-3 abs + 1.6e-2 rel on logits, density 1.6e-2 rel, gradients 6e-2 relative L2, cosine > 0.998)."""
+    from apnrf_amd import render as RD
+    from oracle import render as R
+    sc = H.make_scene(neurons=128, layers=2, C=29, log2_hashmap_size=14, head_gain=2.0)
+    hip, orc = H.hip_field(sc, mfma_bf16=True).train(), H.oracle_field(sc, precision="bf16", requires_grad=True)
+    rng = np.random.default_rng(7)
+    n = 3000 + 21
+    a = sc["aabb"]
+    pos = (rng.random((n, 3)) * (a[3:] - a[:3]) * 0.98 + a[:3] + 0.01 * (a[3:] - a[:3])).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    g_rgb = (rng.normal(size=(n, 3)) * 1e-3).astype(np.float32)
+    g_sig = (rng.normal(size=(n, 1)) * 1e-5).astype(np.float32)
+    g_sem = (rng.normal(size=(n, 29)) * 1e-3).astype(np.float32)
+    rgb, sigma, sem = hip(_cu(pos), _cu(d))
+    torch.autograd.backward([rgb, sigma, sem], [_cu(g_rgb), _cu(g_sig), _cu(g_sem)])
+    r_rgb, r_sigma, r_sem = orc(torch.from_numpy(pos), torch.from_numpy(d))
+    torch.autograd.backward([r_rgb, r_sigma, r_sem], [torch.from_numpy(g_rgb), torch.from_numpy(g_sig), torch.from_numpy(g_sem)])
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), r_rgb.detach().numpy(), atol=8e-3)
+    np.testing.assert_allclose(sem.detach().cpu().numpy(), r_sem.detach().numpy(), atol=8e-3, rtol=1.6e-2)
+    np.testing.assert_allclose(sigma.detach().cpu().numpy(), r_sigma.detach().numpy(), rtol=1.6e-2, atol=1e-6)
+    n_mlp = sum(o * i for o, i in orc.shapes["base"])
+    _grad_close(hip.mlp_base.params.grad[:n_mlp], orc.p_base.grad[:n_mlp], "base mlp", rel=6e-2, cos=0.998)
+    _grad_close(hip.mlp_base.params.grad[n_mlp:], orc.p_base.grad[n_mlp:], "hash table", rel=6e-2, cos=0.998)
+    _grad_close(hip.mlp_head.params.grad, orc.p_head.grad, "rgb head", rel=6e-2, cos=0.998)
+    _grad_close(hip.mlp_sem.params.grad, orc.p_sem.grad, "sem head", rel=6e-2, cos=0.998)
+    # the bf16 mode is really a different arithmetic from the fp16 one (and both are deterministic)
+    hip16 = H.hip_field(sc)
+    with torch.no_grad():
+        s16 = hip16(_cu(pos), _cu(d))[2]
+        s_again = hip.eval()(_cu(pos), _cu(d))[2]
+    assert (s16 - sem.detach()).abs().max() > 1e-4 and torch.equal(s_again, sem.detach())
+    # fused test-time renderer in bf16 against the oracle's bf16 field
+    est = H.hip_estimator(sc)
+    o, dd = H.view_rays(sc, 1, h=24, w=24)
+    orc_ng = H.oracle_field(sc, precision="bf16")
+    ref = R.render_test(1024, orc_ng, sc["occ"], sc["aabb"][None], o, dd, render_bkgd=torch.zeros(3), **H.RENDER_KW)
+    out = RD.render_views(hip, est, o.to(DEV), dd.to(DEV), 576, 1024, render_bkgd=torch.zeros(3), **H.RENDER_KW)
+    for k, tol in (("rgb", 8e-3), ("acc", 8e-3), ("sem", 8e-3)):
+        bad = (np.abs(out[k].cpu().numpy() - ref[k].numpy()) > tol).reshape(576, -1).any(1)
+        assert bad.sum() <= 3, (k, int(bad.sum()))              # a few alpha-threshold ties at bf16 resolution
+    mse = float(((out["rgb"].cpu() - ref["rgb"]) ** 2).mean())
+    assert 10.0 * np.log10(1.0 / max(mse, 1e-20)) > 40.0
+
+
+def test_bf16_train_step_config5_shape():
+    """BASELINE config 5 as written (bf16 MFMA path, 8192-ray train batches, fused backward): `train_step` on scene 102344280 in
+    bf16 mode lowers the loss on a fixed batch and produces finite gradients on touched entries only."""
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene("102344280", log2_hashmap_size=16, seed=2, n_poses=8)
+    hip, est = H.hip_field(sc, mfma_bf16=True), H.hip_estimator(sc)
+    c2w = RD.pose_to_c2w(sc["poses"][1]).astype(np.float32)[None]
+    K = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
+    rng = np.random.default_rng(4)
+    rays = RD.generate_image_rays(torch.from_numpy(c2w), 640, 640, K, DEV, rng.integers(0, 640 * 640, 8192))
+    pix = torch.from_numpy(rng.random((8192, 3)).astype(np.float32)).to(DEV)
+    dep = torch.from_numpy(rng.uniform(0.5, 4.0, 8192).astype(np.float32)).to(DEV)
+    lab = torch.from_numpy(rng.integers(0, 29, 8192)).to(DEV)
+    opt = FusedAdam(hip.parameters(), lr=1e-3, eps=1e-15)
+    losses = []
+    for s_ in range(1, 9):
+        out = RD.train_step(hip, est, opt, rays, pix, dep, lab, torch.zeros(3, device=DEV), step=s_, **H.RENDER_KW)
+        assert not out["skipped"] and out["n_rendering_samples"] > 8192 * 10
+        losses.append(float(out["loss"]))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    n_mlp = 128 * 64 + 128 * 128 + 16 * 128
+    g_tab = hip.mlp_base.params.grad[n_mlp:]
+    assert 0 < int((g_tab != 0).sum()) < g_tab.numel() and bool(torch.isfinite(g_tab).all())
