@@ -22,6 +22,12 @@ class FieldConfig(ctypes.Structure):
                 ("output_fp16", c_int32), ("mfma_bf16", c_int32)]
 
 
+class TrainOpts(ctypes.Structure):
+    _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float), ("cone_angle", c_float),
+                ("alpha_thre", c_float), ("early_stop_eps", c_float), ("render_bkgd", c_float * 3), ("loss_scale", c_float),
+                ("stratified", c_int32), ("seed", c_uint64)]
+
+
 class VanillaConfig(ctypes.Structure):
     _fields_ = [("net_depth", c_int32), ("net_width", c_int32), ("skip_layer", c_int32), ("net_depth_condition", c_int32),
                 ("net_width_condition", c_int32)]
@@ -102,6 +108,15 @@ SIGNATURES = {
     "mnf_field_forward_train": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_field_backward": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_field_forward_train_samples": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_train_step_workspace_bytes": (c_int64, [c_void_p, c_int32, c_int64, c_int64]),
+    "mnf_train_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                                 c_void_p, c_void_p, c_void_p, POINTER(TrainOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                 c_int64, c_void_p, c_int64, c_void_p]),
+    "mnf_score_poses_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "mnf_score_poses": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                  c_float, c_void_p, c_int64, POINTER(RenderOpts), c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_render_workspace_bytes": (c_int64, [c_int64, c_int32]),
     "mnf_render_test": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p, c_void_p,
                                   c_int64, POINTER(RenderOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

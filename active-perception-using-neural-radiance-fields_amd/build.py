@@ -23,6 +23,7 @@ SOURCES = {
     "composite_train.hip": [],
     "occupancy.hip": ["-ffp-contract=off"],
     "vanilla.hip": [],
+    "trainstep.hip": ["-ffp-contract=off"],
     "field.hip@bf16": ["-DMNF_BF16"],
     "train.hip@bf16": ["-DMNF_BF16"],
 }

@@ -76,6 +76,7 @@ struct FieldIO {
                                              // two-launch path (encode_kernel, then the MLP kernel on its output)
     // outputs: user layout (modes 0,1) ...
     float *rgb, *density, *sem;
+    float *positions_out;                    // mode 1, optional: the sample positions [n,3] the kernel formed (the backward's scatter reads them)
     // ... or, in mode 2, composites straight into the renderer's per-ray accumulators
     FusedRender fr;
 };
@@ -98,8 +99,7 @@ int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_
     int set_params_impl(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, hipStream_t stream);      \
     void free_train_state_impl(mnf_field_t f);                                                                                       \
     int64_t train_workspace_bytes_impl(mnf_field_t f, int64_t n);                                                                    \
-    int forward_train_impl(mnf_field_t f, const float *positions, const float *directions, int64_t n, float *rgb, float *density,   \
-                           float *sem, void *workspace, int64_t workspace_bytes, hipStream_t stream);                               \
+    int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream);         \
     int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float *d_rgb, const float *d_density,                 \
                       const float *d_sem, const float *rgb, const float *density, void *workspace, int64_t workspace_bytes,         \
                       float loss_scale, float *g_base, float *g_head, float *g_sem, hipStream_t stream);                            \

@@ -86,6 +86,10 @@ __device__ __forceinline__ void fetch_sample(const KernelArgs &args, const ColDa
                 // utils.py:92 / :614: origins + dirs * (t_starts + t_ends) / 2.0
                 pos[d] = args.io.rays_o[3 * ray + d] + (dir[d] * tsum) / 2.0f;
             }
+            if (args.io.positions_out) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) args.io.positions_out[3 * col + d] = pos[d];
+            }
         }
     } else {
         // renderer tile: column -> ray id (-1: unused); the runs of equal ids are the rays of this tile
@@ -586,7 +590,8 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     a.io = io;
 #define MNF_LAUNCH(MODE, DO) hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO>), dim3(grid), dim3(kThreads), 0, stream, a)
     if (train) {
-        hipLaunchKernelGGL((field_kernel<W, NH, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+        if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else hipLaunchKernelGGL((field_kernel<W, NH, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     } else if (io.enc) {
         // two launches: gather at high occupancy, then the register-heavy MLP chain on ready-made fragments
         half8 *enc = reinterpret_cast<half8 *>(const_cast<void *>(io.enc));

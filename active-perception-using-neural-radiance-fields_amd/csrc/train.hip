@@ -646,23 +646,18 @@ int64_t train_workspace_bytes_impl(mnf_field_t f, int64_t n) {
     return carve_train(tt, nullptr, n).bytes;
 }
 
-int forward_train_impl(mnf_field_t f, const float *positions, const float *directions, int64_t n, float *rgb, float *density,
-                       float *sem, void *workspace, int64_t workspace_bytes, hipStream_t stream) {
+int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream) {
     MNF_REQUIRE(f && f->params_loaded, "field_forward_train: parameters not loaded");
-    MNF_REQUIRE(n >= 0, "field_forward_train: negative n");
-    if (n == 0) return MNF_OK;
-    MNF_REQUIRE(positions && directions && rgb && density && sem, "field_forward_train: null pointer");
+    MNF_REQUIRE(io.n >= 0, "field_forward_train: negative n");
+    if (io.n == 0) return MNF_OK;
     int rc = ensure_train_state(f);
     if (rc) return rc;
     TrainState *ts = reinterpret_cast<TrainState *>(f->train_state);
-    WsView v = carve_train(ts->tt, workspace, n);
+    WsView v = carve_train(ts->tt, workspace, io.n);
     if (!workspace || workspace_bytes < v.bytes) {
         set_error("field_forward_train: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)v.bytes);
         return MNF_ERR_WORKSPACE;
     }
-    FieldIO io = {};
-    io.mode = 0; io.positions = positions; io.directions = directions; io.n = n;
-    io.rgb = rgb; io.density = density; io.sem = sem;
     TrainBuf tb = {v.act, v.masks, v.Np, ts->tt.rows};
     return launch_field_impl(f, io, false, stream, &tb);
 }
@@ -807,8 +802,26 @@ extern "C" int mnf_field_forward_train(mnf_field_t f, const float *positions, co
                                        float *rgb, float *density, float *sem, void *workspace, int64_t workspace_bytes,
                                        mnf_stream_t stream) {
     MNF_REQUIRE(f, "field_forward_train: null handle");
-    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, positions, directions, n, rgb, density, sem, workspace, workspace_bytes, as_stream(stream))
-                            : f16::forward_train_impl(f, positions, directions, n, rgb, density, sem, workspace, workspace_bytes, as_stream(stream));
+    MNF_REQUIRE(n == 0 || (positions && directions && rgb && density && sem), "field_forward_train: null pointer");
+    FieldIO io = {};
+    io.mode = 0; io.positions = positions; io.directions = directions; io.n = n;
+    io.rgb = rgb; io.density = density; io.sem = sem;
+    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream))
+                            : f16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int mnf_field_forward_train_samples(mnf_field_t f, const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                                               const float *t_starts, const float *t_ends, int64_t n, float *rgb, float *density,
+                                               float *sem, float *positions_out, void *workspace, int64_t workspace_bytes,
+                                               mnf_stream_t stream) {
+    MNF_REQUIRE(f, "field_forward_train_samples: null handle");
+    MNF_REQUIRE(n == 0 || (rays_o && rays_d && ray_indices && t_starts && t_ends && rgb && density && sem && positions_out),
+                "field_forward_train_samples: null pointer");
+    FieldIO io = {};
+    io.mode = 1; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = ray_indices; io.t_starts = t_starts; io.t_ends = t_ends; io.n = n;
+    io.rgb = rgb; io.density = density; io.sem = sem; io.positions_out = positions_out;
+    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream))
+                            : f16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t n,

@@ -1,0 +1,332 @@
+// One training iteration's forward + loss + backward as ONE C call, and candidate-view scoring from poses as one C call.
+//
+//   mnf_train_step    scripts/pipeline.py:472-518 for one model: `render_image_with_occgrid_with_depth_guide`
+//                     (perception/models/utils.py:63-219: occupancy sampling with the density pre-pass and the visibility
+//                     filter of nerfacc/estimators/occ_grid.py:80-238, then `sem_rendering`, utils.py:362-461), the three-term
+//                     loss (pipeline.py:506-511) and `loss.backward()` down to the three flat parameter-gradient vectors.
+//                     The optimizer step and the NaN guard stay with the caller (pipeline.py:520-532), as does the occupancy
+//                     refresh (mnf_update_occupancy).
+//   mnf_score_poses   pipeline.py:674-781 for one trajectory: poses -> sub-sampled rays -> probabilistic renders of every
+//                     ensemble member -> per-view predictive-information terms.
+//
+// Both are compositions of the library's own entry points plus the small kernels below (stratified near planes, visibility
+// filter with compaction, loss + its gradient).  Two host syncs per train step (the marched and the surviving sample
+// counts size the following launches), which the reference's boolean-mask indexing has as well.
+//
+// Build with -ffp-contract=off (the marcher's near planes feed bit-exact t values).
+#include <cmath>
+#include <cstring>
+
+#include "field.h"
+
+namespace mnf {
+namespace {
+
+constexpr float kEps = 1.1920928955078125e-07f;
+
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32_10(U4 ctr, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * ctr.x, p1 = (uint64_t)0xCD9E8D57u * ctr.z;
+        ctr = {(uint32_t)(p1 >> 32) ^ ctr.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ ctr.w ^ k1, (uint32_t)p0};
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+// occ_grid.py:181-189: near / far planes, stratified jitter near += U[0,1) * step (Philox counter (ray, 0, 7, 0), key = seed)
+__global__ void __launch_bounds__(256) planes_kernel(int32_t n, float near_plane, float far_plane, float step, int32_t stratified, uint32_t s0,
+                                                     uint32_t s1, float *__restrict__ nearp, float *__restrict__ farp) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float v = near_plane;
+    if (stratified) v += ((float)(philox4x32_10({(uint32_t)r, 0u, 7u, 0u}, s0, s1).x & 0xFFFFFFu) * 5.9604644775390625e-08f) * step;
+    nearp[r] = v; farp[r] = far_plane;
+}
+
+// mean of occs (occ_grid.py:192: alpha_thre = min(alpha_thre, self.occs.mean())) in double, one workgroup
+__global__ void __launch_bounds__(1024) mean_kernel(const float *__restrict__ x, int64_t n, float alpha_thre, float *__restrict__ out) {
+    __shared__ double s[1024];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += (double)x[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 512; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = fminf(alpha_thre, (float)(s[0] / (double)n));
+}
+
+__global__ void __launch_bounds__(1024) max_kernel(const int64_t *__restrict__ x, int64_t n, int64_t *__restrict__ out) {
+    __shared__ long long s[1024];
+    long long m = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = x[i] > m ? x[i] : m;
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 512; d >= 1; d >>= 1) { if ((int)threadIdx.x < d && s[threadIdx.x + d] > s[threadIdx.x]) s[threadIdx.x] = s[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
+// render_visibility_from_density (volrend.py:424-483) on packed samples, one wave per ray: pass 0 counts the survivors of
+// each ray, pass 1 (after the prefix sum of the counts) writes them compacted and grouped by ray.
+template <bool WRITE>
+__global__ void __launch_bounds__(64) visibility_kernel(int32_t n_rays, const int64_t *__restrict__ starts, const int64_t *__restrict__ cnts,
+                                                        const float *__restrict__ ts, const float *__restrict__ te, const float *__restrict__ sig,
+                                                        float early_stop_eps, const float *__restrict__ alpha_thre_dev,
+                                                        int64_t *__restrict__ kept_cnts, const int64_t *__restrict__ kept_starts,
+                                                        float *__restrict__ o_ts, float *__restrict__ o_te, int64_t *__restrict__ o_ray) {
+    const int lane = threadIdx.x;
+    const float alpha_thre = alpha_thre_dev[0];
+    for (int32_t r = blockIdx.x; r < n_rays; r += gridDim.x) {
+        const int64_t s = starts[r];
+        const int c = (int)cnts[r];
+        float carry = 0.0f;
+        int64_t out = WRITE ? kept_starts[r] : 0;
+        int kept = 0;
+        for (int base = 0; base < c; base += 64) {
+            const bool valid = base + lane < c;
+            const int64_t k = s + base + lane;
+            const float a = valid ? ts[k] : 0.f, b = valid ? te[k] : 0.f;
+            const float sdt = valid ? sig[k] * (b - a) : 0.0f;
+            float incl = sdt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const float u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
+            const float alpha = 1.0f - expf(-sdt);
+            const float trans = expf(-((incl - sdt) + carry));
+            carry += __shfl(incl, 63, 64);
+            bool vis = valid && trans >= early_stop_eps;
+            if (alpha_thre > 0.0f) vis = vis && alpha >= alpha_thre;
+            const unsigned long long m = __ballot(vis);
+            if (WRITE && vis) {
+                const int64_t dst = out + __popcll(m & ((1ull << lane) - 1ull));
+                o_ts[dst] = a; o_te[dst] = b; o_ray[dst] = r;
+            }
+            const int nk = __popcll(m);
+            out += nk; kept += nk;
+        }
+        if (!WRITE && lane == 0) kept_cnts[r] = kept;
+    }
+}
+
+// pipeline.py:506-511: 10 * smooth_l1(rgb, pixels) + smooth_l1(depth, dep[:, None]) / 5 + cross_entropy(sem, labels) / 2 (all
+// "mean" reductions) and its gradient with respect to the rendered rgb / depth / semantic logits.  One lane per ray.
+__device__ __forceinline__ void smooth_l1(float x, float &val, float &grad) {      // beta = 1
+    const float ax = fabsf(x);
+    val = ax < 1.0f ? 0.5f * x * x : ax - 0.5f;
+    grad = ax < 1.0f ? x : (x > 0.0f ? 1.0f : -1.0f);
+}
+
+__global__ void __launch_bounds__(256) loss_kernel(int32_t n_rays, int32_t C, const float *__restrict__ rgb, const float *__restrict__ depth,
+                                                   const float *__restrict__ sem, const float *__restrict__ t_rgb, const float *__restrict__ t_dep,
+                                                   const int64_t *__restrict__ t_sem, float *__restrict__ g_rgb, float *__restrict__ g_dep,
+                                                   float *__restrict__ g_sem, float *__restrict__ losses /* [4]: total, rgb, depth, sem */) {
+    __shared__ float s_acc[3][4];
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    float l_rgb = 0.f, l_dep = 0.f, l_sem = 0.f;
+    if (r < n_rays) {
+        const float inv_r = 1.0f / (float)n_rays;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v, g;
+            smooth_l1(rgb[3 * r + k] - t_rgb[3 * r + k], v, g);
+            l_rgb += v;
+            g_rgb[3 * r + k] = g * (10.0f / 3.0f) * inv_r;
+        }
+        float v, g;
+        smooth_l1(depth[r] - t_dep[r], v, g);
+        l_dep = v;
+        g_dep[r] = g * 0.2f * inv_r;
+        const float *lg = sem + (int64_t)r * C;
+        float mx = -INFINITY;
+        for (int k = 0; k < C; ++k) mx = fmaxf(mx, lg[k]);
+        float den = 0.f;
+        for (int k = 0; k < C; ++k) den += expf(lg[k] - mx);
+        const int64_t lab = t_sem[r];
+        l_sem = logf(den) - (lg[lab] - mx);
+        for (int k = 0; k < C; ++k) g_sem[(int64_t)r * C + k] = (expf(lg[k] - mx) / den - (k == lab ? 1.0f : 0.0f)) * 0.5f * inv_r;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { l_rgb += __shfl_xor(l_rgb, d, 64); l_dep += __shfl_xor(l_dep, d, 64); l_sem += __shfl_xor(l_sem, d, 64); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_acc[0][wave] = l_rgb; s_acc[1][wave] = l_dep; s_acc[2][wave] = l_sem; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float inv_r = 1.0f / (float)n_rays;
+        const float a = (s_acc[0][0] + s_acc[0][1] + s_acc[0][2] + s_acc[0][3]) * inv_r / 3.0f;
+        const float b = (s_acc[1][0] + s_acc[1][1] + s_acc[1][2] + s_acc[1][3]) * inv_r;
+        const float c = (s_acc[2][0] + s_acc[2][1] + s_acc[2][2] + s_acc[2][3]) * inv_r;
+        atomicAdd(&losses[1], a); atomicAdd(&losses[2], b); atomicAdd(&losses[3], c);
+        atomicAdd(&losses[0], a * 10.0f + b / 5.0f + c / 2.0f);
+    }
+}
+
+struct StepWs {
+    float *nearp, *farp, *scratch_ts, *scratch_te, *alpha_thre;
+    int64_t *counts, *starts, *kept_cnts, *kept_starts, *totals, *scan;
+    float *ts, *te, *sigma;          // marched
+    int64_t *ray;
+    float *k_ts, *k_te, *k_rgb, *k_sigma, *k_sem, *k_pos, *k_w, *k_tr, *k_dsig, *k_drgb, *k_dsem;   // kept
+    int64_t *k_ray;
+    float *o_rgb, *o_acc, *o_dep, *o_sem, *g_rgb, *g_dep, *g_sem;   // per ray
+    void *field_ws;
+    int64_t field_ws_bytes, bytes;
+};
+
+StepWs carve_step(char *base, mnf_field_t f, int64_t R, int32_t cap, int64_t max_marched, int64_t max_kept) {
+    StepWs w;
+    size_t off = 0;
+    auto take = [&](size_t b) { char *p = base ? base + off : nullptr; off += (b + 255) & ~(size_t)255; return p; };
+    const int C = f->cfg.num_semantic_classes;
+    w.nearp = (float *)take(R * 4); w.farp = (float *)take(R * 4); w.alpha_thre = (float *)take(256);
+    w.counts = (int64_t *)take(R * 8); w.starts = (int64_t *)take(R * 8); w.kept_cnts = (int64_t *)take(R * 8); w.kept_starts = (int64_t *)take(R * 8);
+    w.totals = (int64_t *)take(256); w.scan = (int64_t *)take((size_t)mnf_scan_workspace_bytes(R));
+    w.scratch_ts = (float *)take((size_t)R * cap * 4); w.scratch_te = (float *)take((size_t)R * cap * 4);
+    w.ts = (float *)take(max_marched * 4); w.te = (float *)take(max_marched * 4); w.sigma = (float *)take(max_marched * 4); w.ray = (int64_t *)take(max_marched * 8);
+    w.k_ts = (float *)take(max_kept * 4); w.k_te = (float *)take(max_kept * 4); w.k_ray = (int64_t *)take(max_kept * 8);
+    w.k_rgb = (float *)take(max_kept * 12); w.k_sigma = (float *)take(max_kept * 4); w.k_sem = (float *)take((size_t)max_kept * C * 4);
+    w.k_pos = (float *)take(max_kept * 12); w.k_w = (float *)take(max_kept * 4); w.k_tr = (float *)take(max_kept * 4);
+    w.k_dsig = (float *)take(max_kept * 4); w.k_drgb = (float *)take(max_kept * 12); w.k_dsem = (float *)take((size_t)max_kept * C * 4);
+    w.o_rgb = (float *)take(R * 12); w.o_acc = (float *)take(R * 4); w.o_dep = (float *)take(R * 4); w.o_sem = (float *)take((size_t)R * C * 4);
+    w.g_rgb = (float *)take(R * 12); w.g_dep = (float *)take(R * 4); w.g_sem = (float *)take((size_t)R * C * 4);
+    w.field_ws_bytes = mnf_field_train_workspace_bytes(f, max_kept);
+    w.field_ws = take((size_t)w.field_ws_bytes);
+    w.bytes = (int64_t)off;
+    return w;
+}
+
+inline int32_t scratch_cap(int32_t n_rays) {
+    const int64_t c = ((int64_t)1 << 27) / (n_rays > 0 ? n_rays : 1);
+    return (int32_t)(c < 64 ? 64 : (c > 2048 ? 2048 : c));
+}
+
+}  // namespace
+}  // namespace mnf
+
+using namespace mnf;
+
+extern "C" int64_t mnf_train_step_workspace_bytes(mnf_field_t f, int32_t n_rays, int64_t max_marched, int64_t max_kept) {
+    if (!f || n_rays <= 0 || max_marched <= 0 || max_kept <= 0) return -1;
+    return carve_step(nullptr, f, n_rays, scratch_cap(n_rays), max_marched, max_kept).bytes;
+}
+
+extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
+                              int32_t res_z, const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays,
+                              const float *target_rgb, const float *target_depth, const int64_t *target_sem, const mnf_train_opts *opts,
+                              float *g_base, float *g_head, float *g_sem, float *losses, int64_t *counts_host, int64_t max_marched,
+                              int64_t max_kept, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
+    MNF_REQUIRE(f && f->params_loaded && opts && aabb_host && counts_host, "train_step: bad handle or options");
+    MNF_REQUIRE(binaries && occs && rays_o && rays_d && target_rgb && target_depth && target_sem && g_base && g_head && g_sem && losses && workspace,
+                "train_step: null pointer");
+    MNF_REQUIRE(n_rays > 0 && max_marched > 0 && max_kept > 0 && opts->render_step_size > 0.f, "train_step: bad sizes");
+    hipStream_t s = as_stream(stream);
+    const int32_t cap = scratch_cap(n_rays);
+    const StepWs w = carve_step((char *)workspace, f, n_rays, cap, max_marched, max_kept);
+    if (workspace_bytes < w.bytes) { set_error("train_step: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)w.bytes); return MNF_ERR_WORKSPACE; }
+    const int C = f->cfg.num_semantic_classes;
+    const int64_t cells = (int64_t)res_x * res_y * res_z;
+    counts_host[0] = counts_host[1] = 0;
+    MNF_HIP(hipMemsetAsync(losses, 0, 4 * sizeof(float), s));
+    // ---- occupancy sampling (occ_grid.py:80-238): march, density pre-pass, visibility filter
+    hipLaunchKernelGGL(planes_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
+                       opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, occs, cells, opts->alpha_thre, w.alpha_thre);
+    int rc = mnf_sample_rays(rays_o, rays_d, n_rays, binaries, res_x, res_y, res_z, aabb_host, w.nearp, w.farp, opts->render_step_size,
+                             opts->cone_angle, cap, w.scratch_ts, w.scratch_te, w.counts, bitgrid, stream);
+    if (rc) return rc;
+    rc = mnf_exclusive_scan_i64(w.counts, n_rays, w.starts, w.totals, w.scan, mnf_scan_workspace_bytes(n_rays), stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(max_kernel, dim3(1), dim3(1024), 0, s, w.counts, (int64_t)n_rays, w.totals + 2);
+    int64_t head[3] = {0, 0, 0};                                       // marched total, (kept total, later), longest ray
+    MNF_HIP(hipMemcpyAsync(head, w.totals, sizeof(head), hipMemcpyDeviceToHost, s));
+    MNF_HIP(hipStreamSynchronize(s));                                  // sync 1: the marched count sizes the pre-pass
+    const int64_t marched = head[0];
+    counts_host[0] = marched;
+    if (head[2] > cap) { set_error("train_step: a ray has %lld samples, more than a scratch row holds (%d): use the two-pass sampler", (long long)head[2], cap); return MNF_ERR_UNSUPPORTED; }
+    if (marched > max_marched) { set_error("train_step: %lld marched samples exceed max_marched %lld", (long long)marched, (long long)max_marched); return MNF_ERR_WORKSPACE; }
+    MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));
+    MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
+    MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
+    if (marched == 0) return MNF_OK;
+    // a ray longer than its scratch row would have been truncated: the rows hold `cap` samples (the reference configurations stay far below)
+    rc = mnf_compact_samples(w.scratch_ts, w.scratch_te, cap, w.starts, w.counts, n_rays, w.ts, w.te, w.ray, stream);
+    if (rc) return rc;
+    rc = mnf_field_density_rays(f, rays_o, rays_d, w.ray, w.ts, w.te, w.starts, w.counts, n_rays, marched, opts->early_stop_eps, w.sigma, stream);
+    if (rc) return rc;
+    const int vgrid = n_rays < 65535 ? n_rays : 65535;
+    hipLaunchKernelGGL(visibility_kernel<false>, dim3(vgrid), dim3(64), 0, s, n_rays, w.starts, w.counts, w.ts, w.te, w.sigma, opts->early_stop_eps,
+                       w.alpha_thre, w.kept_cnts, (const int64_t *)nullptr, (float *)nullptr, (float *)nullptr, (int64_t *)nullptr);
+    rc = mnf_exclusive_scan_i64(w.kept_cnts, n_rays, w.kept_starts, w.totals + 1, w.scan, mnf_scan_workspace_bytes(n_rays), stream);
+    if (rc) return rc;
+    int64_t kept = 0;
+    MNF_HIP(hipMemcpyAsync(&kept, w.totals + 1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    MNF_HIP(hipStreamSynchronize(s));                                  // sync 2: the surviving count sizes forward and backward
+    counts_host[1] = kept;
+    if (kept > max_kept) { set_error("train_step: %lld surviving samples exceed max_kept %lld", (long long)kept, (long long)max_kept); return MNF_ERR_WORKSPACE; }
+    if (kept == 0) return MNF_OK;
+    hipLaunchKernelGGL(visibility_kernel<true>, dim3(vgrid), dim3(64), 0, s, n_rays, w.starts, w.counts, w.ts, w.te, w.sigma, opts->early_stop_eps,
+                       w.alpha_thre, (int64_t *)nullptr, w.kept_starts, w.k_ts, w.k_te, w.k_ray);
+    // ---- sem_rendering (utils.py:362-461): field with saved activations, compositing
+    rc = mnf_field_forward_train_samples(f, rays_o, rays_d, w.k_ray, w.k_ts, w.k_te, kept, w.k_rgb, w.k_sigma, w.k_sem, w.k_pos, w.field_ws,
+                                         w.field_ws_bytes, stream);
+    if (rc) return rc;
+    float *bk = nullptr;
+    float bk_host[3] = {opts->render_bkgd[0], opts->render_bkgd[1], opts->render_bkgd[2]};
+    if (bk_host[0] != 0.f || bk_host[1] != 0.f || bk_host[2] != 0.f) {
+        bk = w.alpha_thre + 8;                                         // three floats of the small scalar block
+        MNF_HIP(hipMemcpyAsync(bk, bk_host, sizeof(bk_host), hipMemcpyHostToDevice, s));
+    }
+    rc = mnf_composite_train_forward(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, C, kept, bk, w.o_rgb, w.o_acc,
+                                     w.o_dep, w.o_sem, w.k_w, w.k_tr, nullptr, stream);
+    if (rc) return rc;
+    // ---- loss (pipeline.py:506-511) and backward (pipeline.py:518)
+    hipLaunchKernelGGL(loss_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, s, n_rays, C, w.o_rgb, w.o_dep, w.o_sem, target_rgb, target_depth, target_sem,
+                       w.g_rgb, w.g_dep, w.g_sem, losses);
+    rc = launch_status("loss_kernel");
+    if (rc) return rc;
+    rc = mnf_composite_train_backward(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, C, kept, bk, w.k_w, w.k_tr, w.o_acc,
+                                      w.o_dep, w.g_rgb, nullptr, w.g_dep, w.g_sem, w.k_dsig, w.k_drgb, w.k_dsem, stream);
+    if (rc) return rc;
+    return mnf_field_backward(f, w.k_pos, kept, w.k_drgb, w.k_dsig, w.k_dsem, w.k_rgb, w.k_sigma, w.field_ws, w.field_ws_bytes, opts->loss_scale, g_base,
+                              g_head, g_sem, stream);
+}
+
+extern "C" int64_t mnf_score_poses_workspace_bytes(int32_t n_members, int32_t n_views, int32_t n_pix, int32_t n_classes) {
+    if (n_members <= 0 || n_views <= 0 || n_pix <= 0 || n_classes <= 0) return -1;
+    const int64_t R = (int64_t)n_views * n_pix;
+    const int64_t per_member = R * (3 + 1 + 1 + n_classes + 3 + 1) * 4 + 8 * 256;
+    return R * 24 + 512 + n_members * per_member + 64 + mnf_render_workspace_bytes(R, n_pix) + 4096;
+}
+
+extern "C" int mnf_score_poses(const mnf_field_t *fields_host, const uint8_t *const *binaries_host, const uint32_t *const *bitgrids_host,
+                               int32_t n_members, int32_t res_x, int32_t res_y, int32_t res_z, const float *aabb_host, const float *c2w,
+                               int32_t n_views, int32_t width, int32_t height, float focal, const int64_t *pix_idx, int64_t n_pix,
+                               const mnf_render_opts *opts, double *terms, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
+    MNF_REQUIRE(fields_host && binaries_host && aabb_host && c2w && opts && terms && workspace && pix_idx, "score_poses: null pointer");
+    MNF_REQUIRE(n_members >= 1 && n_views >= 1 && n_pix >= 1, "score_poses: bad sizes");
+    const int C = fields_host[0]->cfg.num_semantic_classes;
+    for (int m = 1; m < n_members; ++m) MNF_REQUIRE(fields_host[m]->cfg.num_semantic_classes == C, "score_poses: members disagree on the class count");
+    const int64_t need = mnf_score_poses_workspace_bytes(n_members, n_views, (int32_t)n_pix, C);
+    if (workspace_bytes < need) { set_error("score_poses: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)need); return MNF_ERR_WORKSPACE; }
+    const int64_t R = (int64_t)n_views * n_pix;
+    char *base = (char *)workspace;
+    size_t off = 0;
+    auto take = [&](size_t b) { char *p = base + off; off += (b + 255) & ~(size_t)255; return p; };
+    float *o = (float *)take(R * 12), *d = (float *)take(R * 12);
+    // member-major stacks, exactly what mnf_score_views reads
+    float *rgb_var = (float *)take((size_t)n_members * R * 12), *depth_var = (float *)take((size_t)n_members * R * 4);
+    float *acc = (float *)take((size_t)n_members * R * 4), *sem = (float *)take((size_t)n_members * R * C * 4);
+    float *rgb = (float *)take(R * 12), *depth = (float *)take(R * 4);
+    int64_t *totals = (int64_t *)take(64);
+    void *rws = take(0);
+    const int64_t rws_bytes = workspace_bytes - (int64_t)off;
+    int rc = mnf_generate_rays(c2w, n_views, width, height, focal, pix_idx, n_pix, o, d, stream);
+    if (rc) return rc;
+    mnf_render_opts ro = *opts;
+    ro.probabilistic = 1; ro.rays_per_view = (int32_t)n_pix; ro.view_order = nullptr;
+    for (int m = 0; m < n_members; ++m) {
+        ro.bitgrid = bitgrids_host ? bitgrids_host[m] : nullptr;
+        rc = mnf_render_test(fields_host[m], binaries_host[m], res_x, res_y, res_z, aabb_host, o, d, R, &ro, rgb, acc + (size_t)m * R, depth,
+                             sem + (size_t)m * R * C, rgb_var + (size_t)m * R * 3, depth_var + (size_t)m * R, totals, rws, rws_bytes, stream);
+        if (rc) return rc;
+    }
+    return mnf_score_views(rgb_var, depth_var, acc, sem, n_members, n_views, (int32_t)n_pix, C, terms, stream);
+}

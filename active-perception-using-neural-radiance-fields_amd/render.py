@@ -231,13 +231,80 @@ def allreduce_gradients(parameters, group=None):
             p_.grad.div_(world)
 
 
+_TRAIN_CAPS = {}
+
+
+@torch.no_grad()
+def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, sem, render_bkgd=None, near_plane=0.1, far_plane=1e10,
+                           render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, early_stop_eps=1e-4, stratified=None):
+    """scripts/pipeline.py:472-518 for one model as ONE C call (`mnf_train_step`, csrc/trainstep.hip): train render (occupancy
+    sampling + density pre-pass + visibility filter + sem_rendering), the three-term loss and its backward.  Fills `.grad` of
+    the three flat parameter vectors and returns dict(loss, loss_rgb, loss_dep, loss_sem [device scalars], n_rendering_samples,
+    n_marched).  Returns None when this estimator / batch cannot take the fused path (multi-level grid, a ray longer than
+    the single-pass scratch row): the caller then uses the autograd path, which is the same arithmetic in separate calls."""
+    if estimator.levels != 1:
+        return None
+    import ctypes
+    lib = L.load_library()
+    o, d = L.contig(rays.origins.reshape(-1, 3), torch.float32), L.contig(rays.viewdirs.reshape(-1, 3), torch.float32)
+    L.require_gpu(o, d, pixels, dep, sem)
+    R, dev = o.shape[0], o.device
+    handle = radiance_field._ensure_handle()
+    binaries, aabb = _single_level(estimator)
+    bits = estimator.bitgrid()
+    res = binaries.shape[1:]
+    opts = L.TrainOpts()
+    opts.near_plane, opts.far_plane, opts.render_step_size, opts.cone_angle = near_plane, far_plane, render_step_size, cone_angle
+    opts.alpha_thre, opts.early_stop_eps, opts.loss_scale = alpha_thre, early_stop_eps, float(radiance_field.loss_scale)
+    bk = [0.0, 0.0, 0.0] if render_bkgd is None else [float(x) for x in render_bkgd.detach().cpu().reshape(-1)[:3]]
+    for i in range(3):
+        opts.render_bkgd[i] = bk[i]
+    opts.stratified = int(radiance_field.training if stratified is None else stratified)
+    opts.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    params = [radiance_field.mlp_base.params, radiance_field.mlp_head.params, radiance_field.mlp_sem.params]
+    for p_ in params:
+        if p_.grad is None or p_.grad.shape != p_.shape or not p_.grad.is_contiguous():
+            p_.grad = torch.empty_like(p_)
+    tp, td, tl = L.contig(pixels, torch.float32), L.contig(dep, torch.float32), L.contig(sem, torch.int64)
+    losses = torch.empty(4, device=dev)
+    counts = (ctypes.c_int64 * 2)()
+    key = (id(radiance_field), R)
+    cap_m, cap_k = _TRAIN_CAPS.get(key, (R * 384, R * 192))
+    for _attempt in range(4):
+        nbytes = int(lib.mnf_train_step_workspace_bytes(handle, R, cap_m, cap_k))
+        ws = _workspace(dev, nbytes)
+        try:
+            L.launch(lib.mnf_train_step, handle, L.ptr(binaries), L.ptr(bits[0]), L.ptr(estimator.occs), res[0], res[1], res[2],
+                     (ctypes.c_float * 6)(*aabb), L.ptr(o), L.ptr(d), R, L.ptr(tp), L.ptr(td), L.ptr(tl), ctypes.byref(opts),
+                     L.ptr(params[0].grad), L.ptr(params[1].grad), L.ptr(params[2].grad), L.ptr(losses), counts, cap_m, cap_k, L.ptr(ws), nbytes)
+            break
+        except L.MnfError as e:
+            if counts[0] > cap_m or counts[1] > cap_k:             # a sample bound was too small: grow and redo
+                cap_m, cap_k = max(cap_m, int(counts[0] * 1.3) + 1024), max(cap_k, int(max(counts[1], counts[0] // 3) * 1.3) + 1024)
+                continue
+            if "scratch row" in str(e):
+                return None
+            raise
+    else:
+        raise L.MnfError("train_step: sample bounds kept growing")
+    _TRAIN_CAPS[key] = (cap_m, cap_k)
+    estimator.last_sampling = {"n_marched": int(counts[0])}
+    for p_ in params:
+        torch.autograd.graph.increment_version(p_.grad)
+    return dict(loss=losses[0], loss_rgb=losses[1], loss_dep=losses[2], loss_sem=losses[3], n_rendering_samples=int(counts[1]),
+                n_marched=int(counts[0]))
+
+
 def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, sem, render_bkgd, step: int,
                near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-3, scheduler=None,
-               data_parallel_group=None, data_parallel=False):
+               data_parallel_group=None, data_parallel=False, fused=True):
     """One model's training iteration exactly as scripts/pipeline.py:447-532 sequences it: occupancy refresh every 16th
     step (:447-470), train render (:472-489), loss 10*smoothL1(rgb) + smoothL1(depth)/5 + CE(sem)/2 (:506-511),
     backward (:518), NaN-gradient guard (:520-529), optimizer and scheduler step (:531-532).  `data_parallel=True`
     averages the gradients over the ranks of `data_parallel_group` before the guard (each rank holds a slice of the rays).
+    `fused=True` (default) runs render + loss + backward as one C call (`fused_forward_backward`); `fused=False` goes through
+    the differentiable Python surface (`render_image_with_occgrid_with_depth_guide` + torch losses + autograd), which is the
+    same kernels call by call.
     Returns dict(loss, loss_rgb, loss_dep, loss_sem as device tensors, n_rendering_samples, skipped)."""
     import torch.nn.functional as F
     radiance_field.train()
@@ -246,17 +313,28 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     occ_eval_fn = NA.FieldDensityOcc(radiance_field, render_step_size)     # pipeline.py:376-378; one fused C call per refresh
 
     estimator.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre)
-    rgb, acc, depth, semantic, n_rendering_samples = render_image_with_occgrid_with_depth_guide(
-        radiance_field, estimator, rays, near_plane=near_plane, render_step_size=render_step_size, render_bkgd=render_bkgd,
-        cone_angle=cone_angle, alpha_thre=alpha_thre, depth=dep)
-    if n_rendering_samples == 0:
-        return dict(loss=None, n_rendering_samples=0, skipped=True)
-    loss_rgb = F.smooth_l1_loss(rgb, pixels)
-    loss_dep = F.smooth_l1_loss(depth, dep.unsqueeze(1))
-    loss_sem = F.cross_entropy(semantic, sem)
-    loss = loss_rgb * 10 + loss_dep / 5 + loss_sem / 2
-    optimizer.zero_grad()
-    loss.backward()
+    out = None
+    if fused:
+        out = fused_forward_backward(radiance_field, estimator, rays, pixels, dep, sem, render_bkgd, near_plane=near_plane,
+                                     render_step_size=render_step_size, cone_angle=cone_angle, alpha_thre=alpha_thre)
+    if out is not None:
+        n_rendering_samples = out["n_rendering_samples"]
+        if n_rendering_samples == 0:
+            optimizer.zero_grad()
+            return dict(loss=None, n_rendering_samples=0, skipped=True)
+        loss, loss_rgb, loss_dep, loss_sem = out["loss"], out["loss_rgb"], out["loss_dep"], out["loss_sem"]
+    else:
+        rgb, acc, depth, semantic, n_rendering_samples = render_image_with_occgrid_with_depth_guide(
+            radiance_field, estimator, rays, near_plane=near_plane, render_step_size=render_step_size, render_bkgd=render_bkgd,
+            cone_angle=cone_angle, alpha_thre=alpha_thre, depth=dep)
+        if n_rendering_samples == 0:
+            return dict(loss=None, n_rendering_samples=0, skipped=True)
+        loss_rgb = F.smooth_l1_loss(rgb, pixels)
+        loss_dep = F.smooth_l1_loss(depth, dep.unsqueeze(1))
+        loss_sem = F.cross_entropy(semantic, sem)
+        loss = loss_rgb * 10 + loss_dep / 5 + loss_sem / 2
+        optimizer.zero_grad()
+        loss.backward()
     if data_parallel:
         allreduce_gradients(radiance_field.parameters(), data_parallel_group)
     from .optim import count_nan_gradients
@@ -414,4 +492,34 @@ def score_views(radiance_fields, estimators, poses, width, height, focal, near_p
             ac.append(r["acc"].reshape(n, h * w)); sm.append(r["sem"].reshape(n, h * w, -1))
         terms_local[:n] = score_view_terms(torch.stack(rv), torch.stack(dv), torch.stack(ac), torch.stack(sm))
     terms = terms_local[:V] if group is False else gather_view_terms(terms_local, V, group)
+    return terms, trajectory_score(terms)
+
+
+@torch.no_grad()
+def score_poses(radiance_fields, estimators, poses, width, height, focal, near_plane, render_step_size, scale, cone_angle,
+                alpha_thre, device="cuda:0"):
+    """`score_views` on one rank as ONE C call (`mnf_score_poses`, csrc/trainstep.hip): poses -> the sub-sampled rays of every
+    view -> probabilistic renders by every ensemble member -> per-view terms.  Returns (terms [V,4] float64, score)."""
+    import ctypes
+    lib = L.load_library()
+    poses = np.asarray(poses)
+    V, M = poses.shape[0], len(radiance_fields)
+    c2w = torch.from_numpy(np.stack([pose_to_c2w(np.asarray(p, np.float64)) for p in poses]).astype(np.float32)[:, :3, :4].copy()).to(device)
+    h, w = int(height * scale), int(width * scale)
+    idx = torch.from_numpy(subsample_indices(width * height, h * w)).to(device)
+    handles = (ctypes.c_void_p * M)(*[f._ensure_handle() for f in radiance_fields])
+    grids = [_single_level(e) for e in estimators]
+    bins = (ctypes.c_void_p * M)(*[g[0].data_ptr() for g in grids])
+    bits = (ctypes.c_void_p * M)(*[e.bitgrid()[0].data_ptr() for e in estimators])
+    opts = L.RenderOpts()
+    opts.near_plane, opts.far_plane, opts.render_step_size = near_plane, 1e10, render_step_size
+    opts.cone_angle, opts.alpha_thre, opts.early_stop_eps = cone_angle, alpha_thre, 1e-4
+    opts.max_samples, opts.probabilistic, opts.rays_per_view, opts.sync_every = 1024, 1, h * w, 8
+    C = radiance_fields[0].num_semantic_classes
+    nbytes = int(lib.mnf_score_poses_workspace_bytes(M, V, h * w, C))
+    ws = _workspace(torch.device(device), nbytes)
+    terms = torch.empty(V, 4, dtype=torch.float64, device=device)
+    res = grids[0][0].shape[1:]
+    L.launch(lib.mnf_score_poses, handles, bins, bits, M, res[0], res[1], res[2], (ctypes.c_float * 6)(*grids[0][1]), L.ptr(c2w), V, width,
+             height, float(np.float32(focal)), L.ptr(idx), h * w, ctypes.byref(opts), L.ptr(terms), L.ptr(ws), nbytes)
     return terms, trajectory_score(terms)

@@ -313,6 +313,40 @@ int mnf_field_backward(mnf_field_t f, const float *positions, int64_t n,
                        void *workspace, int64_t workspace_bytes, float loss_scale,
                        float *g_base, float *g_head, float *g_sem, mnf_stream_t stream);
 
+/* mnf_field_forward_train for packed samples given as (ray, t_start, t_end): positions are formed in the kernel as the closure of
+ * utils.py:122-137 does (origins + dirs * (t_starts + t_ends) / 2) and also written to positions_out [n,3], which
+ * mnf_field_backward takes as `positions`. */
+int mnf_field_forward_train_samples(mnf_field_t f, const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                                    const float *t_starts, const float *t_ends, int64_t n, float *rgb, float *density,
+                                    float *sem, float *positions_out, void *workspace, int64_t workspace_bytes,
+                                    mnf_stream_t stream);
+
+/* ---------------------------------------------------------------- one training iteration's forward + loss + backward
+ * scripts/pipeline.py:472-518 for one model as ONE call: the train render `render_image_with_occgrid_with_depth_guide`
+ * (perception/models/utils.py:63-219: occupancy sampling with stratified near planes, density pre-pass and visibility filter,
+ * occ_grid.py:80-238; then sem_rendering, utils.py:362-461), the loss 10 smooth_l1(rgb) + smooth_l1(depth) / 5 + CE(sem) / 2
+ * (pipeline.py:506-511) and its backward to the three flat parameter-gradient vectors g_base / g_head / g_sem (overwritten).
+ * Not included, as in the reference they belong to the caller: occupancy refresh (mnf_update_occupancy), NaN guard
+ * (mnf_count_nan), optimizer (mnf_adam_step).  losses (device, 4 floats): total, rgb, depth, semantic terms (un-weighted means).
+ * counts_host (HOST, 2 x int64): marched samples, surviving samples (= the reference's n_rendering_samples).
+ * Sizes: the caller bounds the sample counts (max_marched, max_kept) and provides mnf_train_step_workspace_bytes(); if a
+ * bound is exceeded the call fails with MNF_ERR_WORKSPACE after filling counts_host, so the caller can retry larger.
+ * Stratified near planes: near + U[0,1) * render_step_size per ray from Philox4x32-10 (counter (ray, 0, 7, 0), key = seed).
+ * Two stream synchronisations (the two counts size the launches that follow). */
+typedef struct {
+    float near_plane, far_plane, render_step_size, cone_angle, alpha_thre, early_stop_eps;   /* utils.py:63-76 / occ_grid.py:80-96 */
+    float render_bkgd[3];
+    float loss_scale;         /* fp16 activation-gradient scale of the backward (tcnn: 128) */
+    int32_t stratified;       /* occ_grid.py:187-189 (radiance_field.training) */
+    uint64_t seed;
+} mnf_train_opts;
+int64_t mnf_train_step_workspace_bytes(mnf_field_t f, int32_t n_rays, int64_t max_marched, int64_t max_kept);
+int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
+                   int32_t res_z, const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays,
+                   const float *target_rgb, const float *target_depth, const int64_t *target_sem, const mnf_train_opts *opts,
+                   float *g_base, float *g_head, float *g_sem, float *losses, int64_t *counts_host, int64_t max_marched,
+                   int64_t max_kept, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
+
 /* ---------------------------------------------------------------- fused test-mode renderers */
 
 typedef struct {
@@ -383,6 +417,16 @@ int mnf_profile_query(const char *label_host, double *ms_host, int64_t *launches
 int mnf_score_views(const float *rgb_var, const float *depth_var, const float *acc, const float *sem,
                     int32_t n_members, int32_t n_views, int32_t n_pix, int32_t n_classes,
                     double *terms, mnf_stream_t stream);
+
+/* scripts/pipeline.py:674-781 for one trajectory as ONE call: candidate poses (c2w [n_views,3,4] f32, device) -> the
+ * sub-sampled rays of every view (pix_idx [n_pix] int64, device: the np.round(np.linspace) pixels of habitat_to_data.py:462-467)
+ * -> probabilistic renders by every ensemble member (fields_host / binaries_host / bitgrids_host: HOST arrays of n_members
+ * handles / device pointers; bitgrids_host or its entries may be NULL) -> per-view terms [n_views,4] f64 as mnf_score_views. */
+int64_t mnf_score_poses_workspace_bytes(int32_t n_members, int32_t n_views, int32_t n_pix, int32_t n_classes);
+int mnf_score_poses(const mnf_field_t *fields_host, const uint8_t *const *binaries_host, const uint32_t *const *bitgrids_host,
+                    int32_t n_members, int32_t res_x, int32_t res_y, int32_t res_z, const float *aabb_host, const float *c2w,
+                    int32_t n_views, int32_t width, int32_t height, float focal, const int64_t *pix_idx, int64_t n_pix,
+                    const mnf_render_opts *opts, double *terms, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1352,3 +1352,58 @@ def test_bf16_train_step_config5_shape():
     n_mlp = 128 * 64 + 128 * 128 + 16 * 128
     g_tab = hip.mlp_base.params.grad[n_mlp:]
     assert 0 < int((g_tab != 0).sum()) < g_tab.numel() and bool(torch.isfinite(g_tab).all())
+
+
+# ------------------------------------------------------------------ single-call C entry points (mnf_train_step, mnf_score_poses)
+def test_fused_train_step_equals_call_by_call_path():
+    """`mnf_train_step` (render + loss + backward in one C call) against the differentiable Python surface
+    (`render_image_with_occgrid_with_depth_guide` + torch's smooth_l1 / cross_entropy + autograd) on the same batch without
+    stratified jitter: identical sample counts, losses to fp32 rounding, gradients to the atomics' summation-order noise."""
+    import torch.nn.functional as F
+    from apnrf_amd import render as RD
+    sc = H.make_scene(log2_hashmap_size=15, seed=6)
+    est = H.hip_estimator(sc)
+    o, d = H.view_rays(sc, 4, h=24, w=24)
+    rays = RD.Rays(o.to(DEV), d.to(DEV))
+    rng = np.random.default_rng(3)
+    pix = torch.from_numpy(rng.random((576, 3)).astype(np.float32)).to(DEV)
+    dep = torch.from_numpy(rng.uniform(0.5, 4.0, 576).astype(np.float32)).to(DEV)
+    lab = torch.from_numpy(rng.integers(0, 29, 576)).to(DEV)
+    dep[:10] += 3.0                                            # some |depth error| > 1: the linear branch of smooth_l1
+    bk = torch.tensor([0.5, 0.2, 0.9], device=DEV)
+    a, b = H.hip_field(sc), H.hip_field(sc)
+    a.eval()
+    rgb, acc, depth, sem, n = RD.render_image_with_occgrid_with_depth_guide(a, est, rays, render_bkgd=bk, **H.RENDER_KW)
+    l_rgb, l_dep, l_sem = F.smooth_l1_loss(rgb, pix), F.smooth_l1_loss(depth, dep.unsqueeze(1)), F.cross_entropy(sem, lab)
+    (l_rgb * 10 + l_dep / 5 + l_sem / 2).backward()
+    out = RD.fused_forward_backward(b, est, rays, pix, dep, lab, bk, stratified=False, **H.RENDER_KW)
+    assert out is not None and out["n_rendering_samples"] == n and out["n_marched"] >= n
+    for got, want in ((out["loss_rgb"], l_rgb), (out["loss_dep"], l_dep), (out["loss_sem"], l_sem), (out["loss"], l_rgb * 10 + l_dep / 5 + l_sem / 2)):
+        np.testing.assert_allclose(float(got), float(want), rtol=2e-5)
+    for pa, pb, name in zip(a.parameters(), b.parameters(), ("dir", "base", "head", "sem")):
+        if pa.numel():
+            _grad_close(pb.grad, pa.grad.cpu(), name, rel=2e-3, cos=0.99999)
+    # and through train_step: both routes take the same optimizer step from the same state (no jitter in eval-less mode is not
+    # available there, so only the plumbing is checked: a finite loss, parameters moved, counts reported)
+    from apnrf_amd.optim import FusedAdam
+    opt = FusedAdam(b.parameters(), lr=1e-3, eps=1e-15)
+    before = b.mlp_head.params.detach().clone()
+    r = RD.train_step(b, est, opt, rays, pix, dep, lab, bk, step=3, **H.RENDER_KW)
+    assert not r["skipped"] and np.isfinite(float(r["loss"])) and r["n_rendering_samples"] > 0 and (b.mlp_head.params.detach() != before).any()
+    r2 = RD.train_step(b, est, opt, rays, pix, dep, lab, bk, step=5, fused=False, **H.RENDER_KW)
+    assert not r2["skipped"] and abs(float(r2["loss"]) - float(r["loss"])) < 0.5
+
+
+def test_score_poses_single_call_equals_python_route(scene):
+    """`mnf_score_poses` (poses -> rays -> probabilistic renders of both members -> terms, one C call) gives the terms of
+    `render.score_views` (the same steps call by call) bit for bit."""
+    import ctypes
+    from apnrf_amd import _lib as L
+    from apnrf_amd import render as RD
+    sc2 = dict(scene); sc2["params"] = H.S.make_field_params(seed=1)
+    fields = [H.hip_field(scene), H.hip_field(sc2)]
+    ests = [H.hip_estimator(scene), H.hip_estimator(scene)]
+    poses = scene["poses"][[1, 4, 6]]
+    terms_py, score_py = RD.score_views(fields, ests, poses, 640, 640, 320.0, 0.1, 1e-3, 0.025, 0.004, 0.01, DEV)
+    terms_c, score_c = RD.score_poses(fields, ests, poses, 640, 640, 320.0, 0.1, 1e-3, 0.025, 0.004, 0.01, DEV)
+    assert torch.equal(terms_py, terms_c) and float(score_py) == float(score_c)
