@@ -33,6 +33,10 @@
                                -4.6 % field-kernel time; 0 = uniform priority, 1 = the opposite assignment (-2.4 %), 3 = static
                                priority for waves 4-7, 4 = start-up stagger (both 0 %), 5 = finest levels first (+4.7 %) */
 #endif
+#ifndef MNF_SKIP_HEADS
+#define MNF_SKIP_HEADS 0    /* experiment (measured: no gain, 0.570 -> 0.569): skip the head networks of renderer tiles in which no sample
+                               passes the alpha threshold */
+#endif
 #ifndef MNF_NT_FROM
 #define MNF_NT_FROM 99      /* experiment: hash levels >= this are fetched with non-temporal loads */
 #endif
@@ -382,6 +386,26 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             continue;
         }
 
+#if MNF_SKIP_HEADS
+        // Renderer tiles in which no sample passes the alpha threshold (utils.py:714-725 drops them after the query): their rgb
+        // and semantic outputs are multiplied by a zero weight in the compositing, so the two head networks are not evaluated.
+        // The density still goes through the compositing (transmittance, sample counters, ray retirement): results unchanged.
+        if (MODE == 2 && !SAVE) {
+            const float sdt0 = valid ? sigma * (tsm.te - tsm.ts) : 0.0f;
+            const float alpha0 = 1.0f - expf(-sdt0);
+            const bool keep0 = valid && !(args.io.fr.alpha_thre > 0.f && !(alpha0 >= args.io.fr.alpha_thre));
+            if (__ballot(keep0) == 0ull) {
+                const float zrgb[3] = {0.f, 0.f, 0.f};
+                f32x16 zsem[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) zsem[ct][i] = 0.0f;
+                fused_composite(args.io.fr, args.C, lane, tsm, sigma, zrgb, zsem, wc);
+                continue;
+            }
+        }
+#endif
         // ---- heads ----
         half8 bgeo[CT][1];
 #pragma unroll

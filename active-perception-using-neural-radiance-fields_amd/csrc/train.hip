@@ -324,6 +324,9 @@ __global__ void __launch_bounds__(256) fold_replicas_kernel(const float *__restr
 // crossings (6 or 7 flushed corners instead of 8).  The kernel is bound by the rate of memory-side read-modify-writes.  Ray structure is not needed: runs are found by comparing
 // consecutive cells, and a chunk boundary only costs one extra flush.
 constexpr int kWalkChunk = 128;
+#ifndef MNF_EXP_SCATTER
+#define MNF_EXP_SCATTER 0
+#endif
 
 __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs args) {
     const int sub = threadIdx.x & 31;                 // lane inside the half-wave
@@ -354,7 +357,11 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
                 q = (((idx - q) >> 1) + q) >> m.div_shift;
                 idx -= q * m.size;
             }
+#if MNF_EXP_SCATTER != 1      /* timing experiment: 1 = the walk without its atomics */
             atomicAdd(g_dst + ((size_t)(m.offset + idx) << 2) + feat, acc);
+#else
+            if (acc == 123.456f) g_dst[0] = acc;
+#endif
         }
         acc = 0.0f;
     };

@@ -45,15 +45,23 @@ __global__ void __launch_bounds__(256) planes_kernel(int32_t n, float near_plane
     nearp[r] = v; farp[r] = far_plane;
 }
 
-// mean of occs (occ_grid.py:192: alpha_thre = min(alpha_thre, self.occs.mean())) in double, one workgroup
-__global__ void __launch_bounds__(1024) mean_kernel(const float *__restrict__ x, int64_t n, float alpha_thre, float *__restrict__ out) {
-    __shared__ double s[1024];
+// mean of occs (occ_grid.py:192: alpha_thre = min(alpha_thre, self.occs.mean())) in double: 128 partial sums, then one wave
+__global__ void __launch_bounds__(256) mean_partial_kernel(const float *__restrict__ x, int64_t n, double *__restrict__ part) {
+    __shared__ double s[256];
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += (double)x[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += (double)x[i];
     s[threadIdx.x] = acc;
     __syncthreads();
-    for (int d = 512; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d]; __syncthreads(); }
-    if (threadIdx.x == 0) out[0] = fminf(alpha_thre, (float)(s[0] / (double)n));
+    for (int d = 128; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0];
+}
+
+__global__ void __launch_bounds__(64) mean_final_kernel(const double *__restrict__ part, int n_part, int64_t n, float alpha_thre, float *__restrict__ out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 64) acc += part[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (threadIdx.x == 0) out[0] = fminf(alpha_thre, (float)(acc / (double)n));
 }
 
 __global__ void __launch_bounds__(1024) max_kernel(const int64_t *__restrict__ x, int64_t n, int64_t *__restrict__ out) {
@@ -178,7 +186,7 @@ StepWs carve_step(char *base, mnf_field_t f, int64_t R, int32_t cap, int64_t max
     const int C = f->cfg.num_semantic_classes;
     w.nearp = (float *)take(R * 4); w.farp = (float *)take(R * 4); w.alpha_thre = (float *)take(256);
     w.counts = (int64_t *)take(R * 8); w.starts = (int64_t *)take(R * 8); w.kept_cnts = (int64_t *)take(R * 8); w.kept_starts = (int64_t *)take(R * 8);
-    w.totals = (int64_t *)take(256); w.scan = (int64_t *)take((size_t)mnf_scan_workspace_bytes(R));
+    w.totals = (int64_t *)take(2048); w.scan = (int64_t *)take((size_t)mnf_scan_workspace_bytes(R));
     w.scratch_ts = (float *)take((size_t)R * cap * 4); w.scratch_te = (float *)take((size_t)R * cap * 4);
     w.ts = (float *)take(max_marched * 4); w.te = (float *)take(max_marched * 4); w.sigma = (float *)take(max_marched * 4); w.ray = (int64_t *)take(max_marched * 8);
     w.k_ts = (float *)take(max_kept * 4); w.k_te = (float *)take(max_kept * 4); w.k_ray = (int64_t *)take(max_kept * 8);
@@ -228,7 +236,9 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     // ---- occupancy sampling (occ_grid.py:80-238): march, density pre-pass, visibility filter
     hipLaunchKernelGGL(planes_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
                        opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp);
-    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, occs, cells, opts->alpha_thre, w.alpha_thre);
+    double *mean_part = reinterpret_cast<double *>(w.totals + 8);          // 128 doubles behind the counters
+    hipLaunchKernelGGL(mean_partial_kernel, dim3(128), dim3(256), 0, s, occs, cells, mean_part);
+    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(64), 0, s, (const double *)mean_part, 128, cells, opts->alpha_thre, w.alpha_thre);
     int rc = mnf_sample_rays(rays_o, rays_d, n_rays, binaries, res_x, res_y, res_z, aabb_host, w.nearp, w.farp, opts->render_step_size,
                              opts->cone_angle, cap, w.scratch_ts, w.scratch_te, w.counts, bitgrid, stream);
     if (rc) return rc;

@@ -275,6 +275,8 @@ def main():
         n_per_view = width * height
         bk = torch.zeros(3)
 
+        process_samples = torch.zeros((), dtype=torch.int64, device=dev)      # every evaluated sample of this process (PMC sums cover all launches)
+
         def render_pass(V, steps, warmup, with_events):
             batches = [(rays.origins[k:k + V].reshape(-1, 3).contiguous(), rays.viewdirs[k:k + V].reshape(-1, 3).contiguous())
                        for k in range(0, 8, V)]
@@ -282,7 +284,9 @@ def main():
 
             def step(i):
                 o, d = batches[i % len(batches)]
-                return RD.render_views(field, est, o, d, n_per_view, 1024, render_bkgd=bk, image_hw=(height, width), **H.RENDER_KW)
+                r = RD.render_views(field, est, o, d, n_per_view, 1024, render_bkgd=bk, image_hw=(height, width), **H.RENDER_KW)
+                process_samples.add_(r["total"][1])
+                return r
 
             def collect(r):
                 evaluated.add_(r["total"][1])
@@ -324,6 +328,7 @@ def main():
             dt1, s1 = render_pass(1, args.steps, 2, False)
             line["render_views1"] = {"value": n_per_view * world * args.steps / dt1, "unit": "rays/s", "ms_per_view": 1e3 * dt1 / args.steps,
                                      "samples_per_ray": s1 / (n_per_view * args.steps)}
+        line["samples"] = {"timed": int(samples), "process_total": int(process_samples.item())}
         del rays
 
     # ------------------------------------------------------------------ BASELINE config 5: train step

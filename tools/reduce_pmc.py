@@ -17,12 +17,12 @@ def sums(path, counter):
 
 fetch, write = sums(sys.argv[1], "FETCH_SIZE"), sums(sys.argv[2], "WRITE_SIZE")
 line = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])
-samples = line["samples"]["timed"] + line["samples"]["warmup"]
+samples = line["samples"]["process_total"]       # every field-kernel launch of the profiled process (warm-up, timed pass, one-view pass)
 f_kb, launches = fetch["field_kernel"]
 w_kb, _ = write["field_kernel"]
 res = {
     "source": "tools/pmc.sh <tag> FETCH_SIZE ; tools/pmc.sh <tag> WRITE_SIZE (rocprofv3 --kernel-trace --pmc, separate passes, "
-              f"bench.py --steps {line['steps']} --warmup {line['warmup']} --no-cpu-baseline --no-kernel-timing); reduced by tools/reduce_pmc.py",
+              f"bench.py --workload render800 --steps {line['steps']} --warmup {line['warmup']} --no-cpu-baseline --no-kernel-timing); reduced by tools/reduce_pmc.py",
     "field_kernel": {
         "launches": launches, "FETCH_SIZE_KB_sum": f_kb, "WRITE_SIZE_KB_sum": w_kb, "samples_evaluated": samples,
         "fetch_bytes_per_sample_raw": f_kb * 1024 / samples, "write_bytes_per_sample": w_kb * 1024 / samples,
