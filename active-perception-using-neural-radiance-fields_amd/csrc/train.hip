@@ -281,7 +281,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__
 
 // ------------------------------------------------------------------ hash-grid gradient scatter
 struct HashBwdArgs {
-    const float *positions;
+    const float *positions;   // aabb-normalised positions xn = (x - aabb_min) / (aabb_max - aabb_min) [N,3] (normalize_kernel): the
+                              // three divisions are done once per sample, not once per sample, level and lane
     const float *dX;      // [16][Np][4]
     int64_t Np;
     int level0;           // first level of this launch (experiments; 0 in production)
@@ -293,6 +294,16 @@ struct HashBwdArgs {
     float aabb[6];
     LevelMeta levels[16];
 };
+
+// ngp.py:177-178 once per sample for the scatter below (the same expression as the forward kernel's fetch_sample)
+__global__ void __launch_bounds__(256) normalize_kernel(const float *__restrict__ pos, int64_t n, float a0, float a1, float a2, float a3, float a4,
+                                                        float a5, float *__restrict__ xn) {
+    const float lo[3] = {a0, a1, a2}, hi[3] = {a3, a4, a5};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += (int64_t)blockDim.x * gridDim.x) {
+        const int d = (int)(i % 3);
+        xn[i] = (pos[i] - lo[d]) / (hi[d] - lo[d]);
+    }
+}
 
 // Samples arrive sorted by ray and by distance along the ray, so consecutive samples usually sit in the same grid cell
 // of a level (always at the coarse levels, often at the fine ones).  A scattered float atomic is the slow operation
@@ -339,7 +350,6 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
     const LevelMeta m = args.levels[l];
     float *const g_dst = l < args.repl_levels ? args.repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.g_table;
     const float *gl = args.dX + ((int64_t)l * args.Np) * 4 + feat;
-    const float ext[3] = {args.aabb[3] - args.aabb[0], args.aabb[4] - args.aabb[1], args.aabb[5] - args.aabb[2]};
     const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
 
     float acc = 0.0f;
@@ -378,9 +388,9 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
         for (int b = 0; b < B; ++b) {
             if (i + b >= i1) break;
             // position -> cell and fractions, exactly as hash_prep
-            const float x0 = __builtin_fmaf(m.scale, (sx[b] - args.aabb[0]) / ext[0], 0.5f);
-            const float x1 = __builtin_fmaf(m.scale, (sy[b] - args.aabb[1]) / ext[1], 0.5f);
-            const float x2 = __builtin_fmaf(m.scale, (sz[b] - args.aabb[2]) / ext[2], 0.5f);
+            const float x0 = __builtin_fmaf(m.scale, sx[b], 0.5f);
+            const float x1 = __builtin_fmaf(m.scale, sy[b], 0.5f);
+            const float x2 = __builtin_fmaf(m.scale, sz[b], 0.5f);
             const float f0 = floorf(x0), f1 = floorf(x1), f2 = floorf(x2);
             const int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
             const int dx = c0 - cx, dy = c1 - cy, dz = c2 - cz;
@@ -421,7 +431,7 @@ __global__ void __launch_bounds__(256) hash_bwd_simple_kernel(const HashBwdArgs 
     if (i >= args.n) return;
     float xn[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) xn[d] = (args.positions[3 * i + d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);
+    for (int d = 0; d < 3; ++d) xn[d] = args.positions[3 * i + d];
     const int l = blockIdx.y + args.level0;
     const LevelMeta m = args.levels[l];
     float *const g_dst = l < args.repl_levels ? args.repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.g_table;
@@ -625,7 +635,7 @@ void free_train_state_impl(mnf_field_t f) {
 }
 
 struct WsView {
-    half_t *act; uint8_t *masks; float *dX;
+    half_t *act; uint8_t *masks; float *dX, *xn;
     int64_t Np, bytes;
 };
 
@@ -637,6 +647,7 @@ static WsView carve_train(const TrainTables &tt, void *base, int64_t n) {
     v.act = (half_t *)take((size_t)tt.rows * v.Np * 2);
     v.masks = (uint8_t *)take((size_t)(v.Np / 64) * tt.mask_blocks * CT * 64);
     v.dX = (float *)take((size_t)v.Np * 64 * 4);
+    v.xn = (float *)take((size_t)v.Np * 3 * 4);
     v.bytes = (int64_t)off;
     return v;
 }
@@ -732,7 +743,13 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float 
     if (rc) return rc;
     // hash-table gradient
     HashBwdArgs hb;
-    hb.positions = positions; hb.dX = v.dX; hb.Np = v.Np; hb.g_table = g_base + f->n_base_mlp; hb.n = n;
+    {
+        const float *ab = f->cfg.aabb;
+        const int64_t blocks = ceil_div(3 * n, 256);
+        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, positions, n, ab[0], ab[1], ab[2], ab[3],
+                           ab[4], ab[5], v.xn);
+    }
+    hb.positions = v.xn; hb.dX = v.dX; hb.Np = v.Np; hb.g_table = g_base + f->n_base_mlp; hb.n = n;
     std::memcpy(hb.aabb, f->cfg.aabb, sizeof(hb.aabb));
     std::memcpy(hb.levels, f->levels, sizeof(hb.levels));
     int n_levels = 16;
