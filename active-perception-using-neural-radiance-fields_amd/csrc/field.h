@@ -72,6 +72,10 @@ struct FieldIO {
     int32_t n_rays;
     int32_t *ray_counter;
     float sdt_stop;                          // stop a ray once its accumulated sigma * dt exceeds this
+    // two-launch forms of the field evaluation (enc != NULL): phase 0 = gather launch then MLP launch on one stream (diagnostic
+    // MNF_FIELD_SPLIT), 1 = gather launch only, 2 = MLP launch only; both restricted to tile chunk `chunk` of `n_chunks`
+    // (0 / 0 = all tiles).  The renderer's pipelined mode (MNF_FIELD_PIPE) runs phase 1 of chunk i+1 beside phase 2 of chunk i.
+    int32_t phase, chunk, n_chunks, mlp_waves, gather_grid;
     const void *enc;                         // optional [ceil(n/64)][8][64] x 16 B feature scratch: non-null selects the
                                              // two-launch path (encode_kernel, then the MLP kernel on its output)
     // outputs: user layout (modes 0,1) ...

@@ -152,12 +152,14 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
     constexpr int LPB = 2;   // levels per batch of gathers (16 loads in flight per wave, <= 80 VGPRs, 6 waves per SIMD)
     int64_t n = args.io.n;
     if (MODE == 2) { n = *args.io.n_dev; if (n > args.io.n_cap) n = args.io.n_cap; }
-    const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
-    const int64_t n_groups = (n_tiles + kWaves - 1) / kWaves;
+    const int64_t n_tiles_all = (n + kWaveSamples - 1) / kWaveSamples;
+    int64_t tile0 = 0, n_tiles = n_tiles_all;
+    if (args.io.n_chunks > 1) { tile0 = n_tiles_all * args.io.chunk / args.io.n_chunks; n_tiles = n_tiles_all * (args.io.chunk + 1) / args.io.n_chunks; }
+    const int64_t n_groups = (n_tiles - tile0 + kWaves - 1) / kWaves;
     int64_t g_first, g_end, g_step;
     group_range(n_groups, g_first, g_end, g_step);
     for (int64_t grp = g_first; grp < g_end; grp += g_step) {
-        const int64_t tile = grp * kWaves + wave;
+        const int64_t tile = tile0 + grp * kWaves + wave;
         if (tile >= n_tiles) break;
         const int64_t col = tile * kWaveSamples + lane;
         ColData cd = {-1, 64, 0.f, 0.f};
@@ -210,10 +212,12 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 
     int64_t n = args.io.n;
     if (MODE == 2) { n = *args.io.n_dev; if (n > args.io.n_cap) n = args.io.n_cap; }
-    const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
-    if (n_tiles == 0) return;
+    const int64_t n_tiles_all = (n + kWaveSamples - 1) / kWaveSamples;
+    if (n_tiles_all == 0) return;
+    int64_t tile0 = 0, n_tiles = n_tiles_all;
+    if (ENC && args.io.n_chunks > 1) { tile0 = n_tiles_all * args.io.chunk / args.io.n_chunks; n_tiles = n_tiles_all * (args.io.chunk + 1) / args.io.n_chunks; }
     const int wpb = MODE == 3 ? kWavesPerBlock : args.active_waves;
-    const int64_t n_groups = (n_tiles + wpb - 1) / wpb;
+    const int64_t n_groups = (n_tiles - tile0 + wpb - 1) / wpb;
     int64_t g_first = 0, g_end = 1, g_step = 1;
     if (MODE != 3) group_range(n_groups, g_first, g_end, g_step);
     if (g_first >= g_end) return;   // uniform per block: nothing to do
@@ -235,7 +239,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     int64_t ray_start = 0, ray_cnt = 0, ray_base = 0;
     float ray_sdt = 0.0f;
     for (int64_t grp = g_first; MODE == 3 || grp < g_end; grp += g_step) {
-        int64_t tile = grp * wpb + wave, col, n_eff = n;
+        int64_t tile = tile0 + grp * wpb + wave, col, n_eff = n;
         if (MODE == 3) {
             if (ray_base >= ray_cnt || ray_sdt > args.io.sdt_stop) {
                 int r = 0;
@@ -619,11 +623,15 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     } else if (io.enc) {
         // two launches: gather at high occupancy, then the register-heavy MLP chain on ready-made fragments
         half8 *enc = reinterpret_cast<half8 *>(const_cast<void *>(io.enc));
-        const int egrid = 2048;
-        if (io.mode == 0) hipLaunchKernelGGL((encode_kernel<0>), dim3(egrid), dim3(kEncodeThreads), 0, stream, a, enc);
-        else if (io.mode == 1) hipLaunchKernelGGL((encode_kernel<1>), dim3(egrid), dim3(kEncodeThreads), 0, stream, a, enc);
-        else hipLaunchKernelGGL((encode_kernel<2>), dim3(egrid), dim3(kEncodeThreads), 0, stream, a, enc);
-        if (density_only) {
+        const int egrid = io.gather_grid > 0 ? io.gather_grid : 2048;
+        if (io.phase != 2) {
+            if (io.mode == 0) hipLaunchKernelGGL((encode_kernel<0>), dim3(egrid), dim3(kEncodeThreads), 0, stream, a, enc);
+            else if (io.mode == 1) hipLaunchKernelGGL((encode_kernel<1>), dim3(egrid), dim3(kEncodeThreads), 0, stream, a, enc);
+            else hipLaunchKernelGGL((encode_kernel<2>), dim3(egrid), dim3(kEncodeThreads), 0, stream, a, enc);
+        }
+        if (io.mlp_waves > 0 && io.mlp_waves <= kWavesPerBlock) a.active_waves = io.mlp_waves;
+        if (io.phase == 1) {
+        } else if (density_only) {
             if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, true, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
             else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, true, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
             else hipLaunchKernelGGL((field_kernel<W, NH, 2, true, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);

@@ -46,6 +46,33 @@ static bool split_field() {
     return on;
 }
 
+// Pipelined two-kernel form of a render round's field evaluation (experiment, MNF_FIELD_PIPE=<chunks>[,<rounds>[,<mlp waves>[,<gather
+// blocks>]]]): the round's tiles are cut into chunks; the gather kernel of chunk i+1 (few registers, many waves) runs on one stream
+// beside the MLP + compositing kernel of chunk i (4 of its 8 waves active, so that both fit a CU) on another.  This is the form
+// role specialisation can take on gfx950, where all waves of ONE kernel share a register allocation.
+struct PipeCfg { int chunks = 0, rounds = 24, mlp_waves = 4, gather_grid = 768; };
+static const PipeCfg &pipe_cfg() {
+    static PipeCfg c = [] {
+        PipeCfg p;
+        if (const char *e = getenv("MNF_FIELD_PIPE")) sscanf(e, "%d,%d,%d,%d", &p.chunks, &p.rounds, &p.mlp_waves, &p.gather_grid);
+        return p;
+    }();
+    return c;
+}
+struct PipeRes { hipStream_t sg = nullptr, sm = nullptr; hipEvent_t e_main = nullptr, e_done = nullptr; std::vector<hipEvent_t> eg; };
+static PipeRes &pipe_res() {
+    static thread_local PipeRes r;
+    if (!r.sg) {
+        (void)hipStreamCreateWithFlags(&r.sg, hipStreamNonBlocking);
+        (void)hipStreamCreateWithFlags(&r.sm, hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&r.e_main, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&r.e_done, hipEventDisableTiming);
+        r.eg.resize(16);
+        for (auto &e : r.eg) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    }
+    return r;
+}
+
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // A view's rays are marched by its own ceil(rays_per_view / kMarchThreads) workgroups (the last one partly idle when the
@@ -79,7 +106,7 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     p = take(col_cap * 4); if (ws) ws->col_ts = (float *)p;
     p = take(col_cap * 4); if (ws) ws->col_te = (float *)p;
     p = take(col_cap / 64 * 4); if (ws) ws->tile_hdr = (int32_t *)p;
-    if (split_field()) { p = take((col_cap / 64 + 1) * 8192); if (ws) ws->enc = p; }   // diagnostic two-launch path: 128 B per column
+    if (split_field() || pipe_cfg().chunks > 0) { p = take((col_cap / 64 + 1) * 8192); if (ws) ws->enc = p; }   // two-launch paths: 128 B per column
     else if (ws) ws->enc = nullptr;
     if (ws) ws->col_cap = col_cap;
     return (int64_t)off;
@@ -417,7 +444,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     FieldIO io = {};
     io.mode = 2; io.rays_o = rays_o; io.rays_d = rays_d; io.col_ray = ws.col_ray; io.t_starts = ws.col_ts; io.t_ends = ws.col_te;
     io.n_dev = ws.n_cols; io.n_cap = ws.col_cap;
-    io.enc = ws.enc;   // non-null only under MNF_FIELD_SPLIT (diagnostic: gather and MLP as two launches)
+    io.enc = split_field() ? ws.enc : nullptr;   // MNF_FIELD_SPLIT (diagnostic: gather and MLP as two launches on one stream)
     io.fr.tile_hdr = ws.tile_hdr; io.fr.alive = ws.alive; io.fr.alive_count = ws.alive_count;
     io.fr.n_samples = ws.n_samples; io.fr.rgb = rgb; io.fr.acc = acc; io.fr.depth = depth; io.fr.sem = sem;
     io.fr.rgb_var = out.rgb_var; io.fr.depth_var = out.depth_var;
@@ -449,9 +476,32 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
             hipLaunchKernelGGL(round_march_kernel<false>, dim3(march_grid), dim3(kMarchThreads), 0, s, n_rays,
                                opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
                                opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order, bpv);
-        {
+        const PipeCfg &pc = pipe_cfg();
+        if (pc.chunks > 1 && round < pc.rounds) {
             ProfScope ps("field_render", s);
-            rc = launch_field(f, io, false, s);   // field evaluation + compositing + ray retirement of this round
+            PipeRes &pr = pipe_res();
+            const int nc = pc.chunks < 16 ? pc.chunks : 16;
+            MNF_HIP(hipEventRecord(pr.e_main, s));
+            MNF_HIP(hipStreamWaitEvent(pr.sg, pr.e_main, 0));
+            MNF_HIP(hipStreamWaitEvent(pr.sm, pr.e_main, 0));
+            FieldIO pio = io;
+            pio.enc = ws.enc; pio.n_chunks = nc; pio.mlp_waves = pc.mlp_waves; pio.gather_grid = pc.gather_grid;
+            for (int c = 0; c < nc && !rc; ++c) {
+                pio.chunk = c;
+                pio.phase = 1;
+                rc = launch_field(f, pio, false, pr.sg);
+                MNF_HIP(hipEventRecord(pr.eg[c], pr.sg));
+                MNF_HIP(hipStreamWaitEvent(pr.sm, pr.eg[c], 0));
+                pio.phase = 2;
+                if (!rc) rc = launch_field(f, pio, false, pr.sm);
+            }
+            MNF_HIP(hipEventRecord(pr.e_done, pr.sm));
+            MNF_HIP(hipStreamWaitEvent(s, pr.e_done, 0));
+        } else {
+            ProfScope ps("field_render", s);
+            FieldIO fio = io;
+            if (pc.chunks > 0 && !split_field()) fio.enc = nullptr;      // late rounds of the pipelined mode: the fused kernel
+            rc = launch_field(f, fio, false, s);   // field evaluation + compositing + ray retirement of this round
         }
         if (rc) return rc;
     }
