@@ -33,6 +33,9 @@
                                -4.6 % field-kernel time; 0 = uniform priority, 1 = the opposite assignment (-2.4 %), 3 = static
                                priority for waves 4-7, 4 = start-up stagger (both 0 %), 5 = finest levels first (+4.7 %) */
 #endif
+#ifndef MNF_KNOCK
+#define MNF_KNOCK 0
+#endif
 #ifndef MNF_SKIP_HEADS
 #define MNF_SKIP_HEADS 0    /* experiment (measured: no gain, 0.570 -> 0.569): skip the head networks of renderer tiles in which no sample
                                passes the alpha threshold */
@@ -275,7 +278,18 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) bfeat[ct][ks] = src[(ks * 2 + ct) * 64];
-        } else {
+        }
+#if MNF_KNOCK & 4
+        else {   // diagnostic build: no hash gather, features made up from the position
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bfeat[ct][ks][j] = (half_t)(xn[j % 3] * 0.01f * (float)(j + ks + ct));
+        }
+#else
+        else {
             // double-buffered: the loads of batch kb+1 are issued before batch kb is blended
             LevelPrep prep[2][4];
             tab4 v[2][4][8];
@@ -333,6 +347,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             __builtin_amdgcn_s_setprio(2);
 #endif
         }
+#endif
 
         // the mask-dump base of this tile
         uint8_t *mdump = SAVE ? args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
@@ -390,6 +405,12 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             continue;
         }
 
+#if MNF_KNOCK & 2
+        if (MODE == 2 && !SAVE) {   // diagnostic build: density only, no head networks, no compositing
+            if (sigma == 1.2345e30f) args.io.fr.acc[0] = sigma;
+            continue;
+        }
+#endif
 #if MNF_SKIP_HEADS
         // Renderer tiles in which no sample passes the alpha threshold (utils.py:714-725 drops them after the query): their rgb
         // and semantic outputs are multiplied by a zero weight in the compositing, so the two head networks are not evaluated.
@@ -465,7 +486,17 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             rgb[k] = 1.0f / (1.0f + expf(-(h ? t1 : t0)));   // ngp.py:211-212
         }
         if (MODE == 2) {
+#if MNF_KNOCK & 1
+            // diagnostic build: the compositing epilogue is skipped (outputs kept alive by a store that never happens)
+            float sink = sigma + rgb[0] + rgb[1] + rgb[2];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sink += out_sem[ct][i];
+            if (sink == 1.2345e30f) args.io.fr.acc[0] = sink;
+#else
             fused_composite(args.io.fr, args.C, lane, tsm, sigma, rgb, out_sem, wc);
+#endif
             continue;
         }
         if (col < n) {

@@ -51,6 +51,14 @@ static bool split_field() {
 // beside the MLP + compositing kernel of chunk i (4 of its 8 waves active, so that both fit a CU) on another.  This is the form
 // role specialisation can take on gfx950, where all waves of ONE kernel share a register allocation.
 struct PipeCfg { int chunks = 0, rounds = 24, mlp_waves = 4, gather_grid = 768; };
+static hipEvent_t *log_events() {
+    static hipEvent_t ev[2];
+    static bool made = false;
+    if (!made) { (void)hipEventCreate(&ev[0]); (void)hipEventCreate(&ev[1]); made = true; }
+    return ev;
+}
+static bool round_log() { static const bool on = getenv("MNF_ROUND_LOG") != nullptr; return on; }
+
 static const PipeCfg &pipe_cfg() {
     static PipeCfg c = [] {
         PipeCfg p;
@@ -85,7 +93,8 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     // columns of one round: a tile of 64 holds floor(64/stride) rays of `stride` columns, so it is at least half
     // used; n_alive*stride <= max(R, 4*n_alive) <= 4R (utils.py:670) -> <= 8R, plus one partial tile per workgroup
     // (a march workgroup never mixes views: march_blocks_per_view() workgroups per view, so `stride` is the view's budget)
-    const int64_t col_cap = 8 * n_rays + 64 * (n_views * march_blocks_per_view(rays_per_view) + 2);
+    int64_t col_cap = 8 * n_rays + 64 * (n_views * march_blocks_per_view(rays_per_view) + 2);
+    if (const char *e = getenv("MNF_MIN_SAMPLES")) col_cap = (int64_t)(2 * atoi(e) > 8 ? 2 * atoi(e) : 8) * n_rays + 64 * (n_views * march_blocks_per_view(rays_per_view) + 2);   // diagnostic schedule
     size_t off = 0;
     auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += align_up(bytes); return p; };
     char *p;
@@ -425,7 +434,8 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     const int ray_blocks = (int)ceil_div(n_rays > n_views ? n_rays : n_views, kRayThreads);
     const float *ab = aabb_host;
     const I3 res = {res_x, res_y, res_z};
-    const int32_t min_samples = opts->cone_angle == 0.f ? 1 : 4;                      // utils.py:645
+    int32_t min_samples = opts->cone_angle == 0.f ? 1 : 4;                            // utils.py:645
+    if (const char *e = getenv("MNF_MIN_SAMPLES")) min_samples = atoi(e);   // diagnostic only (locality experiments): NOT the reference's schedule
     const float opc_thre = 1.0f - opts->early_stop_eps;                                // utils.py:664
 
     const int64_t cells = (int64_t)res_x * res_y * res_z;
@@ -499,11 +509,25 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
             MNF_HIP(hipStreamWaitEvent(s, pr.e_done, 0));
         } else {
             ProfScope ps("field_render", s);
+            if (round_log()) MNF_HIP(hipEventRecord(log_events()[0], s));
             FieldIO fio = io;
             if (pc.chunks > 0 && !split_field()) fio.enc = nullptr;      // late rounds of the pipelined mode: the fused kernel
             rc = launch_field(f, fio, false, s);   // field evaluation + compositing + ray retirement of this round
+            if (round_log()) MNF_HIP(hipEventRecord(log_events()[1], s));
         }
         if (rc) return rc;
+        if (round_log()) {   // MNF_ROUND_LOG (diagnostic, synchronises every round): columns and per-view budgets of the round
+            int32_t n_cols = 0, ns[8] = {0}, act[8] = {0};
+            MNF_HIP(hipMemcpyAsync(&n_cols, ws.n_cols, 4, hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(ns, ws.n_samples, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(act, ws.active, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipStreamSynchronize(s));
+            float ms = 0.f;
+            if (!(pc.chunks > 1 && round < pc.rounds)) (void)hipEventElapsedTime(&ms, log_events()[0], log_events()[1]);
+            fprintf(stderr, "[mnf round %d] cols %d  field %.4f ms (%.3f ns/col)  budgets", round, n_cols, ms, n_cols ? ms * 1e6 / n_cols : 0.0);
+            for (int v = 0; v < n_views && v < 8; ++v) fprintf(stderr, " %d", act[v] ? ns[v] : 0);
+            fprintf(stderr, "\n");
+        }
     }
     hipLaunchKernelGGL(finalize_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,
                        opts->render_bkgd[0], opts->render_bkgd[1], opts->render_bkgd[2], out);

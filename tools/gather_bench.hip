@@ -1,51 +1,76 @@
-// Microbenchmark: throughput of divergent 8-byte gathers on MI355X as a function of the working set and of how many
-// lanes of a wave share an address.  Build: hipcc --offload-arch=gfx950 -O3 tools/gather_bench.hip -o gpurun_out/gather_bench
-// Each wave issues batches of 32 independent global_load_dwordx2 (as field_kernel does) from a table of `entries` 8-byte
-// entries; lane addresses come from a cheap hash of (wave, iteration, lane / share).
+// Divergent-gather ceiling of gfx950's vector memory path (tools/, not product): every lane of every wave loads W bytes
+// from a pseudo-random entry of a table of S bytes.  What the hash-grid gather of csrc/field.hip does per corner, without
+// anything else.  Reports lane-loads/s, chip-wide and per CU per clock (2.4 GHz), for S in {16 KiB .. 256 MiB} and
+// W in {4, 8, 16}; `coherent` variants let groups of G consecutive lanes fall in one 128-B line (neighbouring samples of
+// a ray meeting the same coarse cell).
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/gather_bench tools/gather_bench.hip && /tmp/gather_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include <cstdlib>
 #include <cstdint>
+#include <vector>
 
-typedef float f2 __attribute__((ext_vector_type(2)));
+template <int W> struct Vec;
+template <> struct Vec<4> { using T = uint32_t; };
+template <> struct Vec<8> { using T = uint2; };
+template <> struct Vec<16> { using T = uint4; };
 
-__global__ void __launch_bounds__(512, 2) gather_kernel(const f2 *__restrict__ table, uint32_t mask, int share, int iters, float *out) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    f2 acc = {0.f, 0.f};
-    for (int it = 0; it < iters; ++it) {
-        f2 v[32];
+__device__ __forceinline__ uint32_t fold(uint32_t v) { return v; }
+__device__ __forceinline__ uint32_t fold(uint2 v) { return v.x ^ v.y; }
+__device__ __forceinline__ uint32_t fold(uint4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
+
+template <int W, int G>
+__global__ __launch_bounds__(256) void gather(const uint8_t* __restrict__ table, uint32_t mask_entries, int iters, uint32_t* out) {
+    using T = typename Vec<W>::T;
+    const T* t = (const T*)table;
+    uint32_t lane_id = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t grp = lane_id / G, sub = lane_id % G;
+    uint32_t s = grp * 2654435761u + 12345u;
+    uint32_t acc = 0;
+    constexpr int per_line = 128 / W;
+    for (int i = 0; i < iters; ++i) {
+        T v[8];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            uint32_t h = (wave * 2654435761u) ^ ((uint32_t)(it * 32 + k) * 805459861u) ^ ((lane / share) * 2246822519u);
-            h ^= h >> 15; h *= 2654435761u; h ^= h >> 13;
-            v[k] = table[h & mask];
+        for (int u = 0; u < 8; ++u) {
+            s = s * 1664525u + 1013904223u;
+            uint32_t h = s ^ (s >> 15);
+            uint32_t e = G == 1 ? h : (h / per_line * per_line + (sub * (per_line / G) + (h >> 20)) % per_line);
+            v[u] = t[e & mask_entries];
         }
 #pragma unroll
-        for (int k = 0; k < 32; ++k) acc += v[k];
+        for (int u = 0; u < 8; ++u) acc ^= fold(v[u]);
     }
-    if (acc.x == 123.f) out[0] = acc.y;
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int W, int G>
+double run(const uint8_t* table, size_t bytes, int blocks, int iters, uint32_t* out) {
+    uint32_t mask = (uint32_t)(bytes / W - 1);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    gather<W, G><<<blocks, 256>>>(table, mask, iters, out);
+    hipEventRecord(a);
+    for (int r = 0; r < 3; ++r) gather<W, G><<<blocks, 256>>>(table, mask, iters, out);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    double loads = 3.0 * blocks * 256.0 * iters * 8;
+    return loads / (ms * 1e-3);
 }
 
 int main() {
-    const size_t max_entries = 1u << 26;   // 512 MB
-    f2 *table; float *out;
-    hipMalloc(&table, max_entries * sizeof(f2)); hipMalloc(&out, 4);
-    hipMemset(table, 0, max_entries * sizeof(f2));
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int iters = 16, grid = 256 * 8;
-    printf("working_set share  lane_gathers/clk/CU   GB/s(8B/lane)\n");
-    for (int lg = 10; lg <= 26; lg += 2) {
-        for (int share : {1, 4, 64}) {
-            const uint32_t mask = (1u << lg) - 1;
-            hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(512), 0, 0, table, mask, share, 2, out);
-            hipEventRecord(e0);
-            hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(512), 0, 0, table, mask, share, iters, out);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            const double lanes = (double)grid * 8 * 64 * 32 * iters;
-            printf("%8.1f KB  %3d   %8.3f   %8.1f   (%.3f ms)\n", (double)(8u << lg) / 1024.0, share, lanes / (ms * 1e-3 * 2.4e9 * 256), lanes * 8 / (ms * 1e-3) / 1e9, ms);
-        }
+    size_t cap = 256u << 20;
+    uint8_t* table; hipMalloc(&table, cap);
+    std::vector<uint32_t> h(cap / 4);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (uint32_t)i * 2246822519u;
+    hipMemcpy(table, h.data(), cap, hipMemcpyHostToDevice);
+    uint32_t* out; hipMalloc(&out, 4);
+    const int blocks = 256 * 8;      // 8 workgroups of 4 waves per CU = 8 waves per SIMD
+    const int iters = 256;
+    size_t sizes[] = {16u << 10, 256u << 10, 2u << 20, 4u << 20, 16u << 20, 64u << 20, 256u << 20};
+    printf("%-10s %-4s %-6s %12s %14s %12s\n", "table", "W", "lanes/line", "Gloads/s", "loads/clk/CU", "GB/s useful");
+    for (size_t s : sizes) {
+        double r;
+#define ROW(W, G) r = run<W, G>(table, s, blocks, iters, out); \
+        printf("%-10zu %-4d %-6d %12.1f %14.3f %12.1f\n", s >> 10, W, G, r * 1e-9, r / 256 / 2.4e9, r * W * 1e-9);
+        ROW(4, 1) ROW(8, 1) ROW(16, 1) ROW(8, 4) ROW(8, 16)
     }
     return 0;
 }
