@@ -18,13 +18,13 @@ SOURCES = {
     "api.cpp": [],
     "march.hip": ["-ffp-contract=off"],
     "render.hip": ["-ffp-contract=off"],
-    "field.hip": [],
+    "field.hip": ["-fno-slp-vectorize"],   # packed-fp32 pairing of the compositing butterflies keeps their DPP operands from folding into the adds
     "train.hip": [],
     "composite_train.hip": [],
     "occupancy.hip": ["-ffp-contract=off"],
     "vanilla.hip": [],
     "trainstep.hip": ["-ffp-contract=off"],
-    "field.hip@bf16": ["-DMNF_BF16"],
+    "field.hip@bf16": ["-DMNF_BF16", "-fno-slp-vectorize"],
     "train.hip@bf16": ["-DMNF_BF16"],
 }
 

@@ -101,6 +101,37 @@ __device__ __forceinline__ void seg_scan32(f32x16 &v, bool head, int c, int maxl
     }
 }
 
+// ---- aligned power-of-two runs (the renderer's tiles at budget 4, 8 or 16: 90 % of all columns) ----
+// Every slot of `stride` columns starts at a multiple of `stride`, so a per-ray sum is a butterfly over the slot's lanes: one
+// DPP add per step and value, no segment flags.  quad_perm [1,0,3,2] / [2,3,0,1] inside a quad, then row_half_mirror (8 lanes)
+// and row_mirror (16 lanes): after each step every lane of the slot holds the same partial sum.
+template <int N>
+__device__ __forceinline__ void slot_totals(float (&v)[N], int stride) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_f32<0xB1, 0xf>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_f32<0x4E, 0xf>(v[k]);
+    if (stride >= 8) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += dpp_f32<0x141, 0xf>(v[k]);
+    }
+    if (stride >= 16) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += dpp_f32<0x140, 0xf>(v[k]);
+    }
+}
+
+// Four values per lane summed over the four lanes of a quad, lane j of the quad keeping the total of value j (a
+// reduce-scatter: 9 instructions instead of 8 for four all-lane totals, and each lane then owns ONE value to write).
+__device__ __forceinline__ float quad_reduce_scatter(float x0, float x1, float x2, float x3, bool odd, bool upper) {
+    const float keep01 = odd ? x1 : x0, send01 = odd ? x0 : x1;
+    const float keep23 = odd ? x3 : x2, send23 = odd ? x2 : x3;
+    const float a = keep01 + dpp_f32<0xB1, 0xf>(send01);     // lanes {j, j^1}: value (j & 1)
+    const float b = keep23 + dpp_f32<0xB1, 0xf>(send23);     //                 value 2 + (j & 1)
+    const float keep = upper ? b : a, send = upper ? a : b;
+    return keep + dpp_f32<0x4E, 0xf>(send);                  // all four lanes: value j
+}
+
 // Wave-uniform counters carried across the tiles a wave processes and flushed with ONE atomic each at the end
 // (same-address atomics serialise at ~12 ns apiece: one per tile would cost more than the compositing itself).
 struct WaveCounters {
@@ -129,6 +160,110 @@ struct TileSample {     // this lane's sample (lane = sample)
     float ts, te;
     float opac0;        // opacity of the ray before this round (prefetched)
 };
+
+// ---- per-ray bookkeeping by the owner lane (both compositing paths) ----
+__device__ __forceinline__ void finish_rays(const FusedRender &fr, int lane, const TileSample &sm, WaveCounters &wc, bool owner, int view,
+                                            int budget, int cnt, const float (&c_new)[3], float d_new, float o_new,
+                                            const float (&v_prev)[4], const float (&vt)[4], float n_kept, float n_marched) {
+    bool still_alive = false;
+    if (owner) {
+        if (fr.probabilistic) {
+            fr.rgb_var[3 * sm.ray] = v_prev[0] + vt[0]; fr.rgb_var[3 * sm.ray + 1] = v_prev[1] + vt[1];
+            fr.rgb_var[3 * sm.ray + 2] = v_prev[2] + vt[2];
+            fr.depth_var[sm.ray] = v_prev[3] + vt[3];
+        }
+        fr.rgb[3 * sm.ray] = c_new[0]; fr.rgb[3 * sm.ray + 1] = c_new[1]; fr.rgb[3 * sm.ray + 2] = c_new[2];
+        fr.acc[sm.ray] = o_new; fr.depth[sm.ray] = d_new;
+        still_alive = (o_new <= fr.opc_thre) && (cnt == budget);       // utils.py:751-756
+        fr.alive[sm.ray] = still_alive;
+    }
+    // survivors per view and sample totals: accumulated per wave, flushed when the view changes / after the last tile
+    const unsigned long long m_owner = __ballot(owner);
+    if (m_owner) {
+        const int first = __ffsll((unsigned long long)m_owner) - 1;
+        const int view0 = __shfl(view, first, 64);
+        const bool uniform = __ballot(owner && view != view0) == 0;
+        const unsigned long long m_alive = __ballot(still_alive);
+        if (uniform) {
+            if (wc.view != view0) { flush_alive(fr, wc, lane); wc.view = view0; }
+            wc.alive += __popcll(m_alive);
+        } else if (still_alive) {
+            atomicAdd(&fr.alive_count[view], 1);
+        }
+        float kept = owner ? n_kept : 0.0f, marched = owner ? n_marched : 0.0f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { kept += __shfl_xor(kept, d, 64); marched += __shfl_xor(marched, d, 64); }
+        wc.kept += kept; wc.marched += marched;
+    }
+}
+
+
+// Compositing of a tile whose slots are aligned runs of 4, 8 or 16 columns (see slot_totals): same arithmetic per sample as
+// the general path below, the per-ray sums as butterflies, and the 29 semantic sums reduce-scattered so that every lane of
+// a slot's first quad adds ONE row per register group into the ray's accumulator (8 read-modify-writes per lane and tile
+// instead of 32 by the slot's last lane).  Summation order differs from the general path (pairwise instead of front to back).
+__device__ __forceinline__ void fused_composite_slots(const FusedRender &fr, int C, int lane, const TileSample &sm, float sigma,
+                                                      const float (&rgb)[3], const f32x16 (&sem)[CT], WaveCounters &wc, bool owner,
+                                                      int view, int budget, const float (&c_prev)[3], float d_prev,
+                                                      const float (&v_prev)[4]) {
+    const int c = lane & 31, h = lane >> 5, stride = sm.stride;
+    const int j = c & 3;
+    // ---- the semantic accumulators this lane will update: ray of the slot that column 32 ct + c belongs to, rows j + 4h + 8g ----
+    float s_prev[CT][4];
+    float *s_ptr[CT];
+    bool s_store[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int slot_ray = __shfl(sm.ray, (32 * ct + c) & ~(stride - 1), 64);     // a slot's valid columns come first
+        s_store[ct] = slot_ray >= 0 && (c & (stride - 1)) < 4;
+        s_ptr[ct] = fr.sem + ((int64_t)(slot_ray < 0 ? 0 : slot_ray) * C + j + 4 * h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s_prev[ct][g] = (s_store[ct] && j + 4 * h + 8 * g < C) ? s_ptr[ct][8 * g] : 0.f;
+    }
+    // ---- weights (volrend.py:258-267, :361-365; utils.py:712-725): exclusive prefix of sigma*dt inside the slot ----
+    const float sdt = sm.valid ? sigma * (sm.te - sm.ts) : 0.0f;
+    const int in_slot = lane & (stride - 1);
+    float incl = sdt;
+    {
+        float t = dpp_f32<0x111, 0xf>(incl); incl += in_slot >= 1 ? t : 0.0f;      // row_shr:1
+        t = dpp_f32<0x112, 0xf>(incl); incl += in_slot >= 2 ? t : 0.0f;            // row_shr:2
+        if (stride >= 8) { t = dpp_f32<0x114, 0xf>(incl); incl += in_slot >= 4 ? t : 0.0f; }
+        if (stride >= 16) { t = dpp_f32<0x118, 0xf>(incl); incl += in_slot >= 8 ? t : 0.0f; }
+    }
+    const float excl = incl - sdt;
+    const float alpha = 1.0f - expf(-sdt);
+    const float opac0 = sm.opac0;
+    const float w = expf(-excl) * (1.0f - opac0) * alpha;
+    const bool keep = sm.valid && !(fr.alpha_thre > 0.f && !(alpha >= fr.alpha_thre));
+    const float wk = keep ? w : 0.0f;
+    const float tmid = (sm.ts + sm.te) / 2.0f;
+    float tot[7] = {wk, wk * rgb[0], wk * rgb[1], wk * rgb[2], wk * tmid, keep ? 1.0f : 0.0f, sm.valid ? 1.0f : 0.0f};
+    slot_totals<7>(tot, stride);
+    const int cnt = (int)(tot[6] + 0.5f);
+    const float c_new[3] = {c_prev[0] + tot[1], c_prev[1] + tot[2], c_prev[2] + tot[3]};
+    const float d_new = d_prev + tot[4];
+    const float o_new = opac0 + tot[0];
+    float vt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (fr.probabilistic) {                                                     // utils.py:984-999
+        const float e0 = rgb[0] - c_new[0], e1 = rgb[1] - c_new[1], e2 = rgb[2] - c_new[2], ed = tmid - d_new;
+        vt[0] = wk * (e0 * e0); vt[1] = wk * (e1 * e1); vt[2] = wk * (e2 * e2); vt[3] = wk * (ed * ed);
+        slot_totals<4>(vt, stride);
+    }
+    // ---- semantic logits (MFMA layout: lane (c, h) holds rows 8g + 4h + i of column 32 ct + c in register 4g + i) ----
+    const bool odd = (j & 1) != 0, upper = (j & 2) != 0;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const float wm = __shfl(wk, 32 * ct + c, 64);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float z = quad_reduce_scatter(sem[ct][4 * g] * wm, sem[ct][4 * g + 1] * wm, sem[ct][4 * g + 2] * wm, sem[ct][4 * g + 3] * wm, odd, upper);
+            if (stride >= 8) z += dpp_f32<0x104, 0xf>(z);                        // row_shl:4: the slot's first quad collects the second ...
+            if (stride >= 16) z += dpp_f32<0x108, 0xf>(z);                       // row_shl:8: ... and the third and fourth
+            if (s_store[ct] && j + 4 * h + 8 * g < C) s_ptr[ct][8 * g] = s_prev[ct][g] + z;
+        }
+    }
+    finish_rays(fr, lane, sm, wc, owner, view, budget, cnt, c_new, d_new, o_new, v_prev, vt, tot[5], tot[6]);
+}
 
 __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, int lane, const TileSample &sm,
                                                 float sigma, const float (&rgb)[3], const f32x16 (&sem)[CT], WaveCounters &wc) {
@@ -159,6 +294,11 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
             v_prev[0] = fr.rgb_var[3 * sm.ray]; v_prev[1] = fr.rgb_var[3 * sm.ray + 1]; v_prev[2] = fr.rgb_var[3 * sm.ray + 2];
             v_prev[3] = fr.depth_var[sm.ray];
         }
+    }
+    const bool fast = maxlen == 4 || maxlen == 8 || maxlen == 16;      // wave-uniform: aligned power-of-two slots
+    if (fast) {
+        fused_composite_slots(fr, C, lane, sm, sigma, rgb, sem, wc, owner, view, budget, c_prev, d_prev, v_prev);
+        return;
     }
     f32x16 s_prev[CT];
     int raym[CT];
@@ -241,37 +381,7 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
             }
         }
     }
-    // ---- per-ray bookkeeping by the owner lane ----
-    bool still_alive = false;
-    if (owner) {
-        if (fr.probabilistic) {
-            fr.rgb_var[3 * sm.ray] = v_prev[0] + vt[0]; fr.rgb_var[3 * sm.ray + 1] = v_prev[1] + vt[1];
-            fr.rgb_var[3 * sm.ray + 2] = v_prev[2] + vt[2];
-            fr.depth_var[sm.ray] = v_prev[3] + vt[3];
-        }
-        fr.rgb[3 * sm.ray] = c_new[0]; fr.rgb[3 * sm.ray + 1] = c_new[1]; fr.rgb[3 * sm.ray + 2] = c_new[2];
-        fr.acc[sm.ray] = o_new; fr.depth[sm.ray] = d_new;
-        still_alive = (o_new <= fr.opc_thre) && (cnt == budget);       // utils.py:751-756
-        fr.alive[sm.ray] = still_alive;
-    }
-    // survivors per view and sample totals: accumulated per wave, flushed when the view changes / after the last tile
-    const unsigned long long m_owner = __ballot(owner);
-    if (m_owner) {
-        const int first = __ffsll((unsigned long long)m_owner) - 1;
-        const int view0 = __shfl(view, first, 64);
-        const bool uniform = __ballot(owner && view != view0) == 0;
-        const unsigned long long m_alive = __ballot(still_alive);
-        if (uniform) {
-            if (wc.view != view0) { flush_alive(fr, wc, lane); wc.view = view0; }
-            wc.alive += __popcll(m_alive);
-        } else if (still_alive) {
-            atomicAdd(&fr.alive_count[view], 1);
-        }
-        float kept = owner ? tot[5] : 0.0f, marched = owner ? tot[6] : 0.0f;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { kept += __shfl_xor(kept, d, 64); marched += __shfl_xor(marched, d, 64); }
-        wc.kept += kept; wc.marched += marched;
-    }
+    finish_rays(fr, lane, sm, wc, owner, view, budget, cnt, c_new, d_new, o_new, v_prev, vt, tot[5], tot[6]);
 }
 
 MNF_DT_END
