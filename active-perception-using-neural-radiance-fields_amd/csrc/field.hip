@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
         TileSample tsm;
         bool valid, selector;
         fetch_sample<MODE, false>(args, cd, col, n, xn, dir, tsm, valid, selector);
-        const LevelMeta *lv = levels_here(args.levels);
+        const LevelsPtr lv = levels_here(args.levels);
         const bool in_box = __ballot(valid && !selector) == 0ull;   // wave-uniform: the cheap dense-level wrap applies
         half8 *dst = enc + (tile * 8 + (lane >> 5)) * 64 + (lane & 31);
 #pragma unroll
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
             tab4 v[LPB][8];
 #pragma unroll
             for (int q = 0; q < LPB; ++q) {
-                hash_prep(lv[l0 + q], xn, prep[q], in_box);
+                hash_prep(level_meta(lv, l0 + q), xn, prep[q], in_box);
                 hash_load(args.table, prep[q], v[q]);
             }
 #pragma unroll
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         TileSample tsm;
         bool valid, selector;
         fetch_sample<MODE, !DENSITY_ONLY>(args, cd, col, n_eff, xn, dir, tsm, valid, selector);
-        const LevelMeta *lv = levels_here(args.levels);
+        const LevelsPtr lv = levels_here(args.levels);
         const bool in_box = __ballot(valid && !selector) == 0ull;   // wave-uniform: the cheap dense-level wrap applies
 
         // ---- hash encode: all 16 levels of this lane's sample (one k-step = 4 levels = 32 gathers in flight),
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                hash_prep(lv[4 * MNF_KB(0) + q], xn, prep[0][q], in_box);
+                hash_prep(level_meta(lv, 4 * MNF_KB(0) + q), xn, prep[0][q], in_box);
                 hash_load(args.table, prep[0][q], v[0][q], 4 * MNF_KB(0) + q >= MNF_NT_FROM);
             }
 #pragma unroll
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 if (kb < 3) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        hash_prep(lv[4 * MNF_KB(kb + 1) + q], xn, prep[nxt][q], in_box);
+                        hash_prep(level_meta(lv, 4 * MNF_KB(kb + 1) + q), xn, prep[nxt][q], in_box);
                         hash_load(args.table, prep[nxt][q], v[nxt][q], 4 * MNF_KB(kb + 1) + q >= MNF_NT_FROM);
                     }
                 }

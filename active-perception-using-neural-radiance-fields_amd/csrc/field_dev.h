@@ -247,10 +247,21 @@ __device__ __forceinline__ void exchange_halves(half8 &lo, half8 &hi) {
 }
 
 // The level table pointer made opaque once per tile, so that the scalar loads of a level's metadata stay next to their
-// use instead of being hoisted out of the tile loop (where they would occupy, and spill, a hundred SGPRs).
-__device__ __forceinline__ const LevelMeta *levels_here(const LevelMeta *p) {
-    asm volatile("" : "+s"(p));
-    return p;
+// use instead of being hoisted out of the tile loop (where they would occupy, and spill, a hundred SGPRs).  The pointer is
+// typed CONSTANT address space: only then does the compiler read the metadata with s_load into SGPRs.  Through a plain
+// global pointer (round 1 and the first half of round 2) it issued vector loads with a uniform address, whose
+// `s_waitcnt vmcnt(0)` also waited for every hash gather still in flight, and it treated `hashed` as a per-lane value.
+typedef const LevelMeta __attribute__((address_space(4))) *LevelsPtr;
+__device__ __forceinline__ LevelsPtr levels_here(const LevelMeta *p) {
+    LevelsPtr q = (LevelsPtr)(uintptr_t)p;
+    asm volatile("" : "+s"(q));
+    return q;
+}
+__device__ __forceinline__ LevelMeta level_meta(LevelsPtr lv, int l) {
+    LevelMeta m;
+    m.scale = lv[l].scale; m.res = lv[l].res; m.size = lv[l].size; m.offset = lv[l].offset; m.hashed = lv[l].hashed;
+    m.div_magic = lv[l].div_magic; m.div_shift = lv[l].div_shift;
+    return m;
 }
 
 // One hash level (wave-uniform metadata) for the lane's sample, split in two so that the gathers of several
