@@ -155,7 +155,8 @@ __device__ __forceinline__ void flush_counters(const FusedRender &fr, WaveCounte
 
 struct TileSample {     // this lane's sample (lane = sample)
     int ray;            // -1: unused column
-    int stride;         // wave-uniform: columns per ray slot in this tile (upper bound of a run length)
+    int stride;         // wave-uniform: columns per ray slot in this tile = the per-ray budget of the tile's view this round
+    int view;           // wave-uniform: the view all rays of the tile belong to (a march workgroup never mixes views)
     bool valid;
     float ts, te;
     float opac0;        // opacity of the ray before this round (prefetched)
@@ -164,7 +165,7 @@ struct TileSample {     // this lane's sample (lane = sample)
 // ---- per-ray bookkeeping by the owner lane (both compositing paths) ----
 __device__ __forceinline__ void finish_rays(const FusedRender &fr, int lane, const TileSample &sm, WaveCounters &wc, bool owner, int view,
                                             int budget, int cnt, const float (&c_new)[3], float d_new, float o_new,
-                                            const float (&v_prev)[4], const float (&vt)[4], float n_kept, float n_marched) {
+                                            const float (&v_prev)[4], const float (&vt)[4], int tile_kept, int tile_marched) {
     bool still_alive = false;
     if (owner) {
         if (fr.probabilistic) {
@@ -178,25 +179,13 @@ __device__ __forceinline__ void finish_rays(const FusedRender &fr, int lane, con
         fr.alive[sm.ray] = still_alive;
     }
     // survivors per view and sample totals: accumulated per wave, flushed when the view changes / after the last tile
-    const unsigned long long m_owner = __ballot(owner);
-    if (m_owner) {
-        const int first = __ffsll((unsigned long long)m_owner) - 1;
-        const int view0 = __shfl(view, first, 64);
-        const bool uniform = __ballot(owner && view != view0) == 0;
-        const unsigned long long m_alive = __ballot(still_alive);
-        if (uniform) {
-            if (wc.view != view0) { flush_alive(fr, wc, lane); wc.view = view0; }
-            wc.alive += __popcll(m_alive);
-        } else if (still_alive) {
-            atomicAdd(&fr.alive_count[view], 1);
-        }
-        float kept = owner ? n_kept : 0.0f, marched = owner ? n_marched : 0.0f;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { kept += __shfl_xor(kept, d, 64); marched += __shfl_xor(marched, d, 64); }
-        wc.kept += kept; wc.marched += marched;
+    // survivors of the tile's view and sample totals: accumulated per wave, flushed when the view changes / after the last tile
+    if (__ballot(owner)) {
+        if (wc.view != sm.view) { flush_alive(fr, wc, lane); wc.view = sm.view; }
+        wc.alive += __popcll(__ballot(still_alive));
+        wc.kept += (float)tile_kept; wc.marched += (float)tile_marched;
     }
 }
-
 
 // Compositing of a tile whose slots are aligned runs of 4, 8 or 16 columns (see slot_totals): same arithmetic per sample as
 // the general path below, the per-ray sums as butterflies, and the 29 semantic sums reduce-scattered so that every lane of
@@ -237,9 +226,9 @@ __device__ __forceinline__ void fused_composite_slots(const FusedRender &fr, int
     const bool keep = sm.valid && !(fr.alpha_thre > 0.f && !(alpha >= fr.alpha_thre));
     const float wk = keep ? w : 0.0f;
     const float tmid = (sm.ts + sm.te) / 2.0f;
-    float tot[7] = {wk, wk * rgb[0], wk * rgb[1], wk * rgb[2], wk * tmid, keep ? 1.0f : 0.0f, sm.valid ? 1.0f : 0.0f};
-    slot_totals<7>(tot, stride);
-    const int cnt = (int)(tot[6] + 0.5f);
+    float tot[6] = {wk, wk * rgb[0], wk * rgb[1], wk * rgb[2], wk * tmid, sm.valid ? 1.0f : 0.0f};
+    slot_totals<6>(tot, stride);
+    const int cnt = (int)(tot[5] + 0.5f);
     const float c_new[3] = {c_prev[0] + tot[1], c_prev[1] + tot[2], c_prev[2] + tot[3]};
     const float d_new = d_prev + tot[4];
     const float o_new = opac0 + tot[0];
@@ -262,7 +251,7 @@ __device__ __forceinline__ void fused_composite_slots(const FusedRender &fr, int
             if (s_store[ct] && j + 4 * h + 8 * g < C) s_ptr[ct][8 * g] = s_prev[ct][g] + z;
         }
     }
-    finish_rays(fr, lane, sm, wc, owner, view, budget, cnt, c_new, d_new, o_new, v_prev, vt, tot[5], tot[6]);
+    finish_rays(fr, lane, sm, wc, owner, view, budget, cnt, c_new, d_new, o_new, v_prev, vt, __popcll(__ballot(keep)), __popcll(__ballot(sm.valid)));
 }
 
 __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, int lane, const TileSample &sm,
@@ -288,8 +277,7 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
         d_prev = fr.depth[sm.ray];
     }
     if (owner) {
-        view = sm.ray / fr.rays_per_view;
-        budget = fr.n_samples[view];
+        view = sm.view; budget = sm.stride;
         if (fr.probabilistic) {
             v_prev[0] = fr.rgb_var[3 * sm.ray]; v_prev[1] = fr.rgb_var[3 * sm.ray + 1]; v_prev[2] = fr.rgb_var[3 * sm.ray + 2];
             v_prev[3] = fr.depth_var[sm.ray];
@@ -381,7 +369,7 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
             }
         }
     }
-    finish_rays(fr, lane, sm, wc, owner, view, budget, cnt, c_new, d_new, o_new, v_prev, vt, tot[5], tot[6]);
+    finish_rays(fr, lane, sm, wc, owner, view, budget, cnt, c_new, d_new, o_new, v_prev, vt, __popcll(__ballot(keep)), __popcll(__ballot(sm.valid)));
 }
 
 MNF_DT_END

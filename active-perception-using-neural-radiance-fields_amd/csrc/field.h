@@ -45,7 +45,7 @@ namespace mnf {
 // Per-round volumetric compositing fused into the field kernel's epilogue (mode 2): the renderer's tiles hold
 // `nslots` rays x `stride` columns (a ray never straddles a 64-column tile), described by one header word per tile.
 struct FusedRender {
-    const int32_t *tile_hdr;      // [tiles]: columns per ray slot (upper bound of a run length)
+    const int32_t *tile_hdr;      // [tiles]: columns per ray slot (= the budget of the tile's view this round) | view << 8
     uint8_t *alive;               // [rays]
     int32_t *alive_count;         // [views] survivors of this round
     const int32_t *n_samples;     // [views] this round's per-ray sample budget

@@ -52,14 +52,15 @@ MNF_DT_BEGIN
 // Renderer columns of one tile (mode 2).  (Loading them one tile ahead was measured: slower, the four extra live
 // registers cost more than the hidden round trip.)
 struct ColData {
-    int ray, stride;
+    int ray, stride, view;
     float ts, te;
 };
 
 __device__ __forceinline__ ColData load_cols(const KernelArgs &args, int64_t tile, int lane) {
     const int64_t col = tile * kWaveSamples + lane;
     ColData c;
-    c.stride = args.io.fr.tile_hdr[tile];
+    const int hdr = __builtin_amdgcn_readfirstlane(args.io.fr.tile_hdr[tile]);
+    c.stride = hdr & 0xff; c.view = hdr >> 8;
     c.ray = args.io.col_ray[col];
     c.ts = args.io.t_starts[col]; c.te = args.io.t_ends[col];
     return c;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void fetch_sample(const KernelArgs &args, const ColDa
     valid = col < n;
     float pos[3] = {0.f, 0.f, 0.f};
     dir[0] = 0.f; dir[1] = 0.f; dir[2] = 1.f;
-    tsm = {-1, 64, false, 0.f, 0.f, 0.f};
+    tsm = {-1, 64, 0, false, 0.f, 0.f, 0.f};
     if (MODE == 0) {
         if (valid) {
 #pragma unroll
@@ -100,7 +101,7 @@ __device__ __forceinline__ void fetch_sample(const KernelArgs &args, const ColDa
         }
     } else {
         // renderer tile: column -> ray id (-1: unused); the runs of equal ids are the rays of this tile
-        tsm.stride = cd.stride; tsm.ray = cd.ray; tsm.ts = cd.ts; tsm.te = cd.te;
+        tsm.stride = cd.stride; tsm.view = cd.view; tsm.ray = cd.ray; tsm.ts = cd.ts; tsm.te = cd.te;
         valid = tsm.ray >= 0;
         tsm.valid = valid;
         if (valid) {
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
         const int64_t tile = tile0 + grp * kWaves + wave;
         if (tile >= n_tiles) break;
         const int64_t col = tile * kWaveSamples + lane;
-        ColData cd = {-1, 64, 0.f, 0.f};
+        ColData cd = {-1, 64, 0, 0.f, 0.f};
         if (MODE == 2) cd = load_cols(args, tile, lane);
         float xn[3], dir[3];
         TileSample tsm;
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             col = tile * kWaveSamples + lane;
         }
         // ---- this lane's sample ----
-        ColData cd = {-1, 64, 0.f, 0.f};
+        ColData cd = {-1, 64, 0, 0.f, 0.f};
         if (MODE == 2) cd = load_cols(args, tile, lane);
         float xn[3], dir[3];
         TileSample tsm;

@@ -268,29 +268,51 @@ __device__ __forceinline__ LevelMeta level_meta(LevelsPtr lv, int l) {
 // levels can be in flight together: hash_prep computes the 8 byte offsets and the separable trilinear weights,
 // hash_blend consumes the 8 loaded entries.  The blend weight of corner (bx,by,bz) is ((wx*wy)*wz), the same
 // association as the oracle's running product.
+#ifndef MNF_MIX_ASM
+#define MNF_MIX_ASM 0
+#endif
+#ifndef MNF_PK
+#define MNF_PK 0            /* 1: x/y grid position, fraction and 1 - fraction as v_pk_fma_f32 / v_pk_add_f32 with the level scale read
+                               from an SGPR pair.  Measured on MI355X: wrong features in lanes 48..63 of occasional tiles (13-35 samples
+                               of 5037 per launch, different tiles from run to run; tools/debug_pk.py) -- kept off.  The packed
+                               multiplies of the blend weights (VGPR operands only) are not affected and stay on. */
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // arithmetic on it is v_pk_{mul,add,fma}_f32: two fp32 results per issue slot
+
 struct LevelPrep {
     uint32_t off[8];
-    float wxy[4], wz[2];
+    f32x2 wxy[2];    // {wx0*wy0, wx1*wy0}, {wx0*wy1, wx1*wy1}
+    float wz[2];
 };
 
 __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], LevelPrep &o, bool all_in_box = false) {
-    float frac[3];
-    uint32_t cell[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float pos = __builtin_fmaf(m.scale, xn[d], 0.5f);
-        const float fl = floorf(pos);
-        frac[d] = pos - fl;
-        cell[d] = (uint32_t)(int32_t)fl;
-    }
-    const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]};
-    o.wz[0] = 1.0f - frac[2]; o.wz[1] = frac[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o.wxy[k] = (1.0f * wx[k & 1]) * wy[k >> 1];
+    // x and y as one packed pair (same operations, same rounding as the scalar form), z alone
+#if MNF_PK
+    const f32x2 pxy = __builtin_elementwise_fma(f32x2{m.scale, m.scale}, f32x2{xn[0], xn[1]}, f32x2{0.5f, 0.5f});
+    const float pz = __builtin_fmaf(m.scale, xn[2], 0.5f);
+    const f32x2 fxy = {floorf(pxy.x), floorf(pxy.y)};
+    const float fz = floorf(pz);
+    const f32x2 frxy = pxy - fxy;
+    const float frz = pz - fz;
+    const uint32_t cell[3] = {(uint32_t)(int32_t)fxy.x, (uint32_t)(int32_t)fxy.y, (uint32_t)(int32_t)fz};
+    const f32x2 one_m = f32x2{1.0f, 1.0f} - frxy;          // {1 - fx, 1 - fy}
+#else
+    const float px = __builtin_fmaf(m.scale, xn[0], 0.5f), py = __builtin_fmaf(m.scale, xn[1], 0.5f), pz = __builtin_fmaf(m.scale, xn[2], 0.5f);
+    const f32x2 fxy = {floorf(px), floorf(py)};
+    const float fz = floorf(pz);
+    const f32x2 frxy = {px - fxy.x, py - fxy.y};
+    const float frz = pz - fz;
+    const uint32_t cell[3] = {(uint32_t)(int32_t)fxy.x, (uint32_t)(int32_t)fxy.y, (uint32_t)(int32_t)fz};
+    const f32x2 one_m = {1.0f - frxy.x, 1.0f - frxy.y};
+#endif
+    o.wz[0] = 1.0f - frz; o.wz[1] = frz;
+    const f32x2 wx = {one_m.x, frxy.x};                    // {wx0, wx1}
+    o.wxy[0] = wx * f32x2{one_m.y, one_m.y};
+    o.wxy[1] = wx * f32x2{frxy.y, frxy.y};
     uint32_t ty[2], tz[2];   // per-axis terms, shared by the four corners that use them
     if (m.hashed) {          // uniform branch; size is 2^k when hashed
-        ty[0] = cell[1] * 2654435761u; ty[1] = (cell[1] + 1u) * 2654435761u;
-        tz[0] = cell[2] * 805459861u;  tz[1] = (cell[2] + 1u) * 805459861u;
+        ty[0] = cell[1] * 2654435761u; ty[1] = ty[0] + 2654435761u;
+        tz[0] = cell[2] * 805459861u;  tz[1] = tz[0] + 805459861u;
     } else {
         ty[0] = cell[1] * m.res; ty[1] = ty[0] + m.res;
         const uint32_t r2 = m.res * m.res;
@@ -345,13 +367,24 @@ __device__ __forceinline__ float fma_mix_half(uint32_t packed, float w, float ac
 
 __device__ __forceinline__ void hash_blend(const LevelPrep &p, const tab4 (&v)[8], float *f) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // corner (bx,by,bz) = bit 0, 1, 2 of its index; weight ((wx*wy)*wz); two corners' weights per packed multiply
+    const f32x2 w4[4] = {p.wxy[0] * f32x2{p.wz[0], p.wz[0]}, p.wxy[1] * f32x2{p.wz[0], p.wz[0]},
+                         p.wxy[0] * f32x2{p.wz[1], p.wz[1]}, p.wxy[1] * f32x2{p.wz[1], p.wz[1]}};
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
-        const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
+        const float w = (corner & 1) ? w4[corner >> 1].y : w4[corner >> 1].x;
+#if MNF_MIX_ASM
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 d = __builtin_bit_cast(u32x2, v[corner]);
         a0 = fma_mix_half<0>(d[0], w, a0); a1 = fma_mix_half<1>(d[0], w, a1);
         a2 = fma_mix_half<0>(d[1], w, a2); a3 = fma_mix_half<1>(d[1], w, a3);
+#else
+        // fma(fpext(half), w, acc): selected as v_fma_mix_f32 (one instruction per feature; no SLP pairing in this file).
+        // Left to the compiler rather than inline asm so that its hazard recogniser sees producer and consumer: the asm form
+        // right behind a v_pk_mul_f32 gave wrong values in lanes 48..63 of occasional tiles.
+        a0 = __builtin_fmaf((float)v[corner][0], w, a0); a1 = __builtin_fmaf((float)v[corner][1], w, a1);
+        a2 = __builtin_fmaf((float)v[corner][2], w, a2); a3 = __builtin_fmaf((float)v[corner][3], w, a3);
+#endif
     }
     f[0] = a0; f[1] = a1; f[2] = a2; f[3] = a3;
 }

@@ -36,7 +36,7 @@ struct RenderWs {
     // per column
     int32_t *col_ray;
     float *col_ts, *col_te;
-    int32_t *tile_hdr;   // per 64-column tile: stride | nslots << 8
+    int32_t *tile_hdr;   // per 64-column tile: stride (= the view's budget this round) | view << 8
     void *enc;           // hash features of the round's columns in MLP fragment order (two-launch field path)
     int64_t col_cap;
 };
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
     const int col0 = s_base + tile_local * 64 + slot * stride;
     if (slot == 0) {   // the first ray of a tile also describes the tile and blanks the columns no ray owns
         const int nslots = min(cap, s_total - tile_local * cap);
-        ws.tile_hdr[(s_base >> 6) + tile_local] = stride;
+        ws.tile_hdr[(s_base >> 6) + tile_local] = stride | (v << 8);   // a workgroup marches one view: the tile's view and budget are uniform
         for (int k = nslots * stride; k < 64; ++k) ws.col_ray[s_base + tile_local * 64 + k] = -1;
     }
 

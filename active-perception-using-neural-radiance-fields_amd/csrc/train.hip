@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(256) hash_bwd_simple_kernel(const HashBwdArgs 
     const float4 g = reinterpret_cast<const float4 *>(args.dX)[(int64_t)l * args.Np + i];
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
-        const float w = p.wxy[corner & 3] * p.wz[corner >> 2];
+        const float w = ((corner & 1) ? p.wxy[(corner >> 1) & 1].y : p.wxy[(corner >> 1) & 1].x) * p.wz[corner >> 2];
         float *dst = g_dst + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
         const float v[4] = {w * g.x, w * g.y, w * g.z, w * g.w};
 #pragma unroll
