@@ -33,6 +33,9 @@
                                -4.6 % field-kernel time; 0 = uniform priority, 1 = the opposite assignment (-2.4 %), 3 = static
                                priority for waves 4-7, 4 = start-up stagger (both 0 %), 5 = finest levels first (+4.7 %) */
 #endif
+#ifndef MNF_COL_AHEAD
+#define MNF_COL_AHEAD 0    /* 1: request the next tile's columns before the compositing of the current one (measured: +1.5 % time, 6 spilled registers) */
+#endif
 #ifndef MNF_KNOCK
 #define MNF_KNOCK 0
 #endif
@@ -49,8 +52,9 @@ MNF_DT_BEGIN
 // ------------------------------------------------------------------ sample fetch (shared by the kernels below)
 // Position / direction of column `col`: mode 0 explicit arrays, mode 1 packed samples with int64 ray ids, mode 2 renderer
 // columns.  xn = position normalised to the aabb (ngp.py:177-178), selector = inside the open unit box (ngp.py:179).
-// Renderer columns of one tile (mode 2).  (Loading them one tile ahead was measured: slower, the four extra live
-// registers cost more than the hidden round trip.)
+// Renderer columns of one tile (mode 2).  The tile header (budget | view << 8, written by the marcher of the same round) is
+// wave-uniform and read with a scalar load.  MNF_COL_AHEAD: the columns of the wave's NEXT tile are requested before the
+// compositing epilogue of the current one, so that a tile does not start with a memory round trip and nothing else in flight.
 struct ColData {
     int ray, stride, view;
     float ts, te;
@@ -59,7 +63,8 @@ struct ColData {
 __device__ __forceinline__ ColData load_cols(const KernelArgs &args, int64_t tile, int lane) {
     const int64_t col = tile * kWaveSamples + lane;
     ColData c;
-    const int hdr = __builtin_amdgcn_readfirstlane(args.io.fr.tile_hdr[tile]);
+    typedef const int32_t __attribute__((address_space(4))) *HdrPtr;
+    const int hdr = ((HdrPtr)(uintptr_t)args.io.fr.tile_hdr)[tile];
     c.stride = hdr & 0xff; c.view = hdr >> 8;
     c.ray = args.io.col_ray[col];
     c.ts = args.io.t_starts[col]; c.te = args.io.t_ends[col];
@@ -236,6 +241,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #endif
 
     WaveCounters wc;
+    ColData cd_next = {-1, 64, 0, 0.f, 0.f};
     // MODE 3 (ray-major density pass, `mnf_field_density_rays`): a wave takes whole rays (dynamically, one atomic per ray)
     // and walks a ray's samples front to back in 64-sample steps; once the optical depth accumulated so far makes every
     // later sample invisible (transmittance below early_stop_eps / 2) the rest of the ray is skipped — its densities stay
@@ -261,7 +267,14 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         }
         // ---- this lane's sample ----
         ColData cd = {-1, 64, 0, 0.f, 0.f};
-        if (MODE == 2) cd = load_cols(args, tile, lane);
+        if (MODE == 2) {
+#if MNF_COL_AHEAD
+            if (!DENSITY_ONLY && !SAVE && !ENC) { if (grp == g_first) cd_next = load_cols(args, tile, lane); cd = cd_next; }
+            else cd = load_cols(args, tile, lane);
+#else
+            cd = load_cols(args, tile, lane);
+#endif
+        }
         float xn[3], dir[3];
         TileSample tsm;
         bool valid, selector;
@@ -487,6 +500,12 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             rgb[k] = 1.0f / (1.0f + expf(-(h ? t1 : t0)));   // ngp.py:211-212
         }
         if (MODE == 2) {
+#if MNF_COL_AHEAD
+            if (!DENSITY_ONLY && !SAVE && !ENC) {
+                const int64_t tile_next = tile0 + (grp + g_step) * wpb + wave;
+                if (grp + g_step < g_end && tile_next < n_tiles) cd_next = load_cols(args, tile_next, lane);
+            }
+#endif
 #if MNF_KNOCK & 1
             // diagnostic build: the compositing epilogue is skipped (outputs kept alive by a store that never happens)
             float sink = sigma + rgb[0] + rgb[1] + rgb[2];

@@ -466,6 +466,9 @@ def trajectory_score(terms: torch.Tensor) -> torch.Tensor:
     return (terms[:, 0] + terms[:, 1] + 3 * terms[:, 2] + 2 * terms[:, 3]).mean()
 
 
+LAST_SCORE_TOTALS = []
+
+
 @torch.no_grad()
 def score_views(radiance_fields, estimators, poses, width, height, focal, near_plane, render_step_size, scale, cone_angle,
                 alpha_thre, device="cuda:0", group=None):
@@ -483,14 +486,16 @@ def score_views(radiance_fields, estimators, poses, width, height, focal, near_p
     terms_local = torch.zeros(per, 4, dtype=torch.float64, device=device)
     if hi > lo:
         o, d, h, w = _pose_rays(poses[lo:hi], width, height, focal, scale, device)
-        rv, dv, ac, sm = [], [], [], []
+        rv, dv, ac, sm, totals = [], [], [], [], []
         n = hi - lo
         for rf, est in zip(radiance_fields, estimators):
             r = render_views(rf, est, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
                              render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, probabilistic=True)
+            totals.append(r["total"])
             rv.append(r["rgb_var"].reshape(n, h * w, 3)); dv.append(r["depth_var"].reshape(n, h * w))
             ac.append(r["acc"].reshape(n, h * w)); sm.append(r["sem"].reshape(n, h * w, -1))
         terms_local[:n] = score_view_terms(torch.stack(rv), torch.stack(dv), torch.stack(ac), torch.stack(sm))
+        LAST_SCORE_TOTALS[:] = totals           # per member: device int64 [kept, evaluated] samples of this rank's views (measurement aid)
     terms = terms_local[:V] if group is False else gather_view_terms(terms_local, V, group)
     return terms, trajectory_score(terms)
 

@@ -404,8 +404,8 @@ def main():
 
     # ------------------------------------------------------------------ BASELINE config 4: candidate-view scoring, views sharded over ranks
     if want("score256"):
-        scene250, f0, e0 = scene_model("102344250", seed=9, steps=min(args.standin_steps, 1000))
-        _, f1, e1 = scene_model("102344250", seed=10, steps=min(args.standin_steps, 1000))
+        scene250, f0, e0 = scene_model("102344250", seed=9)
+        _, f1, e1 = scene_model("102344250", seed=10)
         poses256 = SI._free_space_poses(scene250, 256, seed=9)                  # 8 trajectories x 32 views inside the free space
         group = dist.group.WORLD if distributed else None
 
@@ -416,10 +416,13 @@ def main():
         dt_s = timed(sstep, ssteps, 1, False)
         log(f"score256: {1e3 * dt_s / ssteps:.2f} ms/pass")
         terms, score = sstep(0)
+        evaluated = float(sum(int(t[1]) for t in RD.LAST_SCORE_TOTALS))          # this rank's share of the views, all members
         sc = {"ms_per_pass": 1e3 * dt_s / ssteps, "rays_per_s": 256 * 4096 * 2 * ssteps / dt_s, "views": 256, "rays_per_view": 4096,
               "ensemble_members": 2, "n_gpus": world, "scaling": "strong", "score": float(score),
+              "samples_per_ray_rank0": evaluated / max(1, (256 // world) * 4096 * 2),
+              "samples_per_s_rank0": evaluated * ssteps / dt_s,
               "collective": "one all_gather_into_tensor of [V/N,4] float64 per pass" if world > 1 else "none (single rank)",
-              "workload": "BASELINE config 4: scene 102344250 (two trained stand-ins, 1000 iterations each), 256 candidate poses in free "
+              "workload": "BASELINE config 4: scene 102344250 (two trained stand-ins: seeds 9 and 10, the same protocol as the render scene), 256 candidate poses in free "
                           "space, 64x64 rays each (linspace sub-sample of 640x640), probabilistic render + predictive-information terms"}
         if world > 1:
             full, _ = RD.score_views([f0, f1], [e0, e1], poses256, 640, 640, 320.0, 0.1, 1e-3, 0.1, 0.004, 0.01, dev, group=False)
