@@ -309,37 +309,43 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
     const f32x2 wx = {one_m.x, frxy.x};                    // {wx0, wx1}
     o.wxy[0] = wx * f32x2{one_m.y, one_m.y};
     o.wxy[1] = wx * f32x2{frxy.y, frxy.y};
-    uint32_t ty[2], tz[2];   // per-axis terms, shared by the four corners that use them
-    if (m.hashed) {          // uniform branch; size is 2^k when hashed
-        ty[0] = cell[1] * 2654435761u; ty[1] = ty[0] + 2654435761u;
-        tz[0] = cell[2] * 805459861u;  tz[1] = tz[0] + 805459861u;
-    } else {
-        ty[0] = cell[1] * m.res; ty[1] = ty[0] + m.res;
-        const uint32_t r2 = m.res * m.res;
-        tz[0] = cell[2] * r2; tz[1] = tz[0] + r2;
-    }
+    // ONE wave-uniform branch per level (hashed levels: size is 2^k; dense levels wrap the index as tcnn does).  Written as
+    // two corner loops: with the test inside a single loop the compiler kept a scalar branch per corner.
+    const uint32_t base = m.offset;
+    if (m.hashed) {
+        const uint32_t ty0 = cell[1] * 2654435761u, ty1 = ty0 + 2654435761u;   // per-axis terms, shared by the four corners that use them
+        const uint32_t tz0 = cell[2] * 805459861u, tz1 = tz0 + 805459861u;
+        const uint32_t mask = m.size - 1u;
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        const uint32_t px = cell[0] + (uint32_t)(corner & 1);
-        uint32_t idx;
-        if (m.hashed) {
-            idx = (px ^ ty[(corner >> 1) & 1] ^ tz[corner >> 2]) & (m.size - 1u);
+        for (int corner = 0; corner < 8; ++corner) {
+            const uint32_t px = cell[0] + (uint32_t)(corner & 1);
+            const uint32_t idx = (px ^ ((corner >> 1) & 1 ? ty1 : ty0) ^ ((corner >> 2) ? tz1 : tz0)) & mask;
+            o.off[corner] = (base + idx) * 8u;   // 32-bit byte offset from the uniform table base (SGPR base + VGPR offset)
+        }
+    } else {
+        const uint32_t r2 = m.res * m.res;
+        const uint32_t ty0 = cell[1] * m.res, ty1 = ty0 + m.res;
+        const uint32_t tz0 = cell[2] * r2, tz1 = tz0 + r2;
+        // idx %= m.size (only out-of-box positions / the far corner actually wrap).  `all_in_box` is wave-uniform: with every
+        // position inside the unit box the corner coordinates are <= res, so idx < 2*size and one conditional subtraction is
+        // the modulo (unsigned min of idx and idx - size).  Otherwise: exact for every uint32 and branch-free (multiply-high by
+        // a precomputed reciprocal) -- the compiler's generic modulo put a rarely taken division loop behind every corner.
+        if (all_in_box) {
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const uint32_t idx = cell[0] + (uint32_t)(corner & 1) + ((corner >> 1) & 1 ? ty1 : ty0) + ((corner >> 2) ? tz1 : tz0);
+                o.off[corner] = (base + min(idx, idx - m.size)) * 8u;
+            }
         } else {
-            idx = px + ty[(corner >> 1) & 1] + tz[corner >> 2];
-            // idx %= m.size (only out-of-box positions / the far corner actually wrap).  `all_in_box` is wave-uniform:
-            // with every position inside the unit box the corner coordinates are <= res, so idx < 2*size and one
-            // conditional subtraction is the modulo (unsigned min of idx and idx - size).  Otherwise: exact for every
-            // uint32 and branch-free -- the compiler's generic modulo put a rarely taken division loop, and a reload
-            // of the spilled level metadata, behind every corner of every dense level.
-            if (all_in_box) {
-                idx = min(idx, idx - m.size);
-            } else {
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                uint32_t idx = cell[0] + (uint32_t)(corner & 1) + ((corner >> 1) & 1 ? ty1 : ty0) + ((corner >> 2) ? tz1 : tz0);
                 uint32_t q = __umulhi(m.div_magic, idx);
                 q = (((idx - q) >> 1) + q) >> m.div_shift;
                 idx -= q * m.size;
+                o.off[corner] = (base + idx) * 8u;
             }
         }
-        o.off[corner] = (m.offset + idx) * 8u;   // 32-bit byte offset from the uniform table base (SGPR base + VGPR offset)
     }
 }
 
