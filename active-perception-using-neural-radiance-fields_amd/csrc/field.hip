@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int k = 0; k < L::KSW; ++k) {
                 save_pair<true>(args.train, tile, T::rH0 + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) mdump[((T::mH0 + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
+                for (int ct = 0; ct < CT; ++ct) if (MNF_EXP_SAVE != 3) mdump[((T::mH0 + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
             }
         }
 #pragma unroll
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 for (int k = 0; k < L::KSW; ++k) {
                     save_pair<true>(args.train, tile, T::rH0 + (l + 1) * W + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
+                    for (int ct = 0; ct < CT; ++ct) if (MNF_EXP_SAVE != 3) mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
                 }
             }
         }
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int k = 0; k < L::KSh; ++k) {
                 save_pair<true>(args.train, tile, row0 + 16 * k, lane, stage, a[0][k], a[1][k]);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) mdump[((mblk + k) * CT + ct) * 64] = frag_mask(a[ct][k]);
+                for (int ct = 0; ct < CT; ++ct) if (MNF_EXP_SAVE != 3) mdump[((mblk + k) * CT + ct) * 64] = frag_mask(a[ct][k]);
             }
         };
         // rgb head (ngp.py:143-156, :202-213)

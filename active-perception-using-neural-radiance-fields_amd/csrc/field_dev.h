@@ -152,6 +152,9 @@ __device__ __forceinline__ void save_pair(const TrainBuf &tb, int64_t tile, int 
             }
         }
         __builtin_amdgcn_wave_barrier();
+#if MNF_EXP_SAVE == 2
+        if (src[lane][0] == 0x12345678u)      /* timing experiment: transposes and LDS traffic kept, (almost) no global store */
+#endif
         *reinterpret_cast<u32x4 *>(gbase + (q * 64 + lane) * 16) = src[lane];
         __builtin_amdgcn_wave_barrier();
     }

@@ -62,6 +62,7 @@ def parse():
                     help="random = round 1's random-init weights with an engineered density gain (continuity only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the second, hipEvent-instrumented pass")
+    ap.add_argument("--no-views1", action="store_true", help="skip the one-view-per-call pass (profiling runs: every field-kernel launch then belongs to the headline workload)")
     return ap.parse_args()
 
 
@@ -324,7 +325,7 @@ def main():
                                     "field_kernel_share_of_step": field_ms * 1e-3 / dt,
                                     "timing": "second pass of the same K steps, hipEvent pair around each launch on the launch stream; "
                                               "traffic from the committed rocprofv3 --pmc passes (profiles/r02_pmc.json), scaled to this run"}
-        if V != 1:
+        if V != 1 and not args.no_views1:
             dt1, s1 = render_pass(1, args.steps, 2, False)
             line["render_views1"] = {"value": n_per_view * world * args.steps / dt1, "unit": "rays/s", "ms_per_view": 1e3 * dt1 / args.steps,
                                      "samples_per_ray": s1 / (n_per_view * args.steps)}

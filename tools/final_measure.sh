@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 out=gpurun_out/final; rm -rf $out; mkdir -p $out
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > $out/pytest_gpu.txt
 timeout 600 python bench.py 2> $out/bench.err | tail -1 > $out/bench_line.json
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --workload render800 --no-cpu-baseline --no-kernel-timing > $out/bench_under_rocprof.json 2> $out/rocprof.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --workload render800 --no-cpu-baseline --no-kernel-timing --no-views1 > $out/bench_under_rocprof.json 2> $out/rocprof.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_train -- python3 bench.py --workload train --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/bench_train_under_rocprof.json 2> $out/rocprof_train.err
 timeout 300 bash tools/pmc.sh fin_fetch FETCH_SIZE > $out/pmc_fetch.txt 2>&1
 timeout 300 bash tools/pmc.sh fin_write WRITE_SIZE > $out/pmc_write.txt 2>&1
