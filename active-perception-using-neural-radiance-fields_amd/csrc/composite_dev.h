@@ -283,7 +283,7 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
             v_prev[3] = fr.depth_var[sm.ray];
         }
     }
-    const bool fast = maxlen == 4 || maxlen == 8 || maxlen == 16;      // wave-uniform: aligned power-of-two slots
+    const bool fast = (maxlen == 4 || maxlen == 8 || maxlen == 16) && !fr.general_only;   // wave-uniform: aligned power-of-two slots
     if (fast) {
         fused_composite_slots(fr, C, lane, sm, sigma, rgb, sem, wc, owner, view, budget, c_prev, d_prev, v_prev);
         return;

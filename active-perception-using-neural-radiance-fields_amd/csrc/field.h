@@ -52,6 +52,7 @@ struct FusedRender {
     float *rgb, *acc, *depth, *sem, *rgb_var, *depth_var;   // running accumulators (the call's outputs)
     unsigned long long *totals;   // [2]: kept samples, evaluated samples
     int32_t rays_per_view, probabilistic;
+    int32_t general_only;         // diagnostic (MNF_COMPOSITE_GENERAL=1): composite every tile with the general segmented-scan path
     float alpha_thre, opc_thre;
 };
 

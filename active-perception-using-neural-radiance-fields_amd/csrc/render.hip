@@ -460,6 +460,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     io.fr.rgb_var = out.rgb_var; io.fr.depth_var = out.depth_var;
     io.fr.totals = reinterpret_cast<unsigned long long *>(total_samples);
     io.fr.rays_per_view = opts->rays_per_view; io.fr.probabilistic = opts->probabilistic;
+    io.fr.general_only = getenv("MNF_COMPOSITE_GENERAL") != nullptr;   // tests compare the two compositing paths with it
     io.fr.alpha_thre = opts->alpha_thre; io.fr.opc_thre = opc_thre;
 
     const int max_rounds = (int)ceil_div(opts->max_samples, min_samples);

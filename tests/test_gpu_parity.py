@@ -1218,6 +1218,34 @@ def test_render_views_sharded_single_rank_and_row_tiles(scene, fields):
     np.testing.assert_allclose(tile["rgb"].cpu().numpy(), b["rgb"][128:192].cpu().numpy(), atol=2e-3)   # schedule differs, values agree
 
 
+@pytest.mark.parametrize("min_samples,prob", [(4, False), (4, True), (8, True), (16, False)])
+def test_slot_compositing_equals_general_path(scene, fields, monkeypatch, min_samples, prob):
+    """The render epilogue composites tiles whose ray slots are aligned runs of 4 / 8 / 16 columns with DPP butterflies and a quad
+    reduce-scatter (csrc/composite_dev.h), every other tile with segmented scans.  Same arithmetic per sample, different summation
+    order: outputs agree to fp32 rounding.  MNF_MIN_SAMPLES (a diagnostic schedule, not the reference's) makes slots of 8 and 16
+    occur in every early round; MNF_COMPOSITE_GENERAL=1 sends every tile down the general path."""
+    from apnrf_amd import render as RD
+    hip, _ = fields
+    est = H.hip_estimator(scene)
+    o, d = H.view_rays(scene, 2, h=48, w=48)
+    o, d = torch.cat([o, o[:150]]).to(DEV), torch.cat([d, d[:150]]).to(DEV)      # ragged: the last march workgroup is partly idle
+    n = o.shape[0]
+    bk = torch.zeros(3)
+    monkeypatch.setenv("MNF_MIN_SAMPLES", str(min_samples))
+    fast = RD.render_views(hip, est, o, d, n, 1024, render_bkgd=bk, probabilistic=prob, **H.RENDER_KW)
+    monkeypatch.setenv("MNF_COMPOSITE_GENERAL", "1")
+    gen = RD.render_views(hip, est, o, d, n, 1024, render_bkgd=bk, probabilistic=prob, **H.RENDER_KW)
+    monkeypatch.delenv("MNF_COMPOSITE_GENERAL"); monkeypatch.delenv("MNF_MIN_SAMPLES")
+    tf, tg = fast["total"].cpu().numpy(), gen["total"].cpu().numpy()
+    assert tf[1] > 20 * n                                                         # the schedule really ran
+    assert abs(int(tf[0]) - int(tg[0])) <= 1e-3 * tg[0] and abs(int(tf[1]) - int(tg[1])) <= 1e-3 * tg[1]   # threshold ties only
+    keys = ("rgb", "acc", "depth", "sem") + (("rgb_var", "depth_var") if prob else ())
+    for k in keys:
+        a, b = fast[k].cpu().numpy().reshape(n, -1), gen[k].cpu().numpy().reshape(n, -1)
+        close = np.all(np.abs(a - b) <= 2e-5 + 2e-5 * np.abs(b), axis=1)
+        assert close.mean() > 0.999, (k, float(close.mean()), float(np.abs(a - b).max()))   # a ray retired one round apart moves visibly
+
+
 def test_checkpoint_fixture_hand_computed_density():
     """f2: a checkpoint in the reference's key layout written by tests/golden/make_checkpoint_fixture.py (which imports neither
     the product nor the oracle) loads through `dataset.load_checkpoint`, and the density it yields is the HAND-COMPUTED one
