@@ -52,9 +52,9 @@ static bool split_field() {
 // role specialisation can take on gfx950, where all waves of ONE kernel share a register allocation.
 struct PipeCfg { int chunks = 0, rounds = 24, mlp_waves = 4, gather_grid = 768; };
 static hipEvent_t *log_events() {
-    static hipEvent_t ev[2];
+    static hipEvent_t ev[4];
     static bool made = false;
-    if (!made) { (void)hipEventCreate(&ev[0]); (void)hipEventCreate(&ev[1]); made = true; }
+    if (!made) { for (auto &e : ev) (void)hipEventCreate(&e); made = true; }
     return ev;
 }
 static bool round_log() { static const bool on = getenv("MNF_ROUND_LOG") != nullptr; return on; }
@@ -228,6 +228,19 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
     const bool in_range = in_view < rays_per_view;
     int64_t r = (int64_t)v * rays_per_view + (in_range ? (view_order ? view_order[in_view] : in_view) : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // The occupancy bits are requested first, 16 bytes per lane, so that they travel while the prologue (alive flags, scan,
+    // column reservation) runs; they go to LDS once the workgroup knows that it marches.  (Staged after the prologue in a
+    // one-word-per-lane loop, every iteration waited for its own load: ~10 serial round trips per workgroup, and with 2-3
+    // workgroups per CU a round's march cost 65 us however few rays were alive.)
+    constexpr int kStageVec = kMaxGridWords / 4 / kMarchThreads;
+    uint4 pre[kStageVec];
+    if (LDS_GRID) {
+#pragma unroll
+        for (int j = 0; j < kStageVec; ++j) {
+            const int q = (int)threadIdx.x + j * kMarchThreads;
+            if (4 * q + 3 < n_words) pre[j] = reinterpret_cast<const uint4 *>(ws.bitgrid)[q];
+        }
+    }
     bool go = false;
     int ns = 0;
     if (in_range) {
@@ -264,7 +277,12 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
     __syncthreads();
     if (s_base < 0) return;   // uniform: no ray of this workgroup marches this round (or the workspace guard fired)
     if (LDS_GRID) {
-        for (int i = threadIdx.x; i < n_words; i += kMarchThreads) s_bits[i] = ws.bitgrid[i];
+#pragma unroll
+        for (int j = 0; j < kStageVec; ++j) {
+            const int q = (int)threadIdx.x + j * kMarchThreads;
+            if (4 * q + 3 < n_words) reinterpret_cast<uint4 *>(s_bits)[q] = pre[j];
+        }
+        for (int i = (n_words & ~3) + (int)threadIdx.x; i < n_words; i += kMarchThreads) s_bits[i] = ws.bitgrid[i];
         __syncthreads();
     }
     if (!go) return;
@@ -479,6 +497,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
             }
             if (!flags[0]) break;
         }
+        if (round_log()) MNF_HIP(hipEventRecord(log_events()[2], s));
         if (lds_grid)
             hipLaunchKernelGGL(round_march_kernel<true>, dim3(march_grid), dim3(kMarchThreads), 0, s, n_rays,
                                opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
@@ -487,6 +506,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
             hipLaunchKernelGGL(round_march_kernel<false>, dim3(march_grid), dim3(kMarchThreads), 0, s, n_rays,
                                opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
                                opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order, bpv);
+        if (round_log()) MNF_HIP(hipEventRecord(log_events()[3], s));
         const PipeCfg &pc = pipe_cfg();
         if (pc.chunks > 1 && round < pc.rounds) {
             ProfScope ps("field_render", s);
@@ -525,7 +545,9 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
             MNF_HIP(hipStreamSynchronize(s));
             float ms = 0.f;
             if (!(pc.chunks > 1 && round < pc.rounds)) (void)hipEventElapsedTime(&ms, log_events()[0], log_events()[1]);
-            fprintf(stderr, "[mnf round %d] cols %d  field %.4f ms (%.3f ns/col)  budgets", round, n_cols, ms, n_cols ? ms * 1e6 / n_cols : 0.0);
+            float ms_march = 0.f;
+            (void)hipEventElapsedTime(&ms_march, log_events()[2], log_events()[3]);
+            fprintf(stderr, "[mnf round %d] cols %d  field %.4f ms (%.3f ns/col)  march %.4f ms  budgets", round, n_cols, ms, n_cols ? ms * 1e6 / n_cols : 0.0, ms_march);
             for (int v = 0; v < n_views && v < 8; ++v) fprintf(stderr, " %d", act[v] ? ns[v] : 0);
             fprintf(stderr, "\n");
         }
