@@ -231,7 +231,21 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     if (MODE != 3) group_range(n_groups, g_first, g_end, g_step);
     if (g_first >= g_end) return;   // uniform per block: nothing to do
 
-    for (int i = threadIdx.x; i < kBlocks * 64; i += kThreads) s_w[i] = args.frags[i];
+    {   // weight fragments -> LDS: every load of a lane is issued before the first LDS write (a plain copy loop waited for each
+        // 16-byte load in turn: ~11 serial L2 round trips per launch, which matters in the late render rounds of few tiles)
+        constexpr int kPer = (kBlocks * 64 + kThreads - 1) / kThreads;
+        half8 tmp[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = threadIdx.x + j * kThreads;
+            if (i < kBlocks * 64) tmp[j] = args.frags[i];
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = threadIdx.x + j * kThreads;
+            if (i < kBlocks * 64) s_w[i] = tmp[j];
+        }
+    }
     __syncthreads();
     if (wave >= wpb) return;
 #if MNF_EXP == 3
