@@ -33,6 +33,9 @@
                                -4.6 % field-kernel time; 0 = uniform priority, 1 = the opposite assignment (-2.4 %), 3 = static
                                priority for waves 4-7, 4 = start-up stagger (both 0 %), 5 = finest levels first (+4.7 %) */
 #endif
+#ifndef MNF_EXP_LOCK
+#define MNF_EXP_LOCK 0      /* experiment: a per-SIMD lock around the matrix phase (anti-phase schedule of the two waves of a SIMD) */
+#endif
 #ifndef MNF_COL_AHEAD
 #define MNF_COL_AHEAD 0    /* 1: request the next tile's columns before the compositing of the current one (measured: +1.5 % time, 6 spilled registers) */
 #endif
@@ -213,6 +216,10 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
     __shared__ half8 s_w[kBlocks * 64];
     __shared__ half_t s_stage[SAVE ? kWavesPerBlock * kStageHalves : 1];   // training: per-wave transpose tile of the activation dump
+#if MNF_EXP_LOCK
+    __shared__ int s_lock[4];          // experiment: at most one of the two waves of a SIMD (waves w, w + 4) inside the matrix phase
+    if (threadIdx.x < 4) s_lock[threadIdx.x] = 0;
+#endif
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -384,6 +391,16 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int ks = 0; ks < 4; ++ks) save_pair<false>(args.train, tile, T::rX + 16 * ks, lane, stage, bfeat[0][ks], bfeat[1][ks]);
         }
 
+#if MNF_EXP_LOCK
+        if (MODE == 2 && !SAVE && !DENSITY_ONLY) {
+            int got = 0;
+            do {
+                if (lane == 0) got = atomicCAS(&s_lock[wave & 3], 0, 1) == 0;
+                got = __builtin_amdgcn_readfirstlane(got);
+                if (!got) __builtin_amdgcn_s_sleep(4);
+            } while (!got);
+        }
+#endif
         // ---- base MLP ----
         half8 hb[CT][L::KSW];
         dense_relu<L::RT, 4>(s_w + L::o_b_in * 64, lane, bfeat, hb);
@@ -504,6 +521,11 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         dense_out<L::KSh>(s_w + L::o_s_out * 64, lane, h2, out_sem);
         if (args.out_fp16) round_outputs_fp16(out_sem);
 
+#if MNF_EXP_LOCK
+        if (MODE == 2 && !SAVE && !DENSITY_ONLY) {
+            if (lane == 0) s_lock[wave & 3] = 0;
+        }
+#endif
         // ---- write out ----
         // rgb rows 0..2 of this lane's own sample: lane (lane&31), registers 0..2 of tile h
         float rgb[3];
