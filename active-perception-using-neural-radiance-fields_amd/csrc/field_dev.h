@@ -283,7 +283,8 @@ __device__ __forceinline__ LevelMeta level_meta(LevelsPtr lv, int l) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // arithmetic on it is v_pk_{mul,add,fma}_f32: two fp32 results per issue slot
 
 struct LevelPrep {
-    uint32_t off[8];
+    uint32_t base;   // first entry of the level (wave-uniform): folded into the scalar base address of the gathers, not into every offset
+    uint32_t off[8]; // byte offset of each corner's entry inside the level
     f32x2 wxy[2];    // {wx0*wy0, wx1*wy0}, {wx0*wy1, wx1*wy1}
     float wz[2];
 };
@@ -314,7 +315,7 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
     o.wxy[1] = wx * f32x2{frxy.y, frxy.y};
     // ONE wave-uniform branch per level (hashed levels: size is 2^k; dense levels wrap the index as tcnn does).  Written as
     // two corner loops: with the test inside a single loop the compiler kept a scalar branch per corner.
-    const uint32_t base = m.offset;
+    o.base = m.offset;
     if (m.hashed) {
         const uint32_t ty0 = cell[1] * 2654435761u, ty1 = ty0 + 2654435761u;   // per-axis terms, shared by the four corners that use them
         const uint32_t tz0 = cell[2] * 805459861u, tz1 = tz0 + 805459861u;
@@ -323,7 +324,7 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
         for (int corner = 0; corner < 8; ++corner) {
             const uint32_t px = cell[0] + (uint32_t)(corner & 1);
             const uint32_t idx = (px ^ ((corner >> 1) & 1 ? ty1 : ty0) ^ ((corner >> 2) ? tz1 : tz0)) & mask;
-            o.off[corner] = (base + idx) * 8u;   // 32-bit byte offset from the uniform table base (SGPR base + VGPR offset)
+            o.off[corner] = idx * 8u;   // 32-bit byte offset from the level's first entry (SGPR base + VGPR offset)
         }
     } else {
         const uint32_t r2 = m.res * m.res;
@@ -337,7 +338,7 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
                 const uint32_t idx = cell[0] + (uint32_t)(corner & 1) + ((corner >> 1) & 1 ? ty1 : ty0) + ((corner >> 2) ? tz1 : tz0);
-                o.off[corner] = (base + min(idx, idx - m.size)) * 8u;
+                o.off[corner] = min(idx, idx - m.size) * 8u;
             }
         } else {
 #pragma unroll
@@ -346,22 +347,23 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
                 uint32_t q = __umulhi(m.div_magic, idx);
                 q = (((idx - q) >> 1) + q) >> m.div_shift;
                 idx -= q * m.size;
-                o.off[corner] = (base + idx) * 8u;
+                o.off[corner] = idx * 8u;
             }
         }
     }
 }
 
 __device__ __forceinline__ void hash_load(const tab4 *__restrict__ table, const LevelPrep &p, tab4 (&v)[8], bool stream = false) {
+    const char *level = reinterpret_cast<const char *>(table + p.base);      // uniform: scalar address arithmetic
     if (stream) {   // wave-uniform: a level whose lines are not worth keeping in L2 (experiment: MNF_NT_FROM)
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner)
-            v[corner] = __builtin_nontemporal_load(reinterpret_cast<const tab4 *>(reinterpret_cast<const char *>(table) + p.off[corner]));
+            v[corner] = __builtin_nontemporal_load(reinterpret_cast<const tab4 *>(level + p.off[corner]));
         return;
     }
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner)
-        v[corner] = *reinterpret_cast<const tab4 *>(reinterpret_cast<const char *>(table) + p.off[corner]);
+        v[corner] = *reinterpret_cast<const tab4 *>(level + p.off[corner]);
 }
 
 // acc = fma((float)half, w, acc) in ONE instruction: v_fma_mix_f32 reads the fp16 operand straight from one half of a

@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(256) hash_bwd_simple_kernel(const HashBwdArgs 
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
         const float w = ((corner & 1) ? p.wxy[(corner >> 1) & 1].y : p.wxy[(corner >> 1) & 1].x) * p.wz[corner >> 2];
-        float *dst = g_dst + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index of the entry
+        float *dst = g_dst + (size_t)p.base * 4 + (p.off[corner] >> 1);   // byte offset of the fp16 entry / 2 == float index inside the level
         const float v[4] = {w * g.x, w * g.y, w * g.z, w * g.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
