@@ -247,6 +247,15 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
         go = ws.alive[r] && ws.active[v];
         ns = go ? ws.n_samples[v] : 0;
     }
+    // This ray's record, requested before the column reservation below (two barriers and an atomic round trip): it is there
+    // by the time the ray marches.
+    float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 1.f}, ray_near = 0.f, ray_tmin = 0.f, ray_tmax = 0.f;
+    bool ray_hit = false;
+    if (go) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { ro[d] = rays_o[3 * r + d]; rd[d] = rays_d[3 * r + d]; }
+        ray_near = ws.near_plane[r]; ray_hit = ws.hit[r]; ray_tmin = ws.t_min[r]; ray_tmax = ws.t_max[r];
+    }
     // Column allocation.  All marching rays of the workgroup get `stride` = the largest per-ray budget in the
     // workgroup (budgets are per view, so almost always uniform); a 64-column tile holds cap = 64/stride rays, so no
     // ray straddles a tile and the field kernel can composite a ray inside one wave.  Ray with rank k among the
@@ -298,15 +307,15 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
     }
 
     const float ab[6] = {a0, a1, a2, a3, a4, a5};
-    const F3 org = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
-    const F3 dir = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const F3 org = {ro[0], ro[1], ro[2]};
+    const F3 dir = {rd[0], rd[1], rd[2]};
     const F3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
-    const float near_plane = ws.near_plane[r];
+    const float near_plane = ray_near;
     MarchState st = {near_plane, false, 0};
     RoundSink sink = {ws.col_ts, ws.col_te, col0};
-    if (ws.hit[r]) {   // single grid level: the only interval is [t_min, t_max] (grid.cu:125-151 with n_grids == 1)
-        const float this_tmin = fmaxf(ws.t_min[r], near_plane);
-        const float this_tmax = fminf(ws.t_max[r], far_plane);
+    if (ray_hit) {   // single grid level: the only interval is [t_min, t_max] (grid.cu:125-151 with n_grids == 1)
+        const float this_tmin = fmaxf(ray_tmin, near_plane);
+        const float this_tmax = fminf(ray_tmax, far_plane);
         if (this_tmin < this_tmax) {
             if (LDS_GRID) march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, BitGrid{s_bits}, step_size, cone_angle, ns, st, sink);
             else march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, ByteGrid{binaries}, step_size, cone_angle, ns, st, sink);
