@@ -15,6 +15,7 @@ What one invocation measures (ONE JSON line, rank 0):
                         With N GPUs every rank renders its own views (independent units, no data-path collective: weak
                         scaling); value = whole-job rays/s.
   render_views1         the same at one view per call (the reference's own call granularity)
+  render_random_weights the same views with round 1's engineered random-init weights: identical work on every box and in every round
   roofline              dominant kernel (fused hash-gather + MLP + compositing): algorithmic bytes / hipEvent time
   train                 BASELINE config 5: train step on scene 102344280, 8192 rays (sampling + density pre-pass + forward +
                         loss + backward + fused Adam), ms per step, per-kernel times and its own roofline
@@ -329,6 +330,18 @@ def main():
             dt1, s1 = render_pass(1, args.steps, 2, False)
             line["render_views1"] = {"value": n_per_view * world * args.steps / dt1, "unit": "rays/s", "ms_per_view": 1e3 * dt1 / args.steps,
                                      "samples_per_ray": s1 / (n_per_view * args.steps)}
+        if args.weights == "trained" and not args.no_views1:
+            # the same views with round 1's engineered random-init weights: a workload that is the same on every box and in every
+            # round (the trained stand-in is not: training is non-deterministic), reported beside the headline value, never as it
+            field_t, est_t = field, est
+            field, est = H.hip_field(scene529, dev), H.hip_estimator(scene529, dev)
+            dtr, sr = render_pass(V, args.steps, 2, False)
+            field, est = field_t, est_t
+            line["render_random_weights"] = {"value": n_per_view * V * world * args.steps / dtr, "unit": "rays/s",
+                                             "ms_per_step": 1e3 * dtr / args.steps, "views_per_step": V,
+                                             "samples_per_ray": sr / (n_per_view * V * args.steps), "samples_per_s": sr * world / dtr,
+                                             "note": "deterministic workload (synthetic.make_field_params seed 0, procedural occupancy grid): "
+                                                     "round 1's headline configuration, for comparisons across boxes and rounds"}
         line["samples"] = {"timed": int(samples), "process_total": int(process_samples.item())}
         del rays
 

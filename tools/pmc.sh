@@ -2,7 +2,7 @@
 # usage: tools/pmc.sh <tag> <counters...>   (one rocprofv3 --pmc pass of a short bench; kernel-trace only)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --workload render800 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > gpurun_out/pmc_$tag.json 2> gpurun_out/pmc_$tag.err
+rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --workload render800 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-views1 > gpurun_out/pmc_$tag.json 2> gpurun_out/pmc_$tag.err
 f=$(find gpurun_out/pmc_$tag -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections

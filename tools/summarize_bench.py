@@ -6,6 +6,7 @@ print("value %.2f M rays/s  %.2f ms/step  spr %.1f  %.3f G samples/s" % (d["valu
 r = d.get("roofline")
 if r: print("roofline frac %.4f  avg launch %.4f ms  samples/launch %.3f M  launches %d  share %.3f  traffic/launch %.3f GB  achieved %.0f GB/s" % (r["frac"], r["avg_launch_ms"], r["samples_per_launch"] / 1e6, r["launches"], r["field_kernel_share_of_step"], (r["traffic"] or 0) / 1e9, r["achieved"]))
 if "render_views1" in d: v = d["render_views1"]; print("views1 %.2f M rays/s  %.2f ms/view  spr %.1f" % (v["value"] / 1e6, v["ms_per_view"], v["samples_per_ray"]))
+if "render_random_weights" in d: v = d["render_random_weights"]; print("random weights %.2f M rays/s  %.2f ms/step  spr %.2f  %.3f G samples/s" % (v["value"] / 1e6, v["ms_per_step"], v["samples_per_ray"], v["samples_per_s"] / 1e9))
 if "train" in d:
     t = d["train"]; print("train %.3f ms/step  kept %.3f M  marched %.3f M  roofline %.3f" % (t["ms_per_step"], t["rendering_samples_per_step"] / 1e6, t["marched_samples_per_step"] / 1e6, t["roofline"]["frac"]))
     print("   " + "  ".join("%s %.3f" % (k, v["ms_per_step"]) + (" (%.2f)" % v["frac_of_hbm_peak"] if v.get("frac_of_hbm_peak") else "") for k, v in t["kernels"].items()))
