@@ -78,13 +78,15 @@ def _free_space_poses(scene, n, seed):
 
 
 def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 21, lr=2e-3, seed=9, cache_dir="/tmp",
-                  n_poses=64, verbose=False):
+                  n_poses=64, verbose=False, lr_final=2e-4):
     """-> (NGPRadianceField, OccGridEstimator, info dict), trained as described in the module docstring with
-    `render.train_step` + `optim.FusedAdam`.  `scene` is `tests/helpers.make_scene`-shaped (aabb, res, occ, neurons, layers, C,
+    `render.train_step` + `optim.FusedAdam`; the learning rate stays at `lr` for the first half and decays geometrically to
+    `lr_final` over the second (training is not deterministic -- float atomics -- and with a constant rate four runs of one box
+    differed by 23 % in samples per ray of the resulting scene; with the decay by 9 %: tools/exp_standin_variance.py).  `scene` is `tests/helpers.make_scene`-shaped (aabb, res, occ, neurons, layers, C,
     log2_hashmap_size)."""
     from .ngp import NGPRadianceField
     from .optim import FusedAdam
-    tag = f"{tuple(np.round(scene['aabb'], 3))}_{scene['neurons']}x{scene['layers']}_C{scene['C']}_T{scene['log2_hashmap_size']}_s{steps}_r{max_rays}_seed{seed}"
+    tag = f"{tuple(np.round(scene['aabb'], 3))}_{scene['neurons']}x{scene['layers']}_C{scene['C']}_T{scene['log2_hashmap_size']}_s{steps}_r{max_rays}_seed{seed}" + ("" if lr_final is None else f"_lrf{lr_final}")
     import hashlib
     path = os.path.join(cache_dir, "mnf_standin_" + hashlib.md5(tag.encode()).hexdigest()[:16] + ".pt")
     field = NGPRadianceField(aabb=torch.from_numpy(scene["aabb"]), neurons=scene["neurons"], layers=scene["layers"],
@@ -109,6 +111,9 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
     n_rays, t0, losses, skipped, n_samp = 1024, time.perf_counter(), [], 0, 0
     bk = torch.zeros(3, device=device)
     for step in range(steps):
+        if lr_final is not None and step >= steps // 2:           # geometric decay over the second half
+            for g in opt.param_groups:
+                g["lr"] = lr * (lr_final / lr) ** ((step - steps // 2) / max(1, steps - steps // 2 - 1))
         idx = torch.randint(0, 640 * 640, (n_rays,), generator=gen).numpy()
         ys, xs = idx // 640, idx % 640
         idx = idx[np.argsort((ys // 32) * 20 + xs // 32, kind="stable")]      # grouped by 32x32 image block (dataset.fetch_data)

@@ -263,7 +263,7 @@ def main():
                        "arithmetic": "fp16 hash entries / weights / activations, fp32 accumulate and outputs",
                        "weights": ("trained stand-in (SURVEY 8d): apnrf_amd.standin.train_standin, the product's train_step on an "
                                    "analytic target (opaque procedural rooms, colour fract(xyz), class = cell hash mod 29), "
-                                   f"{args.standin_steps} iterations, FusedAdam lr 2e-3; occupancy grid from update_every_n_steps")
+                                   f"{args.standin_steps} iterations, FusedAdam lr 2e-3 decayed to 2e-4 over the second half; occupancy grid from update_every_n_steps")
                        if args.weights == "trained" else "random-init (hash U(-0.5,0.5), xavier MLPs, |density row| x 8), procedural occupancy"}}
 
     # ------------------------------------------------------------------ BASELINE config 3: 800x800 renders (the headline value)
