@@ -10,7 +10,7 @@ scene = H.make_scene("102344529", n_poses=40)
 c2w = np.stack([RD.pose_to_c2w(p) for p in scene["poses"][[0, 5]]]).astype(np.float32)
 K = np.array([[400.0, 0, 400], [0, 400.0, 400], [0, 0, 1.0]])
 rays = RD.generate_image_rays(torch.from_numpy(c2w), 800, 800, K, dev)
-for name, kw in (("lr 2e-3 constant", {}), ("lr 2e-3 -> 2e-4 over the second half", {"lr_final": 2e-4}), ("lr 2e-3 -> 5e-5", {"lr_final": 5e-5})):
+for name, kw in (("lr 2e-3 constant", {"lr_final": None}), ("lr 2e-3 -> 2e-4 over the second half", {"lr_final": 2e-4}), ("lr 2e-3 -> 5e-5", {"lr_final": 5e-5})):
     out = []
     for r in range(reps):
         field, est, info = SI.train_standin(scene, dev, cache_dir=tempfile.mkdtemp(), **kw)
