@@ -25,7 +25,7 @@ class FieldConfig(ctypes.Structure):
 class TrainOpts(ctypes.Structure):
     _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float), ("cone_angle", c_float),
                 ("alpha_thre", c_float), ("early_stop_eps", c_float), ("render_bkgd", c_float * 3), ("loss_scale", c_float),
-                ("stratified", c_int32), ("seed", c_uint64)]
+                ("stratified", c_int32), ("seed", c_uint64), ("render_bkgd_dev", c_void_p)]
 
 
 class VanillaConfig(ctypes.Structure):
@@ -66,6 +66,8 @@ SIGNATURES = {
                                                c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int32, c_void_p]),
+    "mnf_adam_step_guarded": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_count_nan": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_scan_workspace_bytes": (c_int64, [c_int64]),
     "mnf_pack_info": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -89,6 +91,8 @@ SIGNATURES = {
     "mnf_field_param_count": (c_int64, [c_void_p, c_int32]),
     "mnf_field_grid_meta_host": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_field_set_params": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_field_refresh_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_field_table_mirror": (c_void_p, [c_void_p, POINTER(c_int64)]),
     "mnf_field_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_field_density": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_field_forward_samples": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
@@ -112,7 +116,7 @@ SIGNATURES = {
                                                   c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_train_step_workspace_bytes": (c_int64, [c_void_p, c_int32, c_int64, c_int64]),
     "mnf_train_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
-                                 c_void_p, c_void_p, c_void_p, POINTER(TrainOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                 c_void_p, c_void_p, c_void_p, POINTER(TrainOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                  c_int64, c_void_p, c_int64, c_void_p]),
     "mnf_score_poses_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "mnf_score_poses": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,

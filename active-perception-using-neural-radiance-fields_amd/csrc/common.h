@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "mi355nerf.h"
 
@@ -52,6 +53,14 @@ inline int launch_status(const char *what) {
 inline hipStream_t as_stream(mnf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Diagnostic knobs (tools/README.md) exist only in the -DMNF_DIAG build (libmi355nerf_diag.so): the product library never
+// reads the environment, so no stray variable can change its results, its round schedule or its timings.
+#ifdef MNF_DIAG
+inline const char *diag_env(const char *name) { return getenv(name); }
+#else
+inline const char *diag_env(const char *) { return nullptr; }
+#endif
 
 // per-kernel timing for bench.py (api.cpp): a no-op unless mnf_profile_begin() was called on this thread
 bool prof_on();

@@ -68,6 +68,8 @@ struct FieldIO {
     int64_t n;                               // modes 0, 1
     const int32_t *n_dev;                    // mode 2: number of columns (device)
     int64_t n_cap;                           // mode 2: capacity of the column arrays (the device count is clamped to it)
+    const int64_t *n_dev64;                  // modes 0, 1, optional: the sample count lives on the device (`n` is then its upper
+                                             // bound and sizes the launch): the train step never brings a count to the host
     // mode 3: packed samples walked ray by ray (ray_idx64 / t_starts / t_ends as mode 1) with early termination
     const int64_t *chunk_starts, *chunk_cnts;
     int32_t n_rays;
@@ -97,17 +99,24 @@ struct TrainBuf {
 // dispatchers on the handle's operand type (defined once, in the fp16 translation units)
 void free_train_state(mnf_field_t f);
 int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train = nullptr);
+// training forward / backward with the sample count optionally on the device (io.n_dev64 / n_dev; n = upper bound)
+int forward_train(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream);
+int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb, const float *d_density,
+             const float *d_sem, const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale,
+             float *g_base, float *g_head, float *g_sem, bool zero_grads, hipStream_t stream);
 
 #define MNF_DECLARE_DT_IMPL(ns)                                                                                                      \
     namespace ns {                                                                                                                   \
     int launch_field_impl(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train);           \
-    int set_params_impl(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, hipStream_t stream);      \
+    int set_params_impl(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, bool table_current,       \
+                        hipStream_t stream);                                                                                         \
     void free_train_state_impl(mnf_field_t f);                                                                                       \
     int64_t train_workspace_bytes_impl(mnf_field_t f, int64_t n);                                                                    \
     int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream);         \
-    int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float *d_rgb, const float *d_density,                 \
-                      const float *d_sem, const float *rgb, const float *density, void *workspace, int64_t workspace_bytes,         \
-                      float loss_scale, float *g_base, float *g_head, float *g_sem, hipStream_t stream);                            \
+    int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb,                  \
+                      const float *d_density, const float *d_sem, const float *rgb, const float *density, void *workspace,          \
+                      int64_t workspace_bytes, float loss_scale, float *g_base, float *g_head, float *g_sem, bool zero_grads,       \
+                      hipStream_t stream);                                                                                          \
     }
 MNF_DECLARE_DT_IMPL(f16)
 MNF_DECLARE_DT_IMPL(bf16)

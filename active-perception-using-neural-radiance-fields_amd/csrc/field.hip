@@ -228,6 +228,11 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 
     int64_t n = args.io.n;
     if (MODE == 2) { n = *args.io.n_dev; if (n > args.io.n_cap) n = args.io.n_cap; }
+    if ((MODE == 0 || MODE == 1) && args.io.n_dev64) {   // the count lives on the device (train step): one scalar load
+        typedef const int64_t __attribute__((address_space(4))) *CntPtr;
+        const int64_t nd = *(CntPtr)(uintptr_t)args.io.n_dev64;
+        n = nd < n ? nd : n;
+    }
     const int64_t n_tiles_all = (n + kWaveSamples - 1) / kWaveSamples;
     if (n_tiles_all == 0) return;
     int64_t tile0 = 0, n_tiles = n_tiles_all;
@@ -699,7 +704,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));
     a.C = f->cfg.num_semantic_classes;
     a.out_fp16 = f->cfg.output_fp16 ? 1 : 0;
-    static const int active_waves = getenv("MNF_FIELD_ACTIVE_WAVES") ? atoi(getenv("MNF_FIELD_ACTIVE_WAVES")) : kWavesPerBlock;
+    static const int active_waves = diag_env("MNF_FIELD_ACTIVE_WAVES") ? atoi(diag_env("MNF_FIELD_ACTIVE_WAVES")) : kWavesPerBlock;
     a.active_waves = active_waves >= 1 && active_waves <= kWavesPerBlock ? active_waves : kWavesPerBlock;
     a.levels = reinterpret_cast<const LevelMeta *>(reinterpret_cast<const char *>(f->d_frags) + (size_t)f->shape.blocks_total * 1024);
     a.io = io;
@@ -759,11 +764,14 @@ int launch_field_impl(mnf_field_t f, const FieldIO &io, bool density_only, hipSt
     return MNF_ERR_UNSUPPORTED;
 }
 
-int set_params_impl(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, hipStream_t s) {
+int set_params_impl(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, bool table_current, hipStream_t s) {
     const int64_t n_tab = f->table_entries * 4;
-    hipLaunchKernelGGL(table_to_half_kernel, dim3(2048), dim3(256), 0, s, mlp_base + f->n_base_mlp, (tab_t *)f->d_table, n_tab);
-    int rc = launch_status("table_to_half_kernel");
-    if (rc) return rc;
+    int rc = MNF_OK;
+    if (!table_current) {      // the optimizer kernel may already have written the fp16 table (mnf_adam_step_guarded's mirror)
+        hipLaunchKernelGGL(table_to_half_kernel, dim3(2048), dim3(256), 0, s, mlp_base + f->n_base_mlp, (tab_t *)f->d_table, n_tab);
+        rc = launch_status("table_to_half_kernel");
+        if (rc) return rc;
+    }
     const int64_t n_frag = (int64_t)f->shape.blocks_total * 512;
     hipLaunchKernelGGL(gather_frags_kernel, dim3((unsigned)ceil_div(n_frag, 256)), dim3(256), 0, s, f->d_frag_src, mlp_base, mlp_head,
                        mlp_sem, (half_t *)f->d_frags, n_frag);
@@ -788,8 +796,21 @@ using namespace mnf::f16;    // host-side table builders (identical in both tran
 
 extern "C" int mnf_field_set_params(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, mnf_stream_t stream) {
     MNF_REQUIRE(f && mlp_base && mlp_head && mlp_sem, "field_set_params: null argument");
-    return f->cfg.mfma_bf16 ? bf16::set_params_impl(f, mlp_base, mlp_head, mlp_sem, as_stream(stream))
-                            : f16::set_params_impl(f, mlp_base, mlp_head, mlp_sem, as_stream(stream));
+    return f->cfg.mfma_bf16 ? bf16::set_params_impl(f, mlp_base, mlp_head, mlp_sem, false, as_stream(stream))
+                            : f16::set_params_impl(f, mlp_base, mlp_head, mlp_sem, false, as_stream(stream));
+}
+
+extern "C" int mnf_field_refresh_weights(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, mnf_stream_t stream) {
+    MNF_REQUIRE(f && mlp_base && mlp_head && mlp_sem, "field_refresh_weights: null argument");
+    MNF_REQUIRE(f->params_loaded, "field_refresh_weights: parameters were never loaded (the fp16 table is not current)");
+    return f->cfg.mfma_bf16 ? bf16::set_params_impl(f, mlp_base, mlp_head, mlp_sem, true, as_stream(stream))
+                            : f16::set_params_impl(f, mlp_base, mlp_head, mlp_sem, true, as_stream(stream));
+}
+
+extern "C" void *mnf_field_table_mirror(mnf_field_t f, int64_t *first_param_host) {
+    if (!f) return nullptr;
+    if (first_param_host) *first_param_host = f->n_base_mlp;
+    return f->d_table;
 }
 
 extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {

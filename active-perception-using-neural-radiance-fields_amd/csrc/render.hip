@@ -42,7 +42,7 @@ struct RenderWs {
 };
 
 static bool split_field() {
-    static const bool on = getenv("MNF_FIELD_SPLIT") != nullptr;
+    static const bool on = diag_env("MNF_FIELD_SPLIT") != nullptr;
     return on;
 }
 
@@ -57,12 +57,12 @@ static hipEvent_t *log_events() {
     if (!made) { for (auto &e : ev) (void)hipEventCreate(&e); made = true; }
     return ev;
 }
-static bool round_log() { static const bool on = getenv("MNF_ROUND_LOG") != nullptr; return on; }
+static bool round_log() { static const bool on = diag_env("MNF_ROUND_LOG") != nullptr; return on; }
 
 static const PipeCfg &pipe_cfg() {
     static PipeCfg c = [] {
         PipeCfg p;
-        if (const char *e = getenv("MNF_FIELD_PIPE")) sscanf(e, "%d,%d,%d,%d", &p.chunks, &p.rounds, &p.mlp_waves, &p.gather_grid);
+        if (const char *e = diag_env("MNF_FIELD_PIPE")) sscanf(e, "%d,%d,%d,%d", &p.chunks, &p.rounds, &p.mlp_waves, &p.gather_grid);
         return p;
     }();
     return c;
@@ -94,7 +94,7 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     // used; n_alive*stride <= max(R, 4*n_alive) <= 4R (utils.py:670) -> <= 8R, plus one partial tile per workgroup
     // (a march workgroup never mixes views: march_blocks_per_view() workgroups per view, so `stride` is the view's budget)
     int64_t col_cap = 8 * n_rays + 64 * (n_views * march_blocks_per_view(rays_per_view) + 2);
-    if (const char *e = getenv("MNF_MIN_SAMPLES")) col_cap = (int64_t)(2 * atoi(e) > 8 ? 2 * atoi(e) : 8) * n_rays + 64 * (n_views * march_blocks_per_view(rays_per_view) + 2);   // diagnostic schedule
+    if (const char *e = diag_env("MNF_MIN_SAMPLES")) col_cap = (int64_t)(2 * atoi(e) > 8 ? 2 * atoi(e) : 8) * n_rays + 64 * (n_views * march_blocks_per_view(rays_per_view) + 2);   // diagnostic schedule
     size_t off = 0;
     auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += align_up(bytes); return p; };
     char *p;
@@ -462,7 +462,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     const float *ab = aabb_host;
     const I3 res = {res_x, res_y, res_z};
     int32_t min_samples = opts->cone_angle == 0.f ? 1 : 4;                            // utils.py:645
-    if (const char *e = getenv("MNF_MIN_SAMPLES")) min_samples = atoi(e);   // diagnostic only (locality experiments): NOT the reference's schedule
+    if (const char *e = diag_env("MNF_MIN_SAMPLES")) min_samples = atoi(e);   // diagnostic only (locality experiments): NOT the reference's schedule
     const float opc_thre = 1.0f - opts->early_stop_eps;                                // utils.py:664
 
     const int64_t cells = (int64_t)res_x * res_y * res_z;
@@ -487,7 +487,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     io.fr.rgb_var = out.rgb_var; io.fr.depth_var = out.depth_var;
     io.fr.totals = reinterpret_cast<unsigned long long *>(total_samples);
     io.fr.rays_per_view = opts->rays_per_view; io.fr.probabilistic = opts->probabilistic;
-    io.fr.general_only = getenv("MNF_COMPOSITE_GENERAL") != nullptr;   // tests compare the two compositing paths with it
+    io.fr.general_only = diag_env("MNF_COMPOSITE_GENERAL") != nullptr;   // tests compare the two compositing paths with it
     io.fr.alpha_thre = opts->alpha_thre; io.fr.opc_thre = opc_thre;
 
     const int max_rounds = (int)ceil_div(opts->max_samples, min_samples);
@@ -548,15 +548,20 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
         if (rc) return rc;
         if (round_log()) {   // MNF_ROUND_LOG (diagnostic, synchronises every round): columns and per-view budgets of the round
             int32_t n_cols = 0, ns[8] = {0}, act[8] = {0};
+            std::vector<int32_t> act_all(n_views), alive_all(n_views);
             MNF_HIP(hipMemcpyAsync(&n_cols, ws.n_cols, 4, hipMemcpyDeviceToHost, s));
             MNF_HIP(hipMemcpyAsync(ns, ws.n_samples, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
             MNF_HIP(hipMemcpyAsync(act, ws.active, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(act_all.data(), ws.active, 4 * (size_t)n_views, hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(alive_all.data(), ws.alive_count, 4 * (size_t)n_views, hipMemcpyDeviceToHost, s));
             MNF_HIP(hipStreamSynchronize(s));
+            int n_act = 0; long long n_alive_after = 0;
+            for (int v = 0; v < n_views; ++v) { n_act += act_all[v] != 0; n_alive_after += alive_all[v]; }
             float ms = 0.f;
             if (!(pc.chunks > 1 && round < pc.rounds)) (void)hipEventElapsedTime(&ms, log_events()[0], log_events()[1]);
             float ms_march = 0.f;
             (void)hipEventElapsedTime(&ms_march, log_events()[2], log_events()[3]);
-            fprintf(stderr, "[mnf round %d] cols %d  field %.4f ms (%.3f ns/col)  march %.4f ms  budgets", round, n_cols, ms, n_cols ? ms * 1e6 / n_cols : 0.0, ms_march);
+            fprintf(stderr, "[mnf round %d] cols %d  field %.4f ms (%.3f ns/col)  march %.4f ms  active_views %d  alive_after %lld  budgets", round, n_cols, ms, n_cols ? ms * 1e6 / n_cols : 0.0, ms_march, n_act, n_alive_after);
             for (int v = 0; v < n_views && v < 8; ++v) fprintf(stderr, " %d", act[v] ? ns[v] : 0);
             fprintf(stderr, "\n");
         }

@@ -37,12 +37,22 @@ struct LayoutT {
     static constexpr int blocks = o_b1 + 2 * KSW;
 };
 
+// The number of samples of a training step may live on the device (mnf_train_step never brings it to the host): `n` is then the
+// upper bound the launch was sized for and `n_dev` the actual count, read with one scalar load.
+__device__ __forceinline__ int64_t count_here(int64_t n_cap, const int64_t *n_dev) {
+    if (!n_dev) return n_cap;
+    typedef const int64_t __attribute__((address_space(4))) *CntPtr;
+    const int64_t nd = *(CntPtr)(uintptr_t)n_dev;
+    return nd < n_cap ? nd : n_cap;
+}
+
 struct BwdArgs {
     const half8 *fragsT;
     const float *d_rgb, *d_sigma, *d_sem;   // [N,3], [N], [N,C]
     const float *rgb, *sigma;               // forward outputs [N,3], [N]
     float *dX;                              // [16 levels][Np][4] fp32, un-scaled (level-major for hash_bwd)
     int64_t n;
+    const int64_t *n_dev;
     int C;
     float loss_scale;
     TrainBuf train;
@@ -112,7 +122,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
     __shared__ half_t s_stage[kWavesPerBlock * kStageHalves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
     half_t *stage = s_stage + wave * kStageHalves;
-    const int64_t n = args.n;
+    const int64_t n = count_here(args.n, args.n_dev);
     const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
     if ((int64_t)blockIdx.x * kWavesPerBlock >= n_tiles) return;
     for (int i = threadIdx.x; i < L::blocks * 64; i += kThreads) s_w[i] = args.fragsT[i];
@@ -223,11 +233,12 @@ struct WgradGroup {
 // activation matrix.  Register blocking 2 x 2 reads each activation row once per two output tiles: the kernel is bound
 // by re-reading the activations (44 jobs x 64 rows -> 14 groups, -43 % bytes), not by the MFMAs.
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__ jobs, const WgradGroup *__restrict__ groups, int n_groups,
-                                                    int split, const half_t *__restrict__ act, int64_t n_tiles, int rows, float inv_scale,
-                                                    float *g0, float *g1, float *g2) {
+                                                    int split, const half_t *__restrict__ act, int64_t n_cap, const int64_t *n_dev, int rows,
+                                                    float inv_scale, float *g0, float *g1, float *g2) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= n_groups * split) return;
+    const int64_t n_tiles = (count_here(n_cap, n_dev) + 63) / 64;
     const WgradGroup gp = groups[wid / split];
     const int part = wid % split;
     const int64_t t0 = n_tiles * part / split, t1 = n_tiles * (part + 1) / split;
@@ -298,14 +309,16 @@ struct HashBwdArgs {
     int repl_levels;
     float *g_table;       // fp32 [entries][4]
     int64_t n;
+    const int64_t *n_dev;
     float aabb[6];
     LevelMeta levels[16];
 };
 
 // ngp.py:177-178 once per sample for the scatter below (the same expression as the forward kernel's fetch_sample)
-__global__ void __launch_bounds__(256) normalize_kernel(const float *__restrict__ pos, int64_t n, float a0, float a1, float a2, float a3, float a4,
-                                                        float a5, float *__restrict__ xn) {
+__global__ void __launch_bounds__(256) normalize_kernel(const float *__restrict__ pos, int64_t n_cap, const int64_t *n_dev, float a0, float a1, float a2,
+                                                        float a3, float a4, float a5, float *__restrict__ xn) {
     const float lo[3] = {a0, a1, a2}, hi[3] = {a3, a4, a5};
+    const int64_t n = count_here(n_cap, n_dev);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += (int64_t)blockDim.x * gridDim.x) {
         const int d = (int)(i % 3);
         xn[i] = (pos[i] - lo[d]) / (hi[d] - lo[d]);
@@ -351,8 +364,9 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
     const int corner = sub >> 2, feat = sub & 3;
     const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const int64_t i0 = chunk * kWalkChunk;
-    if (i0 >= args.n) return;
-    const int64_t i1 = i0 + kWalkChunk < args.n ? i0 + kWalkChunk : args.n;
+    const int64_t n_all = count_here(args.n, args.n_dev);
+    if (i0 >= n_all) return;
+    const int64_t i1 = i0 + kWalkChunk < n_all ? i0 + kWalkChunk : n_all;
     const int l = blockIdx.y + args.level0;
     const LevelMeta m = args.levels[l];
     float *const g_dst = l < args.repl_levels ? args.repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.g_table;
@@ -435,7 +449,7 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
 // corner and feature, no run merging.
 __global__ void __launch_bounds__(256) hash_bwd_simple_kernel(const HashBwdArgs args) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= args.n) return;
+    if (i >= count_here(args.n, args.n_dev)) return;
     float xn[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) xn[d] = args.positions[3 * i + d];
@@ -594,6 +608,10 @@ struct TrainState {
     half_t *d_fragT = nullptr;
     WgradJob *d_jobs = nullptr;
     WgradGroup *d_groups = nullptr;
+    // the hash-table scatter (float atomics, memory-side) runs beside the weight-gradient GEMMs (matrix cores + streaming loads)
+    // on a second stream of the handle: both only depend on the backward-data kernel
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static int ensure_train_state(mnf_field_t f) {
@@ -621,6 +639,9 @@ static int ensure_train_state(mnf_field_t f) {
     if (e == hipSuccess) e = hipMemcpy(ts->d_groups, ts->tt.groups.data(), ts->tt.groups.size() * sizeof(WgradGroup), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_fragT_src, ts->tt.fragT.data(), ts->tt.fragT.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_jobs, ts->tt.jobs.data(), ts->tt.jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error("train: %s", hipGetErrorString(e));
         delete ts;
@@ -637,12 +658,15 @@ void free_train_state_impl(mnf_field_t f) {
     if (ts->d_fragT) (void)hipFree(ts->d_fragT);
     if (ts->d_jobs) (void)hipFree(ts->d_jobs);
     if (ts->d_groups) (void)hipFree(ts->d_groups);
+    if (ts->side) (void)hipStreamDestroy(ts->side);
+    if (ts->ev_fork) (void)hipEventDestroy(ts->ev_fork);
+    if (ts->ev_join) (void)hipEventDestroy(ts->ev_join);
     delete ts;
     f->train_state = nullptr;
 }
 
 struct WsView {
-    half_t *act; uint8_t *masks; float *dX, *xn;
+    half_t *act; uint8_t *masks; float *dX, *xn, *repl;
     int64_t Np, bytes;
 };
 
@@ -655,6 +679,7 @@ static WsView carve_train(const TrainTables &tt, void *base, int64_t n) {
     v.masks = (uint8_t *)take((size_t)(v.Np / 64) * tt.mask_blocks * CT * 64);
     v.dX = (float *)take((size_t)v.Np * 64 * 4);
     v.xn = (float *)take((size_t)v.Np * 3 * 4);
+    v.repl = (float *)take((size_t)kReplicas * kReplMaxEntries * 4 * sizeof(float));   // private copies of the coarsest levels' gradient (scatter)
     v.bytes = (int64_t)off;
     return v;
 }
@@ -687,15 +712,17 @@ int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_
     return launch_field_impl(f, io, false, stream, &tb);
 }
 
-int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float *d_rgb, const float *d_density, const float *d_sem,
-                  const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale, float *g_base,
-                  float *g_head, float *g_sem, hipStream_t s) {
+int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb, const float *d_density,
+                  const float *d_sem, const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale,
+                  float *g_base, float *g_head, float *g_sem, bool zero_grads, hipStream_t s) {
     MNF_REQUIRE(f && f->params_loaded, "field_backward: parameters not loaded");
     MNF_REQUIRE(n >= 0 && loss_scale > 0.f, "field_backward: bad arguments");
     MNF_REQUIRE(g_base && g_head && g_sem, "field_backward: null gradient buffer");
-    MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));
-    MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
-    MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
+    if (zero_grads) {
+        MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));
+        MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
+        MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
+    }
     if (n == 0) return MNF_OK;
     MNF_REQUIRE(positions && d_rgb && d_density && d_sem && rgb && density, "field_backward: null pointer");
     int rc = ensure_train_state(f);
@@ -713,7 +740,7 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float 
     BwdArgs a;
     a.fragsT = reinterpret_cast<const half8 *>(ts->d_fragT);
     a.d_rgb = d_rgb; a.d_sigma = d_density; a.d_sem = d_sem; a.rgb = rgb; a.sigma = density;
-    a.dX = v.dX; a.n = n; a.C = f->cfg.num_semantic_classes; a.loss_scale = loss_scale;
+    a.dX = v.dX; a.n = n; a.n_dev = n_dev; a.C = f->cfg.num_semantic_classes; a.loss_scale = loss_scale;
     a.train = {v.act, v.masks, v.Np, ts->tt.rows};
     int grid = 256;
     const int64_t wgs = ceil_div(ceil_div(n, kWaveSamples), kWavesPerBlock);
@@ -733,10 +760,14 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float 
     MNF_REQUIRE(ok, "field_backward: unsupported shape");
     rc = launch_status("dgrad_kernel");
     if (rc) return rc;
+    // ---- fork: the hash-table scatter goes to the handle's side stream, the weight gradients stay on the caller's
+    hipStream_t ss = ts->side;
+    MNF_HIP(hipEventRecord(ts->ev_fork, s));
+    MNF_HIP(hipStreamWaitEvent(ss, ts->ev_fork, 0));
     // weight gradients
     const int n_groups = (int)ts->tt.groups.size();
     // enough sample chunks to fill the chip with waves (the loop is load-latency bound; 2 x 2 blocking leaves room for
-    // ~3 waves per SIMD), but at least 16 tiles per wave so the final atomics stay negligible
+    // ~3 waves per SIMD), but at least 16 tiles per wave so the final atomics stay negligible (sized on the upper bound `n`)
     const int64_t n_tiles = v.Np / 64;
     int split = (int)(256 * 12 / n_groups);
     if (split > n_tiles / 16) split = (int)(n_tiles / 16);
@@ -744,26 +775,25 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float 
     {
         ProfScope ps("wgrad", s);
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * split, 4)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
-                           split, v.act, n_tiles, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem);
+                           split, v.act, n, n_dev, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem);
     }
     rc = launch_status("wgrad_kernel");
     if (rc) return rc;
-    // hash-table gradient
+    // hash-table gradient (side stream)
     HashBwdArgs hb;
     {
         const float *ab = f->cfg.aabb;
         const int64_t blocks = ceil_div(3 * n, 256);
-        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, positions, n, ab[0], ab[1], ab[2], ab[3],
-                           ab[4], ab[5], v.xn);
+        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, ss, positions, n, n_dev, ab[0], ab[1], ab[2],
+                           ab[3], ab[4], ab[5], v.xn);
     }
-    hb.positions = v.xn; hb.dX = v.dX; hb.Np = v.Np; hb.g_table = g_base + f->n_base_mlp; hb.n = n;
+    hb.positions = v.xn; hb.dX = v.dX; hb.Np = v.Np; hb.g_table = g_base + f->n_base_mlp; hb.n = n; hb.n_dev = n_dev;
     std::memcpy(hb.aabb, f->cfg.aabb, sizeof(hb.aabb));
     std::memcpy(hb.levels, f->levels, sizeof(hb.levels));
     int n_levels = 16;
     hb.level0 = 0;
-    if (const char *e = getenv("MNF_HASH_BWD_LEVELS")) { int lo = 0, hi = 16; if (sscanf(e, "%d,%d", &lo, &hi) == 2) { hb.level0 = lo; n_levels = hi - lo; } }
-    // replicated coarse levels: the leading dense levels while they stay small; the copies live in the activation
-    // buffer, which the weight-gradient kernel above was the last to read
+    if (const char *e = diag_env("MNF_HASH_BWD_LEVELS")) { int lo = 0, hi = 16; if (sscanf(e, "%d,%d", &lo, &hi) == 2) { hb.level0 = lo; n_levels = hi - lo; } }
+    // replicated coarse levels: the leading dense levels while they stay small (their own region of the workspace)
     uint32_t repl_entries = 0;
     hb.repl_levels = 0;
     for (int l = 0; l < 16; ++l) {
@@ -772,20 +802,23 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const float 
         hb.repl_levels = l + 1;
     }
     hb.repl_floats = repl_entries * 4;
-    hb.repl = reinterpret_cast<float *>(v.act);
+    hb.repl = v.repl;
     const size_t repl_bytes = (size_t)kReplicas * hb.repl_floats * sizeof(float);
-    if ((size_t)ts->tt.rows * v.Np * 2 < repl_bytes) { hb.repl_levels = 0; hb.repl_floats = 0; }
-    const int prof_scatter = prof_start("hash_scatter", s);
-    if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.repl, 0, repl_bytes, s));
-    static const bool simple = getenv("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane, corner and feature
-    if (simple) hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, s, hb);
-    else hipLaunchKernelGGL(hash_bwd_walk_kernel, dim3((unsigned)ceil_div(ceil_div(n, kWalkChunk) * 32, 256), n_levels), dim3(256), 0, s, hb);
+    const int prof_scatter = prof_start("hash_scatter", ss);
+    if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.repl, 0, repl_bytes, ss));
+    static const bool simple = diag_env("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane, corner and feature
+    if (simple) hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, ss, hb);
+    else hipLaunchKernelGGL(hash_bwd_walk_kernel, dim3((unsigned)ceil_div(ceil_div(n, kWalkChunk) * 32, 256), n_levels), dim3(256), 0, ss, hb);
     rc = launch_status("hash_bwd_walk_kernel");
     if (rc) return rc;
     if (hb.repl_levels)
-        hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, s, hb.repl, hb.repl_floats, hb.g_table);
-    prof_stop(prof_scatter, s);
-    return launch_status("fold_replicas_kernel");
+        hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, ss, hb.repl, hb.repl_floats, hb.g_table);
+    prof_stop(prof_scatter, ss);
+    rc = launch_status("fold_replicas_kernel");
+    // ---- join
+    MNF_HIP(hipEventRecord(ts->ev_join, ss));
+    MNF_HIP(hipStreamWaitEvent(s, ts->ev_join, 0));
+    return rc;
 }
 
 MNF_DT_END
@@ -808,6 +841,35 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
     }
 }
 
+// The same update for a training loop that never synchronises with the host: the step count lives on the device and the whole update is
+// skipped when `skip` is non-zero (non-finite gradients, pipeline.py:520-529; a step that overflowed its sample bounds or rendered
+// no sample, csrc/trainstep.hip).  adam_prepare_kernel advances the count and derives the bias corrections (in double, as the host
+// version does); adam_guarded_kernel optionally mirrors the new parameters from `half_from` on into the field handle's fp16 hash
+// table, so the per-step fp32 -> fp16 conversion pass over the 25 M entries disappears.
+__global__ void adam_prepare_kernel(float *__restrict__ step, const int32_t *__restrict__ skip, float lr, float beta1, float beta2, float *__restrict__ hyper) {
+    const bool sk = skip && *skip != 0;
+    float st = *step;
+    if (!sk) { st += 1.0f; *step = st; }
+    const double bc1 = 1.0 - pow((double)beta1, (double)st), bc2 = 1.0 - pow((double)beta2, (double)st);
+    hyper[0] = (float)((double)lr / bc1); hyper[1] = (float)sqrt(bc2); hyper[2] = sk ? 1.0f : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) adam_guarded_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                           float *__restrict__ v, int64_t n, float beta1, float beta2, float eps,
+                                                           const float *__restrict__ hyper, _Float16 *__restrict__ half_out, int64_t half_from) {
+    const float step_size = hyper[0], bc2_sqrt = hyper[1];
+    if (hyper[2] != 0.0f) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float pn = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        p[i] = pn;
+        if (half_out && i >= half_from) half_out[i - half_from] = (_Float16)pn;
+    }
+}
+
 __global__ void __launch_bounds__(256) count_nan_kernel(const float *__restrict__ g, int64_t n, int32_t *__restrict__ count) {
     int local = 0;
     // NaN as the reference's guard (pipeline.py:520-529), and +-Inf as well: an overflowed fp16 activation gradient shows up
@@ -819,6 +881,19 @@ __global__ void __launch_bounds__(256) count_nan_kernel(const float *__restrict_
 
 void free_train_state(mnf_field_t f) {
     if (f->cfg.mfma_bf16) bf16::free_train_state_impl(f); else f16::free_train_state_impl(f);
+}
+int forward_train(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream) {
+    MNF_REQUIRE(f, "field_forward_train: null handle");
+    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, io, workspace, workspace_bytes, stream) : f16::forward_train_impl(f, io, workspace, workspace_bytes, stream);
+}
+int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb, const float *d_density, const float *d_sem,
+             const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale, float *g_base, float *g_head,
+             float *g_sem, bool zero_grads, hipStream_t stream) {
+    MNF_REQUIRE(f, "field_backward: null handle");
+    return f->cfg.mfma_bf16 ? bf16::backward_impl(f, positions, n, n_dev, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale,
+                                                  g_base, g_head, g_sem, zero_grads, stream)
+                            : f16::backward_impl(f, positions, n, n_dev, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale,
+                                                 g_base, g_head, g_sem, zero_grads, stream);
 }
 }  // namespace mnf
 
@@ -861,10 +936,8 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
                                   void *workspace, int64_t workspace_bytes, float loss_scale,
                                   float *g_base, float *g_head, float *g_sem, mnf_stream_t stream) {
     MNF_REQUIRE(f, "field_backward: null handle");
-    return f->cfg.mfma_bf16 ? bf16::backward_impl(f, positions, n, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale,
-                                                  g_base, g_head, g_sem, as_stream(stream))
-                            : f16::backward_impl(f, positions, n, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale,
-                                                 g_base, g_head, g_sem, as_stream(stream));
+    return backward(f, positions, n, nullptr, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale, g_base, g_head, g_sem, true,
+                    as_stream(stream));
 }
 
 extern "C" int mnf_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
@@ -876,6 +949,20 @@ extern "C" int mnf_adam_step(float *params, const float *grads, float *exp_avg, 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks < 8192 ? (blocks < 1 ? 1 : blocks) : 8192)), dim3(256), 0, as_stream(stream), params,
                        grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps, (float)((double)lr / bc1), (float)std::sqrt(bc2));
     return launch_status("adam_kernel");
+}
+
+extern "C" int mnf_adam_step_guarded(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                                     float beta2, float eps, float *step_dev, const int32_t *skip_dev, float *hyper_dev, void *half_out,
+                                     int64_t half_from, mnf_stream_t stream) {
+    if (n == 0) return MNF_OK;
+    MNF_REQUIRE(params && grads && exp_avg && exp_avg_sq && step_dev && hyper_dev, "adam_step_guarded: bad arguments");
+    MNF_REQUIRE(!half_out || (half_from >= 0 && half_from <= n), "adam_step_guarded: bad fp16 mirror range");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, step_dev, skip_dev, lr, beta1, beta2, hyper_dev);
+    const int64_t blocks = ceil_div(n, 256 * 4);
+    hipLaunchKernelGGL(adam_guarded_kernel, dim3((unsigned)(blocks < 8192 ? (blocks < 1 ? 1 : blocks) : 8192)), dim3(256), 0, s, params, grads, exp_avg,
+                       exp_avg_sq, n, beta1, beta2, eps, (const float *)hyper_dev, reinterpret_cast<_Float16 *>(half_out), half_from);
+    return launch_status("adam_guarded_kernel");
 }
 
 extern "C" int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf_stream_t stream) {

@@ -10,8 +10,11 @@
 //                     ensemble member -> per-view predictive-information terms.
 //
 // Both are compositions of the library's own entry points plus the small kernels below (stratified near planes, visibility
-// filter with compaction, loss + its gradient).  Two host syncs per train step (the marched and the surviving sample
-// counts size the following launches), which the reference's boolean-mask indexing has as well.
+// filter with compaction, loss + its gradient).  mnf_train_step never synchronises with the host: the marched and the
+// surviving sample counts stay on the device (every launch is sized for the caller's upper bounds and reads the actual
+// count from device memory), overflow of a bound is detected on the device (the step then yields zero gradients and a
+// raised skip flag, which `mnf_adam_step_guarded` honours) and reported through `counts_dev`, which the caller reads
+// whenever it wants to (the reference's boolean-mask indexing synchronises twice per step at these points).
 //
 // Build with -ffp-contract=off (the marcher's near planes feed bit-exact t values).
 #include <cmath>
@@ -126,7 +129,8 @@ __device__ __forceinline__ void smooth_l1(float x, float &val, float &grad) {   
 __global__ void __launch_bounds__(256) loss_kernel(int32_t n_rays, int32_t C, const float *__restrict__ rgb, const float *__restrict__ depth,
                                                    const float *__restrict__ sem, const float *__restrict__ t_rgb, const float *__restrict__ t_dep,
                                                    const int64_t *__restrict__ t_sem, float *__restrict__ g_rgb, float *__restrict__ g_dep,
-                                                   float *__restrict__ g_sem, float *__restrict__ losses /* [4]: total, rgb, depth, sem */) {
+                                                   float *__restrict__ g_sem, float *__restrict__ losses /* [4]: total, rgb, depth, sem */,
+                                                   int64_t *__restrict__ status, int32_t *__restrict__ skip) {
     __shared__ float s_acc[3][4];
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     float l_rgb = 0.f, l_dep = 0.f, l_sem = 0.f;
@@ -149,8 +153,12 @@ __global__ void __launch_bounds__(256) loss_kernel(int32_t n_rays, int32_t C, co
         float den = 0.f;
         for (int k = 0; k < C; ++k) den += expf(lg[k] - mx);
         const int64_t lab = t_sem[r];
-        l_sem = logf(den) - (lg[lab] - mx);
-        for (int k = 0; k < C; ++k) g_sem[(int64_t)r * C + k] = (expf(lg[k] - mx) / den - (k == lab ? 1.0f : 0.0f)) * 0.5f * inv_r;
+        // F.cross_entropy raises a device assert for a class id outside [0, C); here the step is flagged (status bit 8, skip
+        // raised: no optimizer update) and the ray contributes nothing, instead of reading past the logits row
+        const bool lab_ok = lab >= 0 && lab < C;
+        if (!lab_ok) { atomicOr(reinterpret_cast<unsigned long long *>(status), 8ull); atomicAdd(skip, 1); }
+        l_sem = lab_ok ? logf(den) - (lg[lab] - mx) : 0.0f;
+        for (int k = 0; k < C; ++k) g_sem[(int64_t)r * C + k] = lab_ok ? (expf(lg[k] - mx) / den - (k == lab ? 1.0f : 0.0f)) * 0.5f * inv_r : 0.0f;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { l_rgb += __shfl_xor(l_rgb, d, 64); l_dep += __shfl_xor(l_dep, d, 64); l_sem += __shfl_xor(l_sem, d, 64); }
@@ -166,6 +174,47 @@ __global__ void __launch_bounds__(256) loss_kernel(int32_t n_rays, int32_t C, co
         atomicAdd(&losses[0], a * 10.0f + b / 5.0f + c / 2.0f);
     }
 }
+
+// Device-side bound checks (what the host did between its two syncs in rounds 1-2).  counts_dev: [marched, kept, longest ray, status];
+// status bits: 1 marched > max_marched, 2 a ray longer than a scratch row, 4 kept > max_kept, 8 class id out of range, 16 no sample
+// survived (the reference `continue`s: no backward, no optimizer step).  On overflow every per-ray count is zeroed, so the kernels
+// behind the guard find nothing to do: the step yields zero gradients and `skip` > 0.
+__global__ void __launch_bounds__(256) guard_marched_kernel(int32_t n_rays, int64_t *__restrict__ counts, int64_t *__restrict__ starts,
+                                                            const int64_t *__restrict__ totals /* [0] marched, [2] longest */, int64_t max_marched,
+                                                            int64_t row_cap, int64_t *__restrict__ eff /* [0] */, int64_t *__restrict__ counts_dev,
+                                                            int32_t *__restrict__ skip) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tot = totals[0], longest = totals[2];
+    const bool bad = tot > max_marched || longest > row_cap;
+    if (bad && r < n_rays) { counts[r] = 0; starts[r] = 0; }
+    if (r == 0) {
+        counts_dev[0] = tot; counts_dev[2] = longest;
+        eff[0] = bad ? 0 : tot;
+        if (bad) {
+            atomicOr(reinterpret_cast<unsigned long long *>(counts_dev + 3), (unsigned long long)((tot > max_marched ? 1 : 0) | (longest > row_cap ? 2 : 0)));
+            atomicAdd(skip, 1);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) guard_kept_kernel(int32_t n_rays, int64_t *__restrict__ kept_cnts, int64_t *__restrict__ kept_starts,
+                                                         const int64_t *__restrict__ totals /* [1] kept */, int64_t max_kept,
+                                                         int64_t *__restrict__ eff /* [1] */, int64_t *__restrict__ counts_dev, int32_t *__restrict__ skip) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t kept = totals[1];
+    const bool bad = kept > max_kept;
+    if (bad && r < n_rays) { kept_cnts[r] = 0; kept_starts[r] = 0; }
+    if (r == 0) {
+        counts_dev[1] = kept;
+        eff[1] = bad ? 0 : kept;
+        if (bad || kept == 0) {
+            atomicOr(reinterpret_cast<unsigned long long *>(counts_dev + 3), bad ? 4ull : 16ull);
+            atomicAdd(skip, 1);
+        }
+    }
+}
+
+__global__ void set3_kernel(float *dst, float a, float b, float c) { dst[0] = a; dst[1] = b; dst[2] = c; }
 
 struct StepWs {
     float *nearp, *farp, *scratch_ts, *scratch_te, *alpha_thre;
@@ -219,9 +268,9 @@ extern "C" int64_t mnf_train_step_workspace_bytes(mnf_field_t f, int32_t n_rays,
 extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
                               int32_t res_z, const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays,
                               const float *target_rgb, const float *target_depth, const int64_t *target_sem, const mnf_train_opts *opts,
-                              float *g_base, float *g_head, float *g_sem, float *losses, int64_t *counts_host, int64_t max_marched,
+                              float *g_base, float *g_head, float *g_sem, float *losses, int64_t *counts_dev, int32_t *skip_dev, int64_t max_marched,
                               int64_t max_kept, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
-    MNF_REQUIRE(f && f->params_loaded && opts && aabb_host && counts_host, "train_step: bad handle or options");
+    MNF_REQUIRE(f && f->params_loaded && opts && aabb_host && counts_dev && skip_dev, "train_step: bad handle or options");
     MNF_REQUIRE(binaries && occs && rays_o && rays_d && target_rgb && target_depth && target_sem && g_base && g_head && g_sem && losses && workspace,
                 "train_step: null pointer");
     MNF_REQUIRE(n_rays > 0 && max_marched > 0 && max_kept > 0 && opts->render_step_size > 0.f, "train_step: bad sizes");
@@ -231,10 +280,16 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     if (workspace_bytes < w.bytes) { set_error("train_step: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)w.bytes); return MNF_ERR_WORKSPACE; }
     const int C = f->cfg.num_semantic_classes;
     const int64_t cells = (int64_t)res_x * res_y * res_z;
-    counts_host[0] = counts_host[1] = 0;
+    const int rblocks = (n_rays + 255) / 256;
     MNF_HIP(hipMemsetAsync(losses, 0, 4 * sizeof(float), s));
+    MNF_HIP(hipMemsetAsync(counts_dev, 0, 4 * sizeof(int64_t), s));
+    MNF_HIP(hipMemsetAsync(skip_dev, 0, sizeof(int32_t), s));
+    MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));
+    MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
+    MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
+    int64_t *eff = w.totals + 4;                                           // [0] marched, [1] kept samples the kernels behind the guards work on
     // ---- occupancy sampling (occ_grid.py:80-238): march, density pre-pass, visibility filter
-    hipLaunchKernelGGL(planes_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
+    hipLaunchKernelGGL(planes_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
                        opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp);
     double *mean_part = reinterpret_cast<double *>(w.totals + 8);          // 128 doubles behind the counters
     hipLaunchKernelGGL(mean_partial_kernel, dim3(128), dim3(256), 0, s, occs, cells, mean_part);
@@ -245,58 +300,51 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     rc = mnf_exclusive_scan_i64(w.counts, n_rays, w.starts, w.totals, w.scan, mnf_scan_workspace_bytes(n_rays), stream);
     if (rc) return rc;
     hipLaunchKernelGGL(max_kernel, dim3(1), dim3(1024), 0, s, w.counts, (int64_t)n_rays, w.totals + 2);
-    int64_t head[3] = {0, 0, 0};                                       // marched total, (kept total, later), longest ray
-    MNF_HIP(hipMemcpyAsync(head, w.totals, sizeof(head), hipMemcpyDeviceToHost, s));
-    MNF_HIP(hipStreamSynchronize(s));                                  // sync 1: the marched count sizes the pre-pass
-    const int64_t marched = head[0];
-    counts_host[0] = marched;
-    if (head[2] > cap) { set_error("train_step: a ray has %lld samples, more than a scratch row holds (%d): use the two-pass sampler", (long long)head[2], cap); return MNF_ERR_UNSUPPORTED; }
-    if (marched > max_marched) { set_error("train_step: %lld marched samples exceed max_marched %lld", (long long)marched, (long long)max_marched); return MNF_ERR_WORKSPACE; }
-    MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));
-    MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
-    MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
-    if (marched == 0) return MNF_OK;
-    // a ray longer than its scratch row would have been truncated: the rows hold `cap` samples (the reference configurations stay far below)
+    // a ray longer than its scratch row would have been truncated (the rows hold `cap` samples; the reference configurations stay far
+    // below) and more marched samples than `max_marched` would not fit the packed arrays: both end the step here, on the device
+    hipLaunchKernelGGL(guard_marched_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, w.counts, w.starts, (const int64_t *)w.totals, max_marched,
+                       (int64_t)cap, eff, counts_dev, skip_dev);
     rc = mnf_compact_samples(w.scratch_ts, w.scratch_te, cap, w.starts, w.counts, n_rays, w.ts, w.te, w.ray, stream);
     if (rc) return rc;
-    rc = mnf_field_density_rays(f, rays_o, rays_d, w.ray, w.ts, w.te, w.starts, w.counts, n_rays, marched, opts->early_stop_eps, w.sigma, stream);
+    rc = mnf_field_density_rays(f, rays_o, rays_d, w.ray, w.ts, w.te, w.starts, w.counts, n_rays, max_marched, opts->early_stop_eps, w.sigma, stream);
     if (rc) return rc;
     const int vgrid = n_rays < 65535 ? n_rays : 65535;
     hipLaunchKernelGGL(visibility_kernel<false>, dim3(vgrid), dim3(64), 0, s, n_rays, w.starts, w.counts, w.ts, w.te, w.sigma, opts->early_stop_eps,
                        w.alpha_thre, w.kept_cnts, (const int64_t *)nullptr, (float *)nullptr, (float *)nullptr, (int64_t *)nullptr);
     rc = mnf_exclusive_scan_i64(w.kept_cnts, n_rays, w.kept_starts, w.totals + 1, w.scan, mnf_scan_workspace_bytes(n_rays), stream);
     if (rc) return rc;
-    int64_t kept = 0;
-    MNF_HIP(hipMemcpyAsync(&kept, w.totals + 1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    MNF_HIP(hipStreamSynchronize(s));                                  // sync 2: the surviving count sizes forward and backward
-    counts_host[1] = kept;
-    if (kept > max_kept) { set_error("train_step: %lld surviving samples exceed max_kept %lld", (long long)kept, (long long)max_kept); return MNF_ERR_WORKSPACE; }
-    if (kept == 0) return MNF_OK;
+    hipLaunchKernelGGL(guard_kept_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, w.kept_cnts, w.kept_starts, (const int64_t *)w.totals, max_kept, eff,
+                       counts_dev, skip_dev);
     hipLaunchKernelGGL(visibility_kernel<true>, dim3(vgrid), dim3(64), 0, s, n_rays, w.starts, w.counts, w.ts, w.te, w.sigma, opts->early_stop_eps,
                        w.alpha_thre, (int64_t *)nullptr, w.kept_starts, w.k_ts, w.k_te, w.k_ray);
     // ---- sem_rendering (utils.py:362-461): field with saved activations, compositing
-    rc = mnf_field_forward_train_samples(f, rays_o, rays_d, w.k_ray, w.k_ts, w.k_te, kept, w.k_rgb, w.k_sigma, w.k_sem, w.k_pos, w.field_ws,
-                                         w.field_ws_bytes, stream);
-    if (rc) return rc;
-    float *bk = nullptr;
-    float bk_host[3] = {opts->render_bkgd[0], opts->render_bkgd[1], opts->render_bkgd[2]};
-    if (bk_host[0] != 0.f || bk_host[1] != 0.f || bk_host[2] != 0.f) {
-        bk = w.alpha_thre + 8;                                         // three floats of the small scalar block
-        MNF_HIP(hipMemcpyAsync(bk, bk_host, sizeof(bk_host), hipMemcpyHostToDevice, s));
+    {
+        FieldIO io = {};
+        io.mode = 1; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = w.k_ray; io.t_starts = w.k_ts; io.t_ends = w.k_te;
+        io.n = max_kept; io.n_dev64 = eff + 1;
+        io.rgb = w.k_rgb; io.density = w.k_sigma; io.sem = w.k_sem; io.positions_out = w.k_pos;
+        rc = forward_train(f, io, w.field_ws, w.field_ws_bytes, s);
+        if (rc) return rc;
     }
-    rc = mnf_composite_train_forward(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, C, kept, bk, w.o_rgb, w.o_acc,
+    const float *bk = opts->render_bkgd_dev;                               // the caller's device colour, or the by-value one
+    if (!bk && (opts->render_bkgd[0] != 0.f || opts->render_bkgd[1] != 0.f || opts->render_bkgd[2] != 0.f)) {
+        float *bkd = w.alpha_thre + 8;                                     // three floats of the small scalar block
+        hipLaunchKernelGGL(set3_kernel, dim3(1), dim3(1), 0, s, bkd, opts->render_bkgd[0], opts->render_bkgd[1], opts->render_bkgd[2]);
+        bk = bkd;
+    }
+    rc = mnf_composite_train_forward(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, C, max_kept, bk, w.o_rgb, w.o_acc,
                                      w.o_dep, w.o_sem, w.k_w, w.k_tr, nullptr, stream);
     if (rc) return rc;
     // ---- loss (pipeline.py:506-511) and backward (pipeline.py:518)
-    hipLaunchKernelGGL(loss_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, s, n_rays, C, w.o_rgb, w.o_dep, w.o_sem, target_rgb, target_depth, target_sem,
-                       w.g_rgb, w.g_dep, w.g_sem, losses);
+    hipLaunchKernelGGL(loss_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, C, w.o_rgb, w.o_dep, w.o_sem, target_rgb, target_depth, target_sem,
+                       w.g_rgb, w.g_dep, w.g_sem, losses, counts_dev + 3, skip_dev);
     rc = launch_status("loss_kernel");
     if (rc) return rc;
-    rc = mnf_composite_train_backward(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, C, kept, bk, w.k_w, w.k_tr, w.o_acc,
+    rc = mnf_composite_train_backward(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, C, max_kept, bk, w.k_w, w.k_tr, w.o_acc,
                                       w.o_dep, w.g_rgb, nullptr, w.g_dep, w.g_sem, w.k_dsig, w.k_drgb, w.k_dsem, stream);
     if (rc) return rc;
-    return mnf_field_backward(f, w.k_pos, kept, w.k_drgb, w.k_dsig, w.k_dsem, w.k_rgb, w.k_sigma, w.field_ws, w.field_ws_bytes, opts->loss_scale, g_base,
-                              g_head, g_sem, stream);
+    return backward(f, w.k_pos, max_kept, eff + 1, w.k_drgb, w.k_dsig, w.k_dsem, w.k_rgb, w.k_sigma, w.field_ws, w.field_ws_bytes, opts->loss_scale, g_base,
+                    g_head, g_sem, false, s);
 }
 
 extern "C" int64_t mnf_score_poses_workspace_bytes(int32_t n_members, int32_t n_views, int32_t n_pix, int32_t n_classes) {

@@ -199,6 +199,15 @@ class NGPRadianceField(torch.nn.Module):
             self._loaded_versions = versions
         return self._handle
 
+    def _refresh_after_optimizer(self):
+        """Called by `optim.FusedAdam` (bound with `bind_field`) after it updated the parameters: its kernel has already written the
+        rounded hash-table values into the handle's fp16 table, so only the MLP weight fragments are re-derived (no conversion pass
+        over the 25 M table entries), and the handle counts as current for the new parameter versions."""
+        lib = L.load_library()
+        L.launch(lib.mnf_field_refresh_weights, self._handle, L.ptr(self.mlp_base.params), L.ptr(self.mlp_head.params), L.ptr(self.mlp_sem.params))
+        self._loaded_versions = (self.mlp_base.params._version, self.mlp_head.params._version, self.mlp_sem.params._version,
+                                 self.mlp_base.params.data_ptr())
+
     def __del__(self):
         try:
             if self._handle:

@@ -1,10 +1,21 @@
 """Optimizer for the field's three flat parameter vectors.
 
 `FusedAdam` is `torch.optim.Adam(params, lr, betas, eps)` as the reference constructs it (scripts/pipeline.py:173-178:
-weight_decay 0, amsgrad off) with the update of a parameter done by ONE HIP kernel (csrc/train.hip adam_kernel) instead
+weight_decay 0, amsgrad off) with the update of a parameter done by ONE HIP kernel (csrc/train.hip adam_guarded_kernel) instead
 of the six foreach passes over the 25 M hash-table entries.  State keys (`step`, `exp_avg`, `exp_avg_sq`) and
 `state_dict()` layout are torch's, so checkpoints written through either optimizer load into the other
-(pipeline.py:630-635 saves `optimizer.state_dict()`)."""
+(pipeline.py:630-635 saves `optimizer.state_dict()`).
+
+The step never synchronises with the host: `state["step"]` is a DEVICE scalar (what torch's own `capturable=True` Adam keeps)
+advanced by the kernel, and `step(skip=flag)` takes a device int32 flag — the whole update, including the step count, is
+left out on the device when the flag is non-zero.  That is the reference's NaN guard (pipeline.py:520-529: `optimizer.zero_grad();
+continue` when any gradient is NaN) without the `.item()` per parameter.
+
+`bind_field(field)`: the optimizer kernel of `mlp_base.params` also writes the rounded new hash-table values into the field
+handle's fp16 table, and after the step only the MLP weight fragments are re-derived (a few KB) — the handle does not re-convert
+the 25 M table entries on the next forward."""
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -17,14 +28,29 @@ class FusedAdam(torch.optim.Optimizer):
         if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+        self._field = None
+        self._scratch = {}          # per parameter: 4 device floats (derived step size, bias correction, skip) — not optimizer state
+
+    def bind_field(self, field):
+        """The NGPRadianceField whose parameters this optimizer updates (optional; see the module docstring)."""
+        self._field = field
+        return self
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, skip=None):
+        """`skip`: optional device int32 scalar; non-zero = leave every parameter, moment and step count untouched."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = L.load_library()
+        field = self._field
+        mirror, mirror_from, touched_field = None, 0, False
+        if field is not None and field.mlp_base.params.is_cuda:
+            handle = field._ensure_handle()                      # the handle holds the CURRENT parameters before they change
+            first = ctypes.c_int64(0)
+            mirror = lib.mnf_field_table_mirror(handle, ctypes.byref(first))
+            mirror_from = int(first.value)
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             for p in group["params"]:
@@ -34,22 +60,31 @@ class FusedAdam(torch.optim.Optimizer):
                     raise L.MnfError("FusedAdam needs contiguous fp32 parameters on the GPU")
                 st = self.state[p]
                 if len(st) == 0:
-                    st["step"] = torch.tensor(0.0)
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                if not st["step"].is_cuda or st["step"].device != p.device:      # a state_dict loaded from torch.optim.Adam keeps it on the host
+                    st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+                hy = self._scratch.get(p)
+                if hy is None or hy.device != p.device:
+                    hy = self._scratch[p] = torch.zeros(4, dtype=torch.float32, device=p.device)
                 g = p.grad.contiguous()
-                L.launch(lib.mnf_adam_step, L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
-                                          float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), int(st["step"].item()))
-                torch.autograd.graph.increment_version(p)      # in-place update outside autograd's view: the handle reloads
+                is_table = field is not None and mirror and p is field.mlp_base.params
+                L.launch(lib.mnf_adam_step_guarded, L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
+                         float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), L.ptr(st["step"]), L.ptr(skip), L.ptr(hy),
+                         ctypes.c_void_p(mirror) if is_table else None, mirror_from if is_table else 0)
+                torch.autograd.graph.increment_version(p)      # in-place update outside autograd's view
+                touched_field = touched_field or (field is not None and any(p is q for q in field.parameters()))
+        if field is not None and mirror and touched_field:
+            field._refresh_after_optimizer()
         return loss
 
 
-def count_nan_gradients(parameters) -> torch.Tensor:
-    """Number of NaN gradient entries over `parameters` as a device int32 scalar (one launch per parameter, no host sync):
-    the guard of pipeline.py:520-529."""
+def count_nan_gradients(parameters, out=None) -> torch.Tensor:
+    """Number of NaN / Inf gradient entries over `parameters` as a device int32 scalar (one launch per parameter, no host sync):
+    the guard of pipeline.py:520-529.  `out`: an existing device int32 scalar to add to (e.g. the skip flag of a train step)."""
     lib = L.load_library()
-    count = None
+    count = out
     for p in parameters:
         if p.grad is None:
             continue

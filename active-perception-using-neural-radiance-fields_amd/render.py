@@ -215,10 +215,12 @@ def render_image_with_occgrid_with_depth_guide(radiance_field, estimator, rays: 
     return colors.view(*shp, -1), opacities.view(*shp, -1), depths.view(*shp, -1), semantics.view(*shp, -1), sum(r[4] for r in results)
 
 
-def allreduce_gradients(parameters, group=None):
+def allreduce_gradients(parameters, group=None, skip=None):
     """Ray-data-parallel training: every rank renders its own slice of the ray batch, then the gradients of
     the three flat parameter vectors are averaged with one all-reduce each (RCCL over xGMI on GPUs; the hash-table vector
-    is 100 MB, the two heads a few KB).  No-op without an initialised process group of more than one rank."""
+    is 100 MB, the two heads a few KB).  `skip` (device int32 scalar): the per-rank "do not apply this step" flag is summed
+    over the ranks as well, so every rank takes the same decision.  No-op without an initialised process group of more
+    than one rank.  EVERY rank must call it every step (a rank whose rays produced no sample contributes zero gradients)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return
@@ -229,22 +231,44 @@ def allreduce_gradients(parameters, group=None):
         if p_.grad is not None:
             dist.all_reduce(p_.grad, op=dist.ReduceOp.SUM, group=group)
             p_.grad.div_(world)
+    if skip is not None:
+        dist.all_reduce(skip, op=dist.ReduceOp.SUM, group=group)
 
 
-_TRAIN_CAPS = {}
+_TRAIN_STATE = {}
+
+# status bits of mnf_train_step's counts_dev[3] (include/mi355nerf.h)
+_ST_MARCHED, _ST_ROW, _ST_KEPT, _ST_LABEL, _ST_EMPTY = 1, 2, 4, 8, 16
+
+
+def _grow_caps(st, marched, kept):
+    st["cap_m"] = max(st["cap_m"], int(marched * 1.3) + 1024)
+    st["cap_k"] = max(st["cap_k"], int(max(kept, marched // 2) * 1.3) + 1024)
+
+
+def _check_status(status):
+    if status & _ST_LABEL:
+        raise L.MnfError("train_step: a semantic class id lies outside [0, num_semantic_classes) (F.cross_entropy's device assert)")
 
 
 @torch.no_grad()
 def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, sem, render_bkgd=None, near_plane=0.1, far_plane=1e10,
-                           render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, early_stop_eps=1e-4, stratified=None):
+                           render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, early_stop_eps=1e-4, stratified=None, sync=True):
     """scripts/pipeline.py:472-518 for one model as ONE C call (`mnf_train_step`, csrc/trainstep.hip): train render (occupancy
     sampling + density pre-pass + visibility filter + sem_rendering), the three-term loss and its backward.  Fills `.grad` of
-    the three flat parameter vectors and returns dict(loss, loss_rgb, loss_dep, loss_sem [device scalars], n_rendering_samples,
-    n_marched).  Returns None when this estimator / batch cannot take the fused path (multi-level grid, a ray longer than
-    the single-pass scratch row): the caller then uses the autograd path, which is the same arithmetic in separate calls."""
+    the three flat parameter vectors.  The call itself never waits for the GPU: the sample counts stay on the device.
+
+    Returns dict(loss, loss_rgb, loss_dep, loss_sem [device scalars], counts [device int64: marched, kept, longest ray, status],
+    skip [device int32 scalar: non-zero = the gradients must not be applied], n_rendering_samples, n_marched).
+      sync=True   (default) the counts are read back once, AFTER everything is enqueued: n_rendering_samples / n_marched are
+                  ints as in the reference; a step whose sample bounds were too small is repeated with larger ones.
+      sync=False  nothing is read back: n_rendering_samples / n_marched are 0-d device tensors; the bounds are adapted from the
+                  previous call's counts (copied to pinned memory in the background); a step beyond its bounds is skipped on
+                  the device (skip != 0) and the bounds grow for the next one.
+    Returns None when this estimator / batch cannot take the fused path (multi-level grid, a ray longer than the single-pass
+    scratch row): the caller then uses the autograd path, which is the same arithmetic in separate calls."""
     if estimator.levels != 1:
         return None
-    import ctypes
     lib = L.load_library()
     o, d = L.contig(rays.origins.reshape(-1, 3), torch.float32), L.contig(rays.viewdirs.reshape(-1, 3), torch.float32)
     L.require_gpu(o, d, pixels, dep, sem)
@@ -256,9 +280,15 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
     opts = L.TrainOpts()
     opts.near_plane, opts.far_plane, opts.render_step_size, opts.cone_angle = near_plane, far_plane, render_step_size, cone_angle
     opts.alpha_thre, opts.early_stop_eps, opts.loss_scale = alpha_thre, early_stop_eps, float(radiance_field.loss_scale)
-    bk = [0.0, 0.0, 0.0] if render_bkgd is None else [float(x) for x in render_bkgd.detach().cpu().reshape(-1)[:3]]
-    for i in range(3):
-        opts.render_bkgd[i] = bk[i]
+    bk_dev = None
+    if render_bkgd is not None and render_bkgd.is_cuda:          # pipeline.py:437 draws the colour on the GPU: hand over the pointer
+        bk_dev = L.contig(render_bkgd.detach().reshape(-1)[:3].to(device=dev, dtype=torch.float32))
+        opts.render_bkgd_dev = bk_dev.data_ptr()
+    else:
+        bk = [0.0, 0.0, 0.0] if render_bkgd is None else [float(x) for x in render_bkgd.detach().reshape(-1)[:3]]
+        for i in range(3):
+            opts.render_bkgd[i] = bk[i]
+        opts.render_bkgd_dev = None
     opts.stratified = int(radiance_field.training if stratified is None else stratified)
     opts.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     params = [radiance_field.mlp_base.params, radiance_field.mlp_head.params, radiance_field.mlp_sem.params]
@@ -266,49 +296,87 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         if p_.grad is None or p_.grad.shape != p_.shape or not p_.grad.is_contiguous():
             p_.grad = torch.empty_like(p_)
     tp, td, tl = L.contig(pixels, torch.float32), L.contig(dep, torch.float32), L.contig(sem, torch.int64)
-    losses = torch.empty(4, device=dev)
-    counts = (ctypes.c_int64 * 2)()
     key = (id(radiance_field), R)
-    cap_m, cap_k = _TRAIN_CAPS.get(key, (R * 384, R * 192))
+    st = _TRAIN_STATE.get(key)
+    if st is None:
+        st = _TRAIN_STATE[key] = dict(cap_m=R * 384, cap_k=R * 192, pending=None)
+    pend = st["pending"]
+    if pend is not None and (sync or pend[1].query()):           # counts of an earlier lazy step: adapt the bounds, surface its errors
+        pend[1].synchronize()
+        c = pend[0].tolist()
+        st["pending"] = None
+        _check_status(c[3])
+        if c[3] & _ST_ROW:
+            raise L.MnfError("train_step: a ray has more samples than a scratch row holds (use the autograd path: fused=False)")
+        if c[3] & (_ST_MARCHED | _ST_KEPT):
+            _grow_caps(st, c[0], c[1])
     for _attempt in range(4):
-        nbytes = int(lib.mnf_train_step_workspace_bytes(handle, R, cap_m, cap_k))
+        losses = torch.empty(4, device=dev)
+        counts = torch.empty(4, dtype=torch.int64, device=dev)
+        skip = torch.empty((), dtype=torch.int32, device=dev)
+        nbytes = int(lib.mnf_train_step_workspace_bytes(handle, R, st["cap_m"], st["cap_k"]))
         ws = _workspace(dev, nbytes)
-        try:
-            L.launch(lib.mnf_train_step, handle, L.ptr(binaries), L.ptr(bits[0]), L.ptr(estimator.occs), res[0], res[1], res[2],
-                     (ctypes.c_float * 6)(*aabb), L.ptr(o), L.ptr(d), R, L.ptr(tp), L.ptr(td), L.ptr(tl), ctypes.byref(opts),
-                     L.ptr(params[0].grad), L.ptr(params[1].grad), L.ptr(params[2].grad), L.ptr(losses), counts, cap_m, cap_k, L.ptr(ws), nbytes)
+        L.launch(lib.mnf_train_step, handle, L.ptr(binaries), L.ptr(bits[0]), L.ptr(estimator.occs), res[0], res[1], res[2],
+                 (ctypes.c_float * 6)(*aabb), L.ptr(o), L.ptr(d), R, L.ptr(tp), L.ptr(td), L.ptr(tl), ctypes.byref(opts),
+                 L.ptr(params[0].grad), L.ptr(params[1].grad), L.ptr(params[2].grad), L.ptr(losses), L.ptr(counts), L.ptr(skip),
+                 st["cap_m"], st["cap_k"], L.ptr(ws), nbytes)
+        if not sync:
             break
-        except L.MnfError as e:
-            if counts[0] > cap_m or counts[1] > cap_k:             # a sample bound was too small: grow and redo
-                cap_m, cap_k = max(cap_m, int(counts[0] * 1.3) + 1024), max(cap_k, int(max(counts[1], counts[0] // 3) * 1.3) + 1024)
-                continue
-            if "scratch row" in str(e):
-                return None
-            raise
+        c = counts.tolist()                                         # the step's one host round trip, after everything is enqueued
+        _check_status(c[3])
+        if c[3] & _ST_ROW:
+            return None
+        if c[3] & (_ST_MARCHED | _ST_KEPT):                         # a sample bound was too small: grow and redo
+            _grow_caps(st, c[0], c[1])
+            continue
+        break
     else:
         raise L.MnfError("train_step: sample bounds kept growing")
-    _TRAIN_CAPS[key] = (cap_m, cap_k)
-    estimator.last_sampling = {"n_marched": int(counts[0])}
     for p_ in params:
         torch.autograd.graph.increment_version(p_.grad)
-    return dict(loss=losses[0], loss_rgb=losses[1], loss_dep=losses[2], loss_sem=losses[3], n_rendering_samples=int(counts[1]),
-                n_marched=int(counts[0]))
+    out = dict(loss=losses[0], loss_rgb=losses[1], loss_dep=losses[2], loss_sem=losses[3], counts=counts, skip=skip, _keep=bk_dev)
+    if sync:
+        estimator.last_sampling = {"n_marched": int(c[0])}
+        out.update(n_rendering_samples=int(c[1]), n_marched=int(c[0]))
+    else:
+        host = torch.empty(4, dtype=torch.int64).pin_memory()
+        host.copy_(counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        st["pending"] = (host, ev)
+        estimator.last_sampling = {"n_marched": counts[0]}
+        out.update(n_rendering_samples=counts[1], n_marched=counts[0])
+    return out
 
 
 def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, sem, render_bkgd, step: int,
                near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-3, scheduler=None,
-               data_parallel_group=None, data_parallel=False, fused=True):
+               data_parallel_group=None, data_parallel=False, fused=True, sync=True, stratified=None):
     """One model's training iteration exactly as scripts/pipeline.py:447-532 sequences it: occupancy refresh every 16th
     step (:447-470), train render (:472-489), loss 10*smoothL1(rgb) + smoothL1(depth)/5 + CE(sem)/2 (:506-511),
     backward (:518), NaN-gradient guard (:520-529), optimizer and scheduler step (:531-532).  `data_parallel=True`
-    averages the gradients over the ranks of `data_parallel_group` before the guard (each rank holds a slice of the rays).
+    averages the gradients (and sums the skip flags) over the ranks of `data_parallel_group` before the guard (each rank holds
+    a slice of the rays; every rank reaches the collective every step, whatever its own batch produced).
     `fused=True` (default) runs render + loss + backward as one C call (`fused_forward_backward`); `fused=False` goes through
     the differentiable Python surface (`render_image_with_occgrid_with_depth_guide` + torch losses + autograd), which is the
     same kernels call by call.
+
+    With `optim.FusedAdam` the decision "skip this iteration" (no surviving sample, non-finite gradient) is taken on the
+    device and the iteration is enqueued without waiting for the GPU:
+      sync=True   (default) ONE host round trip at the end (the reference has one per parameter plus two inside the sampler):
+                  returns n_rendering_samples as an int and skipped as a bool, steps the scheduler only if the optimizer stepped.
+      sync=False  no round trip at all: n_rendering_samples and skipped are device tensors, the scheduler advances every call.
+    Any other optimizer is stepped from the host after reading the flag (sync=True only).
+    `stratified` (fused path): None = jitter the near planes as the reference does in training mode (occ_grid.py:187-189);
+    False = no jitter (reproducible sample sets: parity tests).
     Returns dict(loss, loss_rgb, loss_dep, loss_sem as device tensors, n_rendering_samples, skipped)."""
     import torch.nn.functional as F
+    from .optim import FusedAdam, count_nan_gradients
     radiance_field.train()
     estimator.train()
+    device_guard = isinstance(optimizer, FusedAdam)
+    if not sync and not (fused and device_guard):
+        raise ValueError("train_step(sync=False) needs fused=True and optim.FusedAdam (the skip decision is taken on the device)")
 
     occ_eval_fn = NA.FieldDensityOcc(radiance_field, render_step_size)     # pipeline.py:376-378; one fused C call per refresh
 
@@ -316,36 +384,53 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     out = None
     if fused:
         out = fused_forward_backward(radiance_field, estimator, rays, pixels, dep, sem, render_bkgd, near_plane=near_plane,
-                                     render_step_size=render_step_size, cone_angle=cone_angle, alpha_thre=alpha_thre)
+                                     render_step_size=render_step_size, cone_angle=cone_angle, alpha_thre=alpha_thre, sync=sync,
+                                     stratified=stratified)
     if out is not None:
         n_rendering_samples = out["n_rendering_samples"]
-        if n_rendering_samples == 0:
-            optimizer.zero_grad()
-            return dict(loss=None, n_rendering_samples=0, skipped=True)
         loss, loss_rgb, loss_dep, loss_sem = out["loss"], out["loss_rgb"], out["loss_dep"], out["loss_sem"]
+        skip = out["skip"]                         # device flag: raised by the C call for a step without samples
     else:
         rgb, acc, depth, semantic, n_rendering_samples = render_image_with_occgrid_with_depth_guide(
             radiance_field, estimator, rays, near_plane=near_plane, render_step_size=render_step_size, render_bkgd=render_bkgd,
             cone_angle=cone_angle, alpha_thre=alpha_thre, depth=dep)
+        dev = rays.origins.device
+        skip = torch.zeros((), dtype=torch.int32, device=dev)
+        optimizer.zero_grad()
         if n_rendering_samples == 0:
-            return dict(loss=None, n_rendering_samples=0, skipped=True)
-        loss_rgb = F.smooth_l1_loss(rgb, pixels)
-        loss_dep = F.smooth_l1_loss(depth, dep.unsqueeze(1))
-        loss_sem = F.cross_entropy(semantic, sem)
-        loss = loss_rgb * 10 + loss_dep / 5 + loss_sem / 2
-        optimizer.zero_grad()
-        loss.backward()
+            # pipeline.py:491: `continue`.  With data_parallel the collective below still has to be reached by this rank:
+            # it contributes zero gradients and a raised skip flag.
+            skip += 1
+            for p_ in radiance_field.parameters():
+                p_.grad = torch.zeros_like(p_)
+            loss = loss_rgb = loss_dep = loss_sem = torch.zeros((), device=dev)
+        else:
+            loss_rgb = F.smooth_l1_loss(rgb, pixels)
+            loss_dep = F.smooth_l1_loss(depth, dep.unsqueeze(1))
+            loss_sem = F.cross_entropy(semantic, sem)
+            loss = loss_rgb * 10 + loss_dep / 5 + loss_sem / 2
+            loss.backward()
     if data_parallel:
-        allreduce_gradients(radiance_field.parameters(), data_parallel_group)
-    from .optim import count_nan_gradients
-    bad = count_nan_gradients(radiance_field.parameters())
-    skipped = bool(bad.item() > 0)          # one host sync (the reference syncs once per parameter)
-    if skipped:
-        optimizer.zero_grad()
+        allreduce_gradients(radiance_field.parameters(), data_parallel_group, skip)
+    count_nan_gradients(radiance_field.parameters(), out=skip)                 # pipeline.py:520-529, added to the same flag
+    if device_guard:
+        optimizer.step(skip=skip)                                              # leaves everything untouched when skip != 0
+        if not sync:
+            if scheduler is not None:
+                scheduler.step()
+            return dict(loss=loss.detach(), loss_rgb=loss_rgb.detach(), loss_dep=loss_dep.detach(), loss_sem=loss_sem.detach(),
+                        n_rendering_samples=n_rendering_samples, skipped=skip)
+        skipped = bool(skip.item() > 0)                                        # one host round trip per iteration
     else:
-        optimizer.step()
-        if scheduler is not None:
-            scheduler.step()
+        skipped = bool(skip.item() > 0)
+        if skipped:
+            optimizer.zero_grad()
+        else:
+            optimizer.step()
+    if not skipped and scheduler is not None:
+        scheduler.step()
+    if isinstance(n_rendering_samples, int) and n_rendering_samples == 0:
+        return dict(loss=None, n_rendering_samples=0, skipped=True)
     return dict(loss=loss.detach(), loss_rgb=loss_rgb.detach(), loss_dep=loss_dep.detach(), loss_sem=loss_sem.detach(),
                 n_rendering_samples=n_rendering_samples, skipped=skipped)
 

@@ -77,7 +77,26 @@ def _free_space_poses(scene, n, seed):
     return out
 
 
-def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 21, lr=2e-3, seed=9, cache_dir="/tmp",
+PROTOCOL_VERSION = 3      # bump when the training protocol or anything it runs through changes what a given tag would produce
+
+
+def default_cache_dir() -> str:
+    """Per-user cache directory (MNF_CACHE_DIR, else $XDG_CACHE_HOME/mi355nerf, else ~/.cache/mi355nerf, else a per-uid
+    directory under the system temp dir), created with mode 0700."""
+    import tempfile
+    d = os.environ.get("MNF_CACHE_DIR")
+    if not d:
+        base = os.environ.get("XDG_CACHE_HOME") or (os.path.join(os.path.expanduser("~"), ".cache") if os.path.expanduser("~") not in ("", "/") else None)
+        d = os.path.join(base, "mi355nerf") if base else os.path.join(tempfile.gettempdir(), f"mi355nerf-{os.getuid()}")
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+    except OSError:
+        d = os.path.join(tempfile.gettempdir(), f"mi355nerf-{os.getuid()}")
+        os.makedirs(d, mode=0o700, exist_ok=True)
+    return d
+
+
+def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 21, lr=2e-3, seed=9, cache_dir=None,
                   n_poses=64, verbose=False, lr_final=2e-4):
     """-> (NGPRadianceField, OccGridEstimator, info dict), trained as described in the module docstring with
     `render.train_step` + `optim.FusedAdam`; the learning rate stays at `lr` for the first half and decays geometrically to
@@ -86,14 +105,26 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
     log2_hashmap_size)."""
     from .ngp import NGPRadianceField
     from .optim import FusedAdam
-    tag = f"{tuple(np.round(scene['aabb'], 3))}_{scene['neurons']}x{scene['layers']}_C{scene['C']}_T{scene['log2_hashmap_size']}_s{steps}_r{max_rays}_seed{seed}" + ("" if lr_final is None else f"_lrf{lr_final}")
+    from . import _lib as L
     import hashlib
+    # everything that decides what training produces is part of the tag, including the library build (kernels change between rounds)
+    try:
+        with open(L.lib_path(), "rb") as fh:
+            lib_id = hashlib.md5(fh.read()).hexdigest()[:12]
+    except OSError:
+        lib_id = "nolib"
+    tag = (f"v{PROTOCOL_VERSION}_{scene.get('name')}_{tuple(np.round(scene['aabb'], 3))}_{tuple(scene['res'])}_{scene['neurons']}x{scene['layers']}_C{scene['C']}"
+           f"_T{scene['log2_hashmap_size']}_s{steps}_r{max_rays}_t{target_samples}_p{n_poses}_lr{lr}_lrf{lr_final}_seed{seed}_lib{lib_id}")
+    cache_dir = default_cache_dir() if cache_dir is None else cache_dir
     path = os.path.join(cache_dir, "mnf_standin_" + hashlib.md5(tag.encode()).hexdigest()[:16] + ".pt")
     field = NGPRadianceField(aabb=torch.from_numpy(scene["aabb"]), neurons=scene["neurons"], layers=scene["layers"],
                              num_semantic_classes=scene["C"], log2_hashmap_size=scene["log2_hashmap_size"], seed=seed).to(device)
     est = NA.OccGridEstimator(torch.from_numpy(scene["aabb"]), resolution=scene["res"], levels=1).to(device)
     if os.path.exists(path):
-        ck = torch.load(path, map_location=device)
+        try:
+            ck = torch.load(path, map_location=device, weights_only=True)     # tensors and plain containers only: no code runs on load
+        except Exception:
+            ck = {}
         if ck.get("tag") == tag:
             field.load_state_dict(ck["model"])
             est.occs.copy_(ck["occs"]); est.binaries = ck["binaries"].to(device)
@@ -106,7 +137,7 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
     n_poses = len(poses)
     c2w = np.stack([RD.pose_to_c2w(p) for p in poses]).astype(np.float32)
     K = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
-    opt = FusedAdam(field.parameters(), lr=lr, eps=1e-15)
+    opt = FusedAdam(field.parameters(), lr=lr, eps=1e-15).bind_field(field)
     gen = torch.Generator().manual_seed(seed)
     n_rays, t0, losses, skipped, n_samp = 1024, time.perf_counter(), [], 0, 0
     bk = torch.zeros(3, device=device)
@@ -135,8 +166,12 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
     info = dict(steps=steps, seconds=time.perf_counter() - t0, loss_first=losses[0] if losses else None,
                 loss_last=losses[-1] if losses else None, skipped_steps=skipped, final_rays=n_rays, final_samples=n_samp,
                 occupied_cells=int(est.binaries.sum()), cells=int(est.binaries.numel()), cached=False)
+    info["saved"] = False
     try:
-        torch.save({"tag": tag, "model": field.state_dict(), "occs": est.occs, "binaries": est.binaries, "info": info}, path)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        torch.save({"tag": tag, "model": field.state_dict(), "occs": est.occs, "binaries": est.binaries, "info": info}, tmp)
+        os.replace(tmp, path)                                     # atomic: a reader never sees a half-written file
+        info["saved"] = True
     except OSError:
-        pass
+        pass                                                      # callers with several ranks broadcast the model instead (bench.py)
     return field.eval(), est.eval(), info

@@ -126,7 +126,16 @@ int mnf_composite_train_backward(const int64_t *chunk_starts, const int64_t *chu
 int mnf_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int32_t step, mnf_stream_t stream);
 
-/* Adds the number of NaN entries of `values` to *count (device int32): the gradient guard of pipeline.py:520-529. */
+/* The same step for a training loop that never synchronises with the host (scripts/pipeline.py:520-532 decided on the device):
+ * step_dev (device float, torch's `state["step"]`) is advanced and the update applied only when *skip_dev == 0 (skip_dev: device
+ * int32 or NULL; raised by mnf_count_nan for non-finite gradients and by mnf_train_step for a step without samples or beyond its
+ * bounds).  hyper_dev: 4 device floats of scratch.  half_out / half_from: optional fp16 mirror — parameters half_from.. are also
+ * written, rounded to fp16, to half_out[0..] (the field handle's hash table, mnf_field_table_mirror: no per-step conversion pass). */
+int mnf_adam_step_guarded(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float *step_dev, const int32_t *skip_dev, float *hyper_dev, void *half_out,
+                          int64_t half_from, mnf_stream_t stream);
+
+/* Adds the number of NaN / Inf entries of `values` to *count (device int32): the gradient guard of pipeline.py:520-529. */
 int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf_stream_t stream);
 
 /* `pack_info` (nerfacc/pack.py:10-38) for ray indices in any order: packed_info [n_rays,2] = (chunk start, chunk count).
@@ -232,6 +241,12 @@ int mnf_field_grid_meta_host(mnf_field_t f, float *scale_host, int32_t *res_host
  * hash table and MFMA-fragment-ordered fp16 weights held by the handle. */
 int mnf_field_set_params(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem,
                          mnf_stream_t stream);
+/* The handle's fp16 hash table as an optimizer mirror: device pointer to [entries][4] fp16; *first_param_host receives the index of
+ * the first table entry inside `mlp_base.params` (the base-MLP weights precede it, ngp.py:123-141).  An optimizer that writes the
+ * rounded new table values there (mnf_adam_step_guarded) calls mnf_field_refresh_weights afterwards instead of
+ * mnf_field_set_params: only the few-KB MLP fragments are rebuilt. */
+void *mnf_field_table_mirror(mnf_field_t f, int64_t *first_param_host);
+int mnf_field_refresh_weights(mnf_field_t f, const float *mlp_base, const float *mlp_head, const float *mlp_sem, mnf_stream_t stream);
 
 /* NGPRadianceField.forward (ngp.py:222-238): positions,directions [n,3] f32 ->
  * rgb [n,3], density [n,1], sem [n,C] f32 (any output may be NULL). */
@@ -327,24 +342,30 @@ int mnf_field_forward_train_samples(mnf_field_t f, const float *rays_o, const fl
  * occ_grid.py:80-238; then sem_rendering, utils.py:362-461), the loss 10 smooth_l1(rgb) + smooth_l1(depth) / 5 + CE(sem) / 2
  * (pipeline.py:506-511) and its backward to the three flat parameter-gradient vectors g_base / g_head / g_sem (overwritten).
  * Not included, as in the reference they belong to the caller: occupancy refresh (mnf_update_occupancy), NaN guard
- * (mnf_count_nan), optimizer (mnf_adam_step).  losses (device, 4 floats): total, rgb, depth, semantic terms (un-weighted means).
- * counts_host (HOST, 2 x int64): marched samples, surviving samples (= the reference's n_rendering_samples).
- * Sizes: the caller bounds the sample counts (max_marched, max_kept) and provides mnf_train_step_workspace_bytes(); if a
- * bound is exceeded the call fails with MNF_ERR_WORKSPACE after filling counts_host, so the caller can retry larger.
- * Stratified near planes: near + U[0,1) * render_step_size per ray from Philox4x32-10 (counter (ray, 0, 7, 0), key = seed).
- * Two stream synchronisations (the two counts size the launches that follow). */
+ * (mnf_count_nan), optimizer (mnf_adam_step / mnf_adam_step_guarded).  losses (device, 4 floats): total, rgb, depth, semantic
+ * terms (un-weighted means).
+ * NO stream synchronisation: the sample counts stay on the device.  counts_dev (DEVICE, 4 x int64): [0] marched samples, [1] surviving
+ * samples (= the reference's n_rendering_samples), [2] samples of the longest ray, [3] status bits: 1 marched > max_marched, 2 a ray
+ * longer than a scratch row (use the two-pass sampler), 4 surviving > max_kept, 8 a class id outside [0, C) (F.cross_entropy's device
+ * assert), 16 no sample survived (the reference `continue`s, pipeline.py:491).  skip_dev (DEVICE int32): set to 0, then raised for
+ * every status bit: with it non-zero the gradients are zero / must not be applied (mnf_adam_step_guarded reads it).  The caller
+ * bounds the sample counts (max_marched, max_kept), provides mnf_train_step_workspace_bytes(), reads counts_dev when it wants
+ * to and retries with larger bounds after bits 1 / 4.
+ * Stratified near planes: near + U[0,1) * render_step_size per ray from Philox4x32-10 (counter (ray, 0, 7, 0), key = seed). */
 typedef struct {
     float near_plane, far_plane, render_step_size, cone_angle, alpha_thre, early_stop_eps;   /* utils.py:63-76 / occ_grid.py:80-96 */
     float render_bkgd[3];
     float loss_scale;         /* fp16 activation-gradient scale of the backward (tcnn: 128) */
     int32_t stratified;       /* occ_grid.py:187-189 (radiance_field.training) */
     uint64_t seed;
+    const float *render_bkgd_dev;   /* optional: 3 device floats used instead of render_bkgd (pipeline.py:437 draws the colour on
+                                       the GPU: no host copy of it is needed) */
 } mnf_train_opts;
 int64_t mnf_train_step_workspace_bytes(mnf_field_t f, int32_t n_rays, int64_t max_marched, int64_t max_kept);
 int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
                    int32_t res_z, const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays,
                    const float *target_rgb, const float *target_depth, const int64_t *target_sem, const mnf_train_opts *opts,
-                   float *g_base, float *g_head, float *g_sem, float *losses, int64_t *counts_host, int64_t max_marched,
+                   float *g_base, float *g_head, float *g_sem, float *losses, int64_t *counts_dev, int32_t *skip_dev, int64_t max_marched,
                    int64_t max_kept, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
 
 /* ---------------------------------------------------------------- fused test-mode renderers */

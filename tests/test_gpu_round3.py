@@ -1,0 +1,276 @@
+"""Round-3 GPU tests: the train step that never waits for the host, the device-side skip decision and the optimizer's fp16
+table mirror; parity on TRAINED weights (the benchmarked workload's kind of scene); a multi-step training trajectory against
+the oracle (autograd + torch.optim.Adam + the reference's CyclicLR); ray-data-parallel training with an empty rank."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _train_batch(sc, pose, h, w, seed):
+    o, d = H.view_rays(sc, pose, h=h, w=w)
+    rng = np.random.default_rng(seed)
+    n = o.shape[0]
+    pix = torch.from_numpy(rng.random((n, 3)).astype(np.float32))
+    dep = torch.from_numpy(rng.uniform(0.5, 4.0, n).astype(np.float32))
+    lab = torch.from_numpy(rng.integers(0, sc["C"], n))
+    return o, d, pix, dep, lab
+
+
+# ------------------------------------------------------------------ async train step
+def test_train_step_without_host_sync_equals_synchronous_step():
+    """sync=False (no host round trip, device-side skip decision) and sync=True (one read-back at the end) are the same kernels
+    with the same arguments: same sample counts, same losses, same parameters after the optimizer (float atomics aside)."""
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene(log2_hashmap_size=15)
+    o, d, pix, dep, lab = (t.to(DEV) for t in _train_batch(sc, 3, 24, 24, 0))
+    bk = torch.tensor([0.2, 0.4, 0.6], device=DEV)
+    res = []
+    for sync in (True, False):
+        hip, est = H.hip_field(sc), H.hip_estimator(sc)
+        opt = FusedAdam(hip.parameters(), lr=1e-3, eps=1e-15).bind_field(hip)
+        outs = [RD.train_step(hip, est, opt, RD.Rays(o, d), pix, dep, lab, bk, step=s_, sync=sync, stratified=False, **H.RENDER_KW) for s_ in (1, 2, 3)]
+        if not sync:
+            assert all(isinstance(x["n_rendering_samples"], torch.Tensor) and isinstance(x["skipped"], torch.Tensor) for x in outs)
+        res.append(([int(x["n_rendering_samples"]) for x in outs], [float(x["loss"]) for x in outs], [int(x["skipped"]) for x in outs],
+                    [p.detach().clone() for p in hip.parameters()], float(opt.state[hip.mlp_head.params]["step"])))
+    (n_a, l_a, s_a, p_a, st_a), (n_b, l_b, s_b, p_b, st_b) = res
+    assert n_a[0] == n_b[0] and n_a[0] > 3000 and s_a == s_b == [0, 0, 0] and st_a == st_b == 3.0
+    assert all(abs(x - y) <= max(3, 2e-3 * x) for x, y in zip(n_a, n_b))          # later steps: parameters differ by atomics order
+    np.testing.assert_allclose(l_a, l_b, rtol=2e-3)
+    for a, b in zip(p_a, p_b):
+        if a.numel():
+            assert torch.nn.functional.cosine_similarity(a, b, dim=0) > 0.9999
+
+
+def test_fused_adam_skip_flag_and_table_mirror():
+    """`FusedAdam.step(skip=flag)`: a raised device flag leaves parameters, moments and the step count untouched (pipeline.py:520-529
+    decided on the device); `bind_field`: the hash table the kernels read after the step is the rounded new table (no conversion
+    pass), bit-identical to a handle that re-loads the parameters."""
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene(log2_hashmap_size=14)
+    a, b = H.hip_field(sc), H.hip_field(sc)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(5000, 3, generator=g) * 2 - 1).to(DEV) * torch.tensor([8.0, 1.5, 8.0], device=DEV) + torch.tensor([-9.0, 1.5, -9.0], device=DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(5000, 3, generator=g), dim=-1).to(DEV)
+    oa, ob = FusedAdam(a.parameters(), lr=1e-2, eps=1e-15).bind_field(a), FusedAdam(b.parameters(), lr=1e-2, eps=1e-15)
+    a(x, dirs); b(x, dirs)                                        # both handles hold the initial parameters
+    for step in range(3):
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            if pa.numel():
+                gr = torch.randn(pa.shape, generator=g).to(DEV) * 1e-3
+                pa.grad, pb.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        with torch.no_grad():
+            ra, rb = a(x, dirs), b(x, dirs)                       # a: mirrored table + refreshed fragments; b: full reload
+        for u, v in zip(ra, rb):
+            assert torch.equal(u, v)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.equal(pa, pb)
+    before = [p.detach().clone() for p in a.parameters()]
+    m_before = oa.state[a.mlp_base.params]["exp_avg"].clone()
+    skip = torch.ones((), dtype=torch.int32, device=DEV)
+    oa.step(skip=skip)
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), before))
+    assert torch.equal(oa.state[a.mlp_base.params]["exp_avg"], m_before) and float(oa.state[a.mlp_base.params]["step"]) == 3.0
+    oa.step(skip=torch.zeros((), dtype=torch.int32, device=DEV))
+    base_before = next(q for p, q in zip(a.parameters(), before) if p is a.mlp_base.params)
+    assert float(oa.state[a.mlp_base.params]["step"]) == 4.0 and not torch.equal(a.mlp_base.params.detach(), base_before)
+
+
+def test_train_step_flags_bad_labels_and_recovers_from_small_bounds():
+    """a class id outside [0, C) must not be read past the logits row: the step is flagged on the device (status bit
+    8, skip raised) and surfaces as an error.  Sample bounds that are too small end the step on the device with zero gradients;
+    the synchronous path repeats it with larger bounds, the asynchronous one skips it and grows the bounds for the next call."""
+    from apnrf_amd import _lib as L
+    from apnrf_amd import render as RD
+    sc = H.make_scene(log2_hashmap_size=14)
+    hip, est = H.hip_field(sc), H.hip_estimator(sc)
+    hip.train()
+    o, d, pix, dep, lab = (t.to(DEV) for t in _train_batch(sc, 2, 16, 16, 1))
+    bad = lab.clone(); bad[7] = 29; bad[100] = -100
+    with pytest.raises(L.MnfError, match="class id"):
+        RD.fused_forward_backward(hip, est, RD.Rays(o, d), pix, dep, bad, None, stratified=False, **H.RENDER_KW)
+    out = RD.fused_forward_backward(hip, est, RD.Rays(o, d), pix, dep, lab, None, stratified=False, **H.RENDER_KW)
+    n_ok, g_ok = out["n_rendering_samples"], hip.mlp_head.params.grad.clone()
+    assert n_ok > 1000 and int(out["skip"]) == 0
+    key = (id(hip), o.shape[0])
+    RD._TRAIN_STATE[key].update(cap_m=2048, cap_k=1024)           # far too small
+    out = RD.fused_forward_backward(hip, est, RD.Rays(o, d), pix, dep, lab, None, stratified=False, **H.RENDER_KW)
+    assert out["n_rendering_samples"] == n_ok and RD._TRAIN_STATE[key]["cap_k"] >= n_ok       # repeated with larger bounds
+    np.testing.assert_allclose(hip.mlp_head.params.grad.cpu().numpy(), g_ok.cpu().numpy(), rtol=2e-2, atol=1e-6)
+    RD._TRAIN_STATE[key].update(cap_m=2048, cap_k=1024)
+    lazy = RD.fused_forward_backward(hip, est, RD.Rays(o, d), pix, dep, lab, None, stratified=False, sync=False, **H.RENDER_KW)
+    assert int(lazy["skip"]) > 0 and int(lazy["counts"][3]) & 1 and float(hip.mlp_head.params.grad.abs().max()) == 0.0
+    for _ in range(3):                                            # marched bound first, then (if still too small) the surviving bound
+        torch.cuda.synchronize()
+        lazy = RD.fused_forward_backward(hip, est, RD.Rays(o, d), pix, dep, lab, None, stratified=False, sync=False, **H.RENDER_KW)
+        if int(lazy["skip"]) == 0:
+            break
+    assert int(lazy["skip"]) == 0 and int(lazy["n_rendering_samples"]) == n_ok
+    # rays that miss the grid: no sample, skip raised with status bit 16, zero gradients (pipeline.py:491 `continue`)
+    up = torch.zeros_like(d); up[:, 1] = 1.0
+    far_o = o + torch.tensor([0.0, 100.0, 0.0], device=DEV)
+    miss = RD.fused_forward_backward(hip, est, RD.Rays(far_o, up), pix, dep, lab, None, stratified=False, **H.RENDER_KW)
+    assert miss["n_rendering_samples"] == 0 and int(miss["skip"]) > 0 and int(miss["counts"][3]) & 16
+
+
+# ------------------------------------------------------------------ parity on trained weights
+@pytest.fixture(scope="module")
+def trained():
+    """A small trained stand-in (300 iterations of the product's own train step on the analytic rooms target): sharp densities,
+    saturated opacities, an occupancy grid that came out of update_every_n_steps — what the benchmarked scenes look like."""
+    from apnrf_amd import standin as SI
+    sc = H.make_scene("102344250", n_poses=40)
+    field, est, info = SI.train_standin(sc, DEV, steps=300, seed=21)
+    sc = dict(sc)
+    sc["params"] = {"mlp_base": field.mlp_base.params.detach().cpu().numpy(), "mlp_head": field.mlp_head.params.detach().cpu().numpy(),
+                    "mlp_sem": field.mlp_sem.params.detach().cpu().numpy()}
+    sc["occ"] = est.binaries.cpu().numpy()
+    return sc, field, est, info
+
+
+def _render_errors(out, ref, prob):
+    errs = {}
+    for k in ("rgb", "acc", "depth", "sem") + (("rgb_var", "depth_var") if prob else ()):
+        a, b = out[k].cpu().numpy().reshape(ref[k].shape[0], -1), ref[k].numpy().reshape(ref[k].shape[0], -1)
+        errs[k] = np.abs(a - b).max(axis=1)
+    return errs
+
+
+@pytest.mark.parametrize("prob", [False, True])
+def test_render_trained_weights_matches_oracle(trained, prob):
+    """utils.py:555-779 / :782-1032 on TRAINED weights: north-star tolerance 1e-3 abs on every output; rays whose
+    alpha-threshold / termination decision flips on an fp32 tie get the tie budget (<= 2 rays up to 5e-2)."""
+    from apnrf_amd import render as RD
+    from oracle import render as R
+    sc, field, est, info = trained
+    orc = H.oracle_field(sc)
+    bk = torch.tensor([0.1, 0.3, 0.6])
+    tie_rays = 0
+    for pose in (0, 13):
+        o, d = H.view_rays(sc, pose, h=24, w=24)
+        fn = R.render_prob_test if prob else R.render_test
+        ref = fn(1024, orc, sc["occ"], sc["aabb"][None], o, d, render_bkgd=bk, **H.RENDER_KW)
+        out = RD.render_views(field, est, o.to(DEV), d.to(DEV), o.shape[0], 1024, render_bkgd=bk, probabilistic=prob, **H.RENDER_KW)
+        errs = _render_errors(out, ref, prob)
+        worst = np.max(np.stack([errs[k] / (1.0 if k != "depth" else 1.0) for k in errs]), axis=0)
+        tie = worst > 1e-3
+        tie_rays += int(tie.sum())
+        assert worst[~tie].max() <= 1e-3 and (worst[tie] <= 5e-2).all(), {k: float(v.max()) for k, v in errs.items()}
+        tot = int(out["total"][0])
+        assert abs(tot - ref["total_samples"]) <= max(4, 2e-3 * ref["total_samples"]), (tot, ref["total_samples"])
+        mse = float(((out["rgb"].cpu() - ref["rgb"]) ** 2).mean())
+        assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 50.0
+    assert tie_rays <= 2, tie_rays
+
+
+def test_train_gradients_trained_weights_match_oracle(trained):
+    """One train-render + loss + backward on TRAINED weights against oracle autograd (the round-2 checks ran on random-init weights)."""
+    import torch.nn.functional as F
+    from apnrf_amd import render as RD
+    from oracle import render as R
+    sc, field, est, info = trained
+    orc = H.oracle_field(sc, requires_grad=True)
+    o, d, pix, dep, lab = _train_batch(sc, 5, 12, 12, 4)
+    bk = torch.tensor([0.5, 0.2, 0.9])
+    field.train()
+    out = RD.fused_forward_backward(field, est, RD.Rays(o.to(DEV), d.to(DEV)), pix.to(DEV), dep.to(DEV), lab.to(DEV), bk, stratified=False, **H.RENDER_KW)
+    field.eval()
+    ref = R.render_train(orc, sc["occ"], sc["aabb"][None], float(est.occs.mean().item()), o, d, torch.full((o.shape[0],), 0.1),
+                         render_bkgd=bk, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01)
+    r_loss = F.smooth_l1_loss(ref[0], pix) * 10 + F.smooth_l1_loss(ref[2], dep.unsqueeze(1)) / 5 + F.cross_entropy(ref[3], lab) / 2
+    r_loss.backward()
+    assert abs(out["n_rendering_samples"] - ref[4]) <= max(3, 2e-3 * ref[4]) and ref[4] > 500
+    np.testing.assert_allclose(float(out["loss"]), r_loss.item(), rtol=5e-4)
+    n_mlp = sum(o_ * i_ for o_, i_ in orc.shapes["base"])
+    for name, g, r in [("base mlp", field.mlp_base.params.grad[:n_mlp], orc.p_base.grad[:n_mlp]), ("hash table", field.mlp_base.params.grad[n_mlp:], orc.p_base.grad[n_mlp:]),
+                       ("rgb head", field.mlp_head.params.grad, orc.p_head.grad), ("sem head", field.mlp_sem.params.grad, orc.p_sem.grad)]:
+        g, r = g.detach().cpu().double(), r.double()
+        rel = float((g - r).norm() / r.norm().clamp_min(1e-30))
+        cos = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp_min(1e-30))
+        assert rel < 5e-2 and cos > 0.998, (name, rel, cos)
+
+
+# ------------------------------------------------------------------ multi-step training trajectory vs the oracle
+def test_training_trajectory_matches_oracle():
+    """VERDICT r02 missing 5: the reference trains thousands of steps per phase (pipeline.py:398-535).  Same initial parameters, the
+    same 30 ray batches, no jitter, no occupancy refresh inside the window: the HIP train step (fused forward / loss / backward,
+    device-side guard, FusedAdam with the fp16 table mirror) against the oracle (autograd through the fp16-rounded forward,
+    torch.optim.Adam), both behind the reference's CyclicLR (pipeline.py:183-193)."""
+    import torch.nn.functional as F
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    from oracle import render as R
+    sc = H.make_scene(log2_hashmap_size=15)
+    hip, orc = H.hip_field(sc), H.oracle_field(sc, requires_grad=True)
+    est = H.hip_estimator(sc)
+    occs_mean = float(est.occs.mean().item())
+    n_steps = 30
+    sched_kw = dict(base_lr=1e-4, max_lr=1e-3, step_size_up=int(n_steps / 4), mode="exp_range", gamma=1.0, cycle_momentum=False)
+    opt_h = FusedAdam(hip.parameters(), lr=1e-3, eps=1e-15).bind_field(hip)
+    opt_o = torch.optim.Adam([orc.p_base, orc.p_head, orc.p_sem], lr=1e-3, eps=1e-15)
+    sch_h = torch.optim.lr_scheduler.ChainedScheduler([torch.optim.lr_scheduler.CyclicLR(opt_h, **sched_kw)])
+    sch_o = torch.optim.lr_scheduler.ChainedScheduler([torch.optim.lr_scheduler.CyclicLR(opt_o, **sched_kw)])
+    bk = torch.tensor([0.3, 0.3, 0.3])
+    steps = [s for s in range(1, 40) if s % 16][:n_steps]          # no occupancy refresh (random cell draws) inside the window
+    loss_h, loss_o, n_h, n_o = [], [], [], []
+    for k, step in enumerate(steps):
+        o, d, pix, dep, lab = _train_batch(sc, k % 6, 10, 10, 100 + k % 6)      # six batches with fixed targets, visited five times each
+        out = RD.train_step(hip, est, opt_h, RD.Rays(o.to(DEV), d.to(DEV)), pix.to(DEV), dep.to(DEV), lab.to(DEV), bk.to(DEV), step=step,
+                            scheduler=sch_h, stratified=False, **H.RENDER_KW)
+        assert not out["skipped"]
+        loss_h.append(float(out["loss"])); n_h.append(out["n_rendering_samples"])
+        ref = R.render_train(orc, sc["occ"], sc["aabb"][None], occs_mean, o, d, torch.full((o.shape[0],), 0.1), render_bkgd=bk,
+                             render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01)
+        r_loss = F.smooth_l1_loss(ref[0], pix) * 10 + F.smooth_l1_loss(ref[2], dep.unsqueeze(1)) / 5 + F.cross_entropy(ref[3], lab) / 2
+        opt_o.zero_grad(); r_loss.backward(); opt_o.step(); sch_o.step()
+        orc._derive()
+        loss_o.append(r_loss.item()); n_o.append(ref[4])
+        assert abs(opt_h.param_groups[0]["lr"] - opt_o.param_groups[0]["lr"]) < 1e-12
+    loss_h, loss_o = np.array(loss_h), np.array(loss_o)
+    rel = np.abs(loss_h - loss_o) / loss_o
+    print("trajectory: loss first/last", loss_o[0], loss_o[-1], "max rel diff", rel.max(), "samples", n_h[-1], n_o[-1])
+    assert loss_o[-6:].mean() < 0.9 * loss_o[:6].mean(), (loss_o[:6], loss_o[-6:])       # it does train (same six batches, fifth visit vs first)
+    assert rel.max() < 1e-3, rel
+    assert all(abs(a - b) <= max(3, 3e-3 * b) for a, b in zip(n_h, n_o))
+    n_mlp = sum(o_ * i_ for o_, i_ in orc.shapes["base"])
+    init = sc["params"]
+    for name, p, q, p0 in [("base mlp", hip.mlp_base.params[:n_mlp], orc.p_base[:n_mlp], init["mlp_base"][:n_mlp]),
+                           ("hash table", hip.mlp_base.params[n_mlp:], orc.p_base[n_mlp:], init["mlp_base"][n_mlp:]),
+                           ("rgb head", hip.mlp_head.params, orc.p_head, init["mlp_head"]), ("sem head", hip.mlp_sem.params, orc.p_sem, init["mlp_sem"])]:
+        p, q, p0 = p.detach().cpu().double(), q.detach().double(), torch.from_numpy(p0).double()
+        cos = float(torch.dot(p, q) / (p.norm() * q.norm()))
+        dp, dq = p - p0, q - p0
+        cos_d = float(torch.dot(dp, dq) / (dp.norm() * dq.norm()).clamp_min(1e-30))
+        print(f"trajectory: {name}: parameter cosine {cos:.6f}, update cosine {cos_d:.4f}")
+        assert cos > 0.999, (name, cos)
+        assert cos_d > 0.9, (name, cos_d)
+
+
+# ------------------------------------------------------------------ ray-data-parallel step with an empty rank
+def test_data_parallel_step_with_an_empty_rank_does_not_hang():
+    """Two ranks on this GPU (gloo): rank 1's rays miss the grid.  Both ranks must reach the gradient all-reduce, take the same
+    skip decision and finish (round 2 returned early on the empty rank and left the other one inside the collective)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "dp_empty_rank.py"), str(r), "2"], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("data-parallel step hung")
+    assert all(p.returncode == 0 for p in procs) and all("DP_EMPTY_RANK_OK" in o for o in outs), "\n".join(o[-1500:] for o in outs)
