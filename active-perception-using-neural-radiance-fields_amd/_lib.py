@@ -25,7 +25,7 @@ class FieldConfig(ctypes.Structure):
 class TrainOpts(ctypes.Structure):
     _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float), ("cone_angle", c_float),
                 ("alpha_thre", c_float), ("early_stop_eps", c_float), ("render_bkgd", c_float * 3), ("loss_scale", c_float),
-                ("stratified", c_int32), ("seed", c_uint64), ("render_bkgd_dev", c_void_p)]
+                ("stratified", c_int32), ("seed", c_uint64), ("render_bkgd_dev", c_void_p), ("deterministic", c_int32)]
 
 
 class VanillaConfig(ctypes.Structure):
@@ -38,6 +38,12 @@ class RenderOpts(ctypes.Structure):
                 ("cone_angle", c_float), ("alpha_thre", c_float), ("early_stop_eps", c_float),
                 ("render_bkgd", c_float * 3), ("max_samples", c_int32), ("probabilistic", c_int32),
                 ("rays_per_view", c_int32), ("sync_every", c_int32), ("view_order", c_void_p), ("bitgrid", c_void_p)]
+
+
+class RenderJob(ctypes.Structure):
+    _fields_ = [("field", c_void_p), ("binaries", c_void_p), ("bitgrid", c_void_p), ("rays_o", c_void_p), ("rays_d", c_void_p),
+                ("n_rays", c_int64), ("rgb", c_void_p), ("acc", c_void_p), ("depth", c_void_p), ("sem", c_void_p), ("rgb_var", c_void_p),
+                ("depth_var", c_void_p), ("total_samples", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/mi355nerf.h
@@ -125,6 +131,7 @@ SIGNATURES = {
     "mnf_render_test": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p, c_void_p,
                                   c_int64, POINTER(RenderOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_render_jobs": (c_int32, [POINTER(RenderJob), c_int32, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(RenderOpts), c_void_p]),
     "mnf_planner_map": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mnf_profile_begin": (c_int32, []),
     "mnf_profile_end": (c_int32, [POINTER(c_double), POINTER(c_int64)]),
@@ -187,6 +194,11 @@ def launch(fn, *args):
     a model on cuda:1 runs on GPU 1 whatever the caller's current device is (the reference's `DEVICE_GUARD`,
     utils_cuda.cuh:23-24).  Appends the stream argument and raises MnfError on a non-zero return code."""
     dev = next((a.device for a in args if isinstance(a, DevPtr) and a.device is not None), None)
+    if dev is None:      # an anchor object (`.p` = DevPtr) names the GPU of a call whose device pointers sit inside a host array
+        anchor = next((a for a in args if hasattr(a, "p") and isinstance(getattr(a, "p"), DevPtr)), None)
+        if anchor is not None:
+            dev = anchor.p.device
+            args = tuple(a for a in args if a is not anchor)
     if dev is None:
         check(fn(*args, stream()))
         return

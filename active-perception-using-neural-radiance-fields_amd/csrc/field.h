@@ -84,6 +84,7 @@ struct FieldIO {
     // outputs: user layout (modes 0,1) ...
     float *rgb, *density, *sem;
     float *positions_out;                    // mode 1, optional: the sample positions [n,3] the kernel formed (the backward's scatter reads them)
+    float *xn_out;                           // mode 1, optional: the aabb-normalised positions [n,3] (ngp.py:177-178) instead: the scatter's own input
     // ... or, in mode 2, composites straight into the renderer's per-ray accumulators
     FusedRender fr;
 };
@@ -103,7 +104,7 @@ int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_
 int forward_train(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream);
 int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb, const float *d_density,
              const float *d_sem, const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale,
-             float *g_base, float *g_head, float *g_sem, bool zero_grads, hipStream_t stream);
+             float *g_base, float *g_head, float *g_sem, bool zero_grads, bool positions_normalized, bool deterministic, hipStream_t stream);
 
 #define MNF_DECLARE_DT_IMPL(ns)                                                                                                      \
     namespace ns {                                                                                                                   \
@@ -116,7 +117,7 @@ int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_
     int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb,                  \
                       const float *d_density, const float *d_sem, const float *rgb, const float *density, void *workspace,          \
                       int64_t workspace_bytes, float loss_scale, float *g_base, float *g_head, float *g_sem, bool zero_grads,       \
-                      hipStream_t stream);                                                                                          \
+                      bool positions_normalized, bool deterministic, hipStream_t stream);                                           \
     }
 MNF_DECLARE_DT_IMPL(f16)
 MNF_DECLARE_DT_IMPL(bf16)

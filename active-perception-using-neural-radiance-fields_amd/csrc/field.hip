@@ -128,6 +128,10 @@ __device__ __forceinline__ void fetch_sample(const KernelArgs &args, const ColDa
         xn[d] = (pos[d] - args.aabb[d]) / (args.aabb[3 + d] - args.aabb[d]);   // ngp.py:177-178
         selector = selector && (xn[d] > 0.0f) && (xn[d] < 1.0f);               // ngp.py:179
     }
+    if (MODE == 1 && args.io.xn_out && valid) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) args.io.xn_out[3 * col + d] = xn[d];
+    }
     if (!valid) { xn[0] = 0.5f; xn[1] = 0.5f; xn[2] = 0.5f; }
 }
 

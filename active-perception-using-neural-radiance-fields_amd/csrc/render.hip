@@ -12,6 +12,7 @@
 // same launches, each with its own round schedule.
 //
 // Build with -ffp-contract=off (march_dev.h).
+#include <chrono>
 #include <vector>
 
 #include "field.h"
@@ -46,11 +47,6 @@ static bool split_field() {
     return on;
 }
 
-// Pipelined two-kernel form of a render round's field evaluation (experiment, MNF_FIELD_PIPE=<chunks>[,<rounds>[,<mlp waves>[,<gather
-// blocks>]]]): the round's tiles are cut into chunks; the gather kernel of chunk i+1 (few registers, many waves) runs on one stream
-// beside the MLP + compositing kernel of chunk i (4 of its 8 waves active, so that both fit a CU) on another.  This is the form
-// role specialisation can take on gfx950, where all waves of ONE kernel share a register allocation.
-struct PipeCfg { int chunks = 0, rounds = 24, mlp_waves = 4, gather_grid = 768; };
 static hipEvent_t *log_events() {
     static hipEvent_t ev[4];
     static bool made = false;
@@ -58,28 +54,6 @@ static hipEvent_t *log_events() {
     return ev;
 }
 static bool round_log() { static const bool on = diag_env("MNF_ROUND_LOG") != nullptr; return on; }
-
-static const PipeCfg &pipe_cfg() {
-    static PipeCfg c = [] {
-        PipeCfg p;
-        if (const char *e = diag_env("MNF_FIELD_PIPE")) sscanf(e, "%d,%d,%d,%d", &p.chunks, &p.rounds, &p.mlp_waves, &p.gather_grid);
-        return p;
-    }();
-    return c;
-}
-struct PipeRes { hipStream_t sg = nullptr, sm = nullptr; hipEvent_t e_main = nullptr, e_done = nullptr; std::vector<hipEvent_t> eg; };
-static PipeRes &pipe_res() {
-    static thread_local PipeRes r;
-    if (!r.sg) {
-        (void)hipStreamCreateWithFlags(&r.sg, hipStreamNonBlocking);
-        (void)hipStreamCreateWithFlags(&r.sm, hipStreamNonBlocking);
-        (void)hipEventCreateWithFlags(&r.e_main, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&r.e_done, hipEventDisableTiming);
-        r.eg.resize(16);
-        for (auto &e : r.eg) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    }
-    return r;
-}
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -115,7 +89,7 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     p = take(col_cap * 4); if (ws) ws->col_ts = (float *)p;
     p = take(col_cap * 4); if (ws) ws->col_te = (float *)p;
     p = take(col_cap / 64 * 4); if (ws) ws->tile_hdr = (int32_t *)p;
-    if (split_field() || pipe_cfg().chunks > 0) { p = take((col_cap / 64 + 1) * 8192); if (ws) ws->enc = p; }   // two-launch paths: 128 B per column
+    if (split_field()) { p = take((col_cap / 64 + 1) * 8192); if (ws) ws->enc = p; }   // two-launch path: 128 B per column
     else if (ws) ws->enc = nullptr;
     if (ws) ws->col_cap = col_cap;
     return (int64_t)off;
@@ -432,15 +406,65 @@ extern "C" int64_t mnf_render_workspace_bytes(int64_t n_rays, int32_t rays_per_v
     return carve(nullptr, nullptr, n_rays, rays_per_view);
 }
 
-extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32_t res_y, int32_t res_z,
-                               const float *aabb_host, const float *rays_o, const float *rays_d, int64_t n_rays,
-                               const mnf_render_opts *opts,
-                               float *rgb, float *acc, float *depth, float *sem, float *rgb_var, float *depth_var,
-                               int64_t *total_samples, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
+// ------------------------------------------------------------------ render jobs
+// One job = one mnf_render_test call (a batch of views of one field).  Several independent jobs (the members of an ensemble,
+// groups of views of one call) advance side by side on separate streams: every job is a chain prep -> march -> field per round,
+// and while one job's short kernels (prep, march, the tail of a field launch) leave compute units idle the other jobs' launches
+// fill them.  A view's result does not depend on which job it is in (its round schedule and its tiles are its own).
+// The host enqueues `sync_every` rounds per job at a time and learns one block LATE whether a job has finished (the flag word is
+// copied to pinned memory behind the first prep of a block and waited for after the block is enqueued): the queues never run dry,
+// at the price of at most one block of empty rounds per job.
+namespace mnf {
+namespace {
+
+struct JobRes {          // per-thread pool: pinned flag words, events, side streams
+    int32_t *flags = nullptr;
+    hipEvent_t ev_flags = nullptr, ev_join = nullptr;
+    hipStream_t side = nullptr;
+};
+struct JobPool {
+    std::vector<JobRes> res;
+    hipEvent_t ev_fork = nullptr;
+    int ensure(size_t n) {
+        if (!ev_fork) MNF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        while (res.size() < n) {
+            JobRes r;
+            MNF_HIP(hipHostMalloc((void **)&r.flags, 64, hipHostMallocDefault));
+            MNF_HIP(hipEventCreateWithFlags(&r.ev_flags, hipEventDisableTiming));
+            MNF_HIP(hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming));
+            MNF_HIP(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
+            res.push_back(r);
+        }
+        return MNF_OK;
+    }
+};
+JobPool &job_pool() { static thread_local JobPool p; return p; }
+
+struct RenderJob {
+    mnf_field_t f;
+    const uint8_t *binaries;
+    const float *rays_o, *rays_d;
+    int64_t n_rays;
+    mnf_render_opts opts;
+    RenderWs ws;
+    RenderOut out;
+    FieldIO io;
+    hipStream_t s;
+    JobRes *res;
+    I3 grid;
+    float ab[6];
+    int n_words, max_rounds, round;
+    bool lds_grid, done, flags_pending;
+    int32_t n_views, bpv, min_samples, C;
+};
+
+int job_begin(RenderJob &j, mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32_t res_y, int32_t res_z, const float *aabb_host,
+              const float *rays_o, const float *rays_d, int64_t n_rays, const mnf_render_opts *opts, float *rgb, float *acc, float *depth,
+              float *sem, float *rgb_var, float *depth_var, int64_t *total_samples, void *workspace, int64_t workspace_bytes, hipStream_t s,
+              JobRes *res) {
     MNF_REQUIRE(f && opts && aabb_host, "render_test: null argument");
     MNF_REQUIRE(f->params_loaded, "render_test: field parameters not loaded");
-    MNF_REQUIRE(n_rays >= 0, "render_test: negative n_rays");
-    if (n_rays == 0) return MNF_OK;
+    MNF_REQUIRE(n_rays > 0, "render_test: a job needs rays");
     MNF_REQUIRE(opts->rays_per_view > 0 && n_rays % opts->rays_per_view == 0,
                 "render_test: n_rays (%lld) must be a multiple of rays_per_view (%d)", (long long)n_rays, opts->rays_per_view);
     MNF_REQUIRE(n_rays <= (int64_t)500 * 1000 * 1000, "render_test: too many rays for 32-bit column indices");
@@ -452,123 +476,207 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
         set_error("render_test: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)need);
         return MNF_ERR_WORKSPACE;
     }
-    RenderWs ws;
-    carve(&ws, (char *)workspace, n_rays, opts->rays_per_view);
-    RenderOut out = {rgb, acc, depth, sem, opts->probabilistic ? rgb_var : nullptr, opts->probabilistic ? depth_var : nullptr, total_samples};
-    hipStream_t s = as_stream(stream);
-    const int32_t n_views = (int32_t)(n_rays / opts->rays_per_view);
-    const int32_t C = f->cfg.num_semantic_classes;
-    const int ray_blocks = (int)ceil_div(n_rays > n_views ? n_rays : n_views, kRayThreads);
-    const float *ab = aabb_host;
-    const I3 res = {res_x, res_y, res_z};
-    int32_t min_samples = opts->cone_angle == 0.f ? 1 : 4;                            // utils.py:645
-    if (const char *e = diag_env("MNF_MIN_SAMPLES")) min_samples = atoi(e);   // diagnostic only (locality experiments): NOT the reference's schedule
+    j.f = f; j.binaries = binaries; j.rays_o = rays_o; j.rays_d = rays_d; j.n_rays = n_rays; j.opts = *opts; j.s = s; j.res = res;
+    carve(&j.ws, (char *)workspace, n_rays, opts->rays_per_view);
+    j.out = {rgb, acc, depth, sem, opts->probabilistic ? rgb_var : nullptr, opts->probabilistic ? depth_var : nullptr, total_samples};
+    j.n_views = (int32_t)(n_rays / opts->rays_per_view);
+    j.C = f->cfg.num_semantic_classes;
+    const int ray_blocks = (int)ceil_div(n_rays > j.n_views ? n_rays : j.n_views, kRayThreads);
+    for (int k = 0; k < 6; ++k) j.ab[k] = aabb_host[k];
+    const float *ab = j.ab;
+    j.grid = {res_x, res_y, res_z};
+    j.min_samples = opts->cone_angle == 0.f ? 1 : 4;                                  // utils.py:645
+    if (const char *e = diag_env("MNF_MIN_SAMPLES")) j.min_samples = atoi(e);   // diagnostic only (locality experiments): NOT the reference's schedule
     const float opc_thre = 1.0f - opts->early_stop_eps;                                // utils.py:664
-
     const int64_t cells = (int64_t)res_x * res_y * res_z;
-    const int n_words = (int)ceil_div(cells, 32);
-    const bool lds_grid = n_words <= kMaxGridWords;
-    if (lds_grid) {
-        if (opts->bitgrid) ws.bitgrid = const_cast<uint32_t *>(opts->bitgrid);   // the estimator's own packed grid: nothing to build
-        else hipLaunchKernelGGL(pack_grid_kernel, dim3((int)ceil_div(n_words, 256)), dim3(256), 0, s, binaries, cells, ws.bitgrid, n_words);
+    j.n_words = (int)ceil_div(cells, 32);
+    j.lds_grid = j.n_words <= kMaxGridWords;
+    if (j.lds_grid) {
+        if (opts->bitgrid) j.ws.bitgrid = const_cast<uint32_t *>(opts->bitgrid);   // the estimator's own packed grid: nothing to build
+        else hipLaunchKernelGGL(pack_grid_kernel, dim3((int)ceil_div(j.n_words, 256)), dim3(256), 0, s, binaries, cells, j.ws.bitgrid, j.n_words);
     }
-    MNF_HIP(hipMemsetAsync(sem, 0, (size_t)n_rays * C * sizeof(float), s));   // [R,C] accumulators: one streaming fill
-    hipLaunchKernelGGL(init_kernel, dim3(ray_blocks), dim3(kRayThreads), 0, s, n_rays, opts->rays_per_view, C, rays_o, rays_d,
-                       ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], opts->near_plane, ws, out);
+    MNF_HIP(hipMemsetAsync(sem, 0, (size_t)n_rays * j.C * sizeof(float), s));   // [R,C] accumulators: one streaming fill
+    hipLaunchKernelGGL(init_kernel, dim3(ray_blocks), dim3(kRayThreads), 0, s, n_rays, opts->rays_per_view, j.C, rays_o, rays_d,
+                       ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], opts->near_plane, j.ws, j.out);
     int rc = launch_status("init_kernel");
     if (rc) return rc;
-
     FieldIO io = {};
-    io.mode = 2; io.rays_o = rays_o; io.rays_d = rays_d; io.col_ray = ws.col_ray; io.t_starts = ws.col_ts; io.t_ends = ws.col_te;
-    io.n_dev = ws.n_cols; io.n_cap = ws.col_cap;
-    io.enc = split_field() ? ws.enc : nullptr;   // MNF_FIELD_SPLIT (diagnostic: gather and MLP as two launches on one stream)
-    io.fr.tile_hdr = ws.tile_hdr; io.fr.alive = ws.alive; io.fr.alive_count = ws.alive_count;
-    io.fr.n_samples = ws.n_samples; io.fr.rgb = rgb; io.fr.acc = acc; io.fr.depth = depth; io.fr.sem = sem;
-    io.fr.rgb_var = out.rgb_var; io.fr.depth_var = out.depth_var;
+    io.mode = 2; io.rays_o = rays_o; io.rays_d = rays_d; io.col_ray = j.ws.col_ray; io.t_starts = j.ws.col_ts; io.t_ends = j.ws.col_te;
+    io.n_dev = j.ws.n_cols; io.n_cap = j.ws.col_cap;
+    io.enc = split_field() ? j.ws.enc : nullptr;   // MNF_FIELD_SPLIT (diagnostic: gather and MLP as two launches on one stream)
+    io.fr.tile_hdr = j.ws.tile_hdr; io.fr.alive = j.ws.alive; io.fr.alive_count = j.ws.alive_count;
+    io.fr.n_samples = j.ws.n_samples; io.fr.rgb = rgb; io.fr.acc = acc; io.fr.depth = depth; io.fr.sem = sem;
+    io.fr.rgb_var = j.out.rgb_var; io.fr.depth_var = j.out.depth_var;
     io.fr.totals = reinterpret_cast<unsigned long long *>(total_samples);
     io.fr.rays_per_view = opts->rays_per_view; io.fr.probabilistic = opts->probabilistic;
     io.fr.general_only = diag_env("MNF_COMPOSITE_GENERAL") != nullptr;   // tests compare the two compositing paths with it
     io.fr.alpha_thre = opts->alpha_thre; io.fr.opc_thre = opc_thre;
+    j.io = io;
+    j.max_rounds = (int)ceil_div(opts->max_samples, j.min_samples);
+    j.bpv = (int32_t)march_blocks_per_view(opts->rays_per_view);
+    j.round = 0; j.done = false; j.flags_pending = false;
+    return MNF_OK;
+}
 
-    const int max_rounds = (int)ceil_div(opts->max_samples, min_samples);
-    const int32_t bpv = (int32_t)march_blocks_per_view(opts->rays_per_view);
-    const int march_grid = (int)((int64_t)n_views * bpv);
-    for (int round = 0; round < max_rounds; ++round) {
-        hipLaunchKernelGGL(round_prep_kernel, dim3(1), dim3(256), 0, s, n_views, opts->rays_per_view, opts->max_samples, min_samples, ws);
-        if (opts->sync_every > 0 && round > 0 && round % opts->sync_every == 0) {
-            // the prep just enqueued decided whether any view still has a round to run
-            int32_t flags[2] = {1, 0};   // any_active, overflow (adjacent words)
-            MNF_HIP(hipMemcpyAsync(flags, ws.any_active, sizeof(flags), hipMemcpyDeviceToHost, s));
-            MNF_HIP(hipStreamSynchronize(s));
-            if (flags[1]) {
-                set_error("render_test: a round needed more sample columns than the workspace holds");
-                return MNF_ERR_WORKSPACE;
-            }
-            if (!flags[0]) break;
+// enqueue the next `block` rounds of a job; behind the first prep of every block but the first, the flag words go to pinned memory
+int job_enqueue_block(RenderJob &j, int block) {
+    hipStream_t s = j.s;
+    const float *ab = j.ab;
+    const mnf_render_opts *opts = &j.opts;
+    const int march_grid = (int)((int64_t)j.n_views * j.bpv);
+    const int last = j.round + block < j.max_rounds ? j.round + block : j.max_rounds;
+    for (int k = 0; j.round < last; ++j.round, ++k) {
+        const int round = j.round;
+        hipLaunchKernelGGL(round_prep_kernel, dim3(1), dim3(256), 0, s, j.n_views, opts->rays_per_view, opts->max_samples, j.min_samples, j.ws);
+        if (k == 0 && round > 0) {
+            // the prep just enqueued decided whether any view still has a round to run: any_active, overflow (adjacent words)
+            MNF_HIP(hipMemcpyAsync(j.res->flags, j.ws.any_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipEventRecord(j.res->ev_flags, s));
+            j.flags_pending = true;
         }
         if (round_log()) MNF_HIP(hipEventRecord(log_events()[2], s));
-        if (lds_grid)
-            hipLaunchKernelGGL(round_march_kernel<true>, dim3(march_grid), dim3(kMarchThreads), 0, s, n_rays,
-                               opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
-                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order, bpv);
+        if (j.lds_grid)
+            hipLaunchKernelGGL(round_march_kernel<true>, dim3(march_grid), dim3(kMarchThreads), 0, s, j.n_rays,
+                               opts->rays_per_view, j.rays_o, j.rays_d, j.binaries, j.grid, j.n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
+                               opts->far_plane, opts->render_step_size, opts->cone_angle, j.ws, opts->view_order, j.bpv);
         else
-            hipLaunchKernelGGL(round_march_kernel<false>, dim3(march_grid), dim3(kMarchThreads), 0, s, n_rays,
-                               opts->rays_per_view, rays_o, rays_d, binaries, res, n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
-                               opts->far_plane, opts->render_step_size, opts->cone_angle, ws, opts->view_order, bpv);
+            hipLaunchKernelGGL(round_march_kernel<false>, dim3(march_grid), dim3(kMarchThreads), 0, s, j.n_rays,
+                               opts->rays_per_view, j.rays_o, j.rays_d, j.binaries, j.grid, j.n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
+                               opts->far_plane, opts->render_step_size, opts->cone_angle, j.ws, opts->view_order, j.bpv);
         if (round_log()) MNF_HIP(hipEventRecord(log_events()[3], s));
-        const PipeCfg &pc = pipe_cfg();
-        if (pc.chunks > 1 && round < pc.rounds) {
-            ProfScope ps("field_render", s);
-            PipeRes &pr = pipe_res();
-            const int nc = pc.chunks < 16 ? pc.chunks : 16;
-            MNF_HIP(hipEventRecord(pr.e_main, s));
-            MNF_HIP(hipStreamWaitEvent(pr.sg, pr.e_main, 0));
-            MNF_HIP(hipStreamWaitEvent(pr.sm, pr.e_main, 0));
-            FieldIO pio = io;
-            pio.enc = ws.enc; pio.n_chunks = nc; pio.mlp_waves = pc.mlp_waves; pio.gather_grid = pc.gather_grid;
-            for (int c = 0; c < nc && !rc; ++c) {
-                pio.chunk = c;
-                pio.phase = 1;
-                rc = launch_field(f, pio, false, pr.sg);
-                MNF_HIP(hipEventRecord(pr.eg[c], pr.sg));
-                MNF_HIP(hipStreamWaitEvent(pr.sm, pr.eg[c], 0));
-                pio.phase = 2;
-                if (!rc) rc = launch_field(f, pio, false, pr.sm);
-            }
-            MNF_HIP(hipEventRecord(pr.e_done, pr.sm));
-            MNF_HIP(hipStreamWaitEvent(s, pr.e_done, 0));
-        } else {
+        int rc;
+        {
             ProfScope ps("field_render", s);
             if (round_log()) MNF_HIP(hipEventRecord(log_events()[0], s));
-            FieldIO fio = io;
-            if (pc.chunks > 0 && !split_field()) fio.enc = nullptr;      // late rounds of the pipelined mode: the fused kernel
-            rc = launch_field(f, fio, false, s);   // field evaluation + compositing + ray retirement of this round
+            rc = launch_field(j.f, j.io, false, s);   // field evaluation + compositing + ray retirement of this round
             if (round_log()) MNF_HIP(hipEventRecord(log_events()[1], s));
         }
         if (rc) return rc;
         if (round_log()) {   // MNF_ROUND_LOG (diagnostic, synchronises every round): columns and per-view budgets of the round
+            const int n_views = j.n_views;
             int32_t n_cols = 0, ns[8] = {0}, act[8] = {0};
             std::vector<int32_t> act_all(n_views), alive_all(n_views);
-            MNF_HIP(hipMemcpyAsync(&n_cols, ws.n_cols, 4, hipMemcpyDeviceToHost, s));
-            MNF_HIP(hipMemcpyAsync(ns, ws.n_samples, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
-            MNF_HIP(hipMemcpyAsync(act, ws.active, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
-            MNF_HIP(hipMemcpyAsync(act_all.data(), ws.active, 4 * (size_t)n_views, hipMemcpyDeviceToHost, s));
-            MNF_HIP(hipMemcpyAsync(alive_all.data(), ws.alive_count, 4 * (size_t)n_views, hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(&n_cols, j.ws.n_cols, 4, hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(ns, j.ws.n_samples, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(act, j.ws.active, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(act_all.data(), j.ws.active, 4 * (size_t)n_views, hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(alive_all.data(), j.ws.alive_count, 4 * (size_t)n_views, hipMemcpyDeviceToHost, s));
             MNF_HIP(hipStreamSynchronize(s));
             int n_act = 0; long long n_alive_after = 0;
             for (int v = 0; v < n_views; ++v) { n_act += act_all[v] != 0; n_alive_after += alive_all[v]; }
-            float ms = 0.f;
-            if (!(pc.chunks > 1 && round < pc.rounds)) (void)hipEventElapsedTime(&ms, log_events()[0], log_events()[1]);
-            float ms_march = 0.f;
+            float ms = 0.f, ms_march = 0.f;
+            (void)hipEventElapsedTime(&ms, log_events()[0], log_events()[1]);
             (void)hipEventElapsedTime(&ms_march, log_events()[2], log_events()[3]);
             fprintf(stderr, "[mnf round %d] cols %d  field %.4f ms (%.3f ns/col)  march %.4f ms  active_views %d  alive_after %lld  budgets", round, n_cols, ms, n_cols ? ms * 1e6 / n_cols : 0.0, ms_march, n_act, n_alive_after);
             for (int v = 0; v < n_views && v < 8; ++v) fprintf(stderr, " %d", act[v] ? ns[v] : 0);
             fprintf(stderr, "\n");
         }
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3((int)ceil_div(n_rays, kRayThreads)), dim3(kRayThreads), 0, s, n_rays,
-                       opts->render_bkgd[0], opts->render_bkgd[1], opts->render_bkgd[2], out);
+    return MNF_OK;
+}
+
+// wait for the flag words of the block just enqueued (they were written at its START: the device is still a block behind)
+int job_check(RenderJob &j) {
+    if (j.flags_pending) {
+        MNF_HIP(hipEventSynchronize(j.res->ev_flags));
+        j.flags_pending = false;
+        if (j.res->flags[1]) {
+            set_error("render_test: a round needed more sample columns than the workspace holds");
+            return MNF_ERR_WORKSPACE;
+        }
+        if (!j.res->flags[0]) j.done = true;        // the rounds of this block find nothing to do
+    }
+    if (j.round >= j.max_rounds) j.done = true;
+    return MNF_OK;
+}
+
+int job_finish(RenderJob &j) {
+    hipLaunchKernelGGL(finalize_kernel, dim3((int)ceil_div(j.n_rays, kRayThreads)), dim3(kRayThreads), 0, j.s, j.n_rays,
+                       j.opts.render_bkgd[0], j.opts.render_bkgd[1], j.opts.render_bkgd[2], j.out);
     return launch_status("finalize_kernel");
+}
+
+int run_jobs(std::vector<RenderJob> &jobs) {
+    int block = jobs[0].opts.sync_every > 0 ? jobs[0].opts.sync_every : 1 << 30;
+    if (round_log()) block = 1 << 30;
+    bool any = true;
+#ifdef MNF_DIAG
+    const bool host_log = diag_env("MNF_HOST_LOG") != nullptr;     // host time spent enqueuing vs waiting (diagnostic)
+    double t_enq = 0.0, t_wait = 0.0; int n_rounds = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+#endif
+    while (any) {
+#ifdef MNF_DIAG
+        const double t0 = now();
+        for (auto &j : jobs) n_rounds -= j.round;
+#endif
+        for (auto &j : jobs) if (!j.done) { int rc = job_enqueue_block(j, block); if (rc) return rc; }
+#ifdef MNF_DIAG
+        const double t1 = now();
+        for (auto &j : jobs) n_rounds += j.round;
+#endif
+        any = false;
+        for (auto &j : jobs) if (!j.done) { int rc = job_check(j); if (rc) return rc; any = any || !j.done; }
+#ifdef MNF_DIAG
+        t_enq += t1 - t0; t_wait += now() - t1;
+#endif
+    }
+#ifdef MNF_DIAG
+    if (host_log) fprintf(stderr, "[mnf jobs] %zu jobs, %d job-rounds: host enqueue %.3f ms (%.2f us per job-round), host wait %.3f ms\n", jobs.size(), n_rounds,
+                          1e3 * t_enq, n_rounds ? 1e6 * t_enq / n_rounds : 0.0, 1e3 * t_wait);
+#endif
+    for (auto &j : jobs) { int rc = job_finish(j); if (rc) return rc; }
+    return MNF_OK;
+}
+
+}  // namespace
+}  // namespace mnf
+
+extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32_t res_y, int32_t res_z,
+                               const float *aabb_host, const float *rays_o, const float *rays_d, int64_t n_rays,
+                               const mnf_render_opts *opts,
+                               float *rgb, float *acc, float *depth, float *sem, float *rgb_var, float *depth_var,
+                               int64_t *total_samples, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
+    MNF_REQUIRE(n_rays >= 0, "render_test: negative n_rays");
+    if (n_rays == 0) return MNF_OK;
+    JobPool &pool = job_pool();
+    int rc = pool.ensure(1);
+    if (rc) return rc;
+    std::vector<RenderJob> jobs(1);
+    rc = job_begin(jobs[0], f, binaries, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, rgb, acc, depth, sem, rgb_var, depth_var,
+                   total_samples, workspace, workspace_bytes, as_stream(stream), &pool.res[0]);
+    if (rc) return rc;
+    return run_jobs(jobs);
+}
+
+extern "C" int mnf_render_jobs(const mnf_render_job *jobs_host, int32_t n_jobs, int32_t res_x, int32_t res_y, int32_t res_z,
+                               const float *aabb_host, const mnf_render_opts *opts, mnf_stream_t stream) {
+    MNF_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= 64 && opts, "render_jobs: bad arguments");
+    JobPool &pool = job_pool();
+    int rc = pool.ensure((size_t)n_jobs);
+    if (rc) return rc;
+    hipStream_t s0 = as_stream(stream);
+    std::vector<RenderJob> jobs;
+    jobs.reserve(n_jobs);
+    MNF_HIP(hipEventRecord(pool.ev_fork, s0));            // whatever produced the inputs on the caller's stream comes first
+    for (int k = 0; k < n_jobs; ++k) {
+        const mnf_render_job &d = jobs_host[k];
+        if (d.n_rays == 0) continue;
+        hipStream_t s = k == 0 ? s0 : pool.res[k].side;
+        if (k) MNF_HIP(hipStreamWaitEvent(s, pool.ev_fork, 0));
+        mnf_render_opts o = *opts;
+        o.bitgrid = d.bitgrid;
+        jobs.emplace_back();
+        rc = job_begin(jobs.back(), d.field, d.binaries, res_x, res_y, res_z, aabb_host, d.rays_o, d.rays_d, d.n_rays, &o, d.rgb, d.acc, d.depth,
+                       d.sem, d.rgb_var, d.depth_var, d.total_samples, d.workspace, d.workspace_bytes, s, &pool.res[k]);
+        if (rc) return rc;
+    }
+    if (jobs.empty()) return MNF_OK;
+    rc = run_jobs(jobs);
+    // join: the caller's stream continues after every job (also on an error path, so that no side stream is left racing the caller)
+    for (auto &j : jobs)
+        if (j.s != s0) { (void)hipEventRecord(j.res->ev_join, j.s); (void)hipStreamWaitEvent(s0, j.res->ev_join, 0); }
+    return rc;
 }
 
 extern "C" int mnf_score_views(const float *rgb_var, const float *depth_var, const float *acc, const float *sem,

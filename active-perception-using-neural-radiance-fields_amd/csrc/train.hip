@@ -234,7 +234,7 @@ struct WgradGroup {
 // by re-reading the activations (44 jobs x 64 rows -> 14 groups, -43 % bytes), not by the MFMAs.
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__ jobs, const WgradGroup *__restrict__ groups, int n_groups,
                                                     int split, const half_t *__restrict__ act, int64_t n_cap, const int64_t *n_dev, int rows,
-                                                    float inv_scale, float *g0, float *g1, float *g2) {
+                                                    float inv_scale, float *g0, float *g1, float *g2, float *__restrict__ partials) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= n_groups * split) return;
@@ -280,6 +280,18 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__
                 for (int q = 0; q < 4; ++q) acc[1][1] = mfma(a[1][q], b[1][q], acc[1][1]);
         }
     }
+    if (partials) {   // deterministic mode: this wave's partial sums go to its own slot; wgrad_reduce_kernel adds the slots in a fixed order
+        float *dst = partials + ((size_t)wid * 4) * 1024 + lane * 16;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (o >= gp.no || i >= gp.ni) continue;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dst[(o * 2 + i) * 1024 + k] = acc[o][i][k];
+            }
+        return;
+    }
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -297,7 +309,38 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__
         }
 }
 
+// deterministic mode: one thread per element of a (group, o, i) output tile sums the `split` partial slots front to back
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradJob *__restrict__ jobs, const WgradGroup *__restrict__ groups, int n_groups, int split,
+                                                           const float *__restrict__ partials, float inv_scale, float *g0, float *g1, float *g2) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // ((group * 4 + oi) * 64 + lane) * 16 + k
+    if (e >= (int64_t)n_groups * 4 * 1024) return;
+    const int k = (int)(e & 15), lane = (int)((e >> 4) & 63), oi = (int)((e >> 10) & 3), grp = (int)(e >> 12);
+    const WgradGroup gp = groups[grp];
+    const int o = oi >> 1, i = oi & 1;
+    if (o >= gp.no || i >= gp.ni) return;
+    const WgradJob &jb = jobs[gp.job[o][i]];
+    const int r = lane & 31, h = lane >> 5;
+    const int col = jb.colmap[r];
+    const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
+    if (col < 0 || row >= jb.n_valid) return;
+    float sum = 0.0f;
+    for (int part = 0; part < split; ++part) sum += partials[(((size_t)grp * split + part) * 4 + oi) * 1024 + lane * 16 + k];
+    float *g = jb.buf == 0 ? g0 : (jb.buf == 1 ? g1 : g2);
+    g[jb.param_off + (int64_t)(jb.n0 + row) * jb.stride + col] = sum * inv_scale;   // every weight belongs to exactly one tile
+}
+
 // ------------------------------------------------------------------ hash-grid gradient scatter
+// Deterministic mode (mnf_train_opts.deterministic): the table gradient is accumulated in 64-bit fixed point (value * 2^56, integer
+// atomics: associative, so the result does not depend on the order in which the adds arrive), then converted to fp32 once.  The
+// memory-side atomic unit takes 8-byte integer adds at the request rate of 4-byte float adds (tools/atomic_bench.hip), so the mode
+// costs the wider zero-fill and the conversion pass, not scatter time.  Range +-128 (saturating), resolution 1.4e-17.
+constexpr float kFixScale = 72057594037927936.0f;        // 2^56
+constexpr double kFixInv = 1.0 / 72057594037927936.0;
+__device__ __forceinline__ unsigned long long to_fixed(float v) {
+    const float c = fminf(fmaxf(v, -127.99999f), 127.99999f);
+    return (unsigned long long)__float2ll_rn(c * kFixScale);              // NaN -> 0 (llrint of NaN is unspecified: guard below)
+}
+
 struct HashBwdArgs {
     const float *positions;   // aabb-normalised positions xn = (x - aabb_min) / (aabb_max - aabb_min) [N,3] (normalize_kernel): the
                               // three divisions are done once per sample, not once per sample, level and lane
@@ -310,6 +353,9 @@ struct HashBwdArgs {
     float *g_table;       // fp32 [entries][4]
     int64_t n;
     const int64_t *n_dev;
+    unsigned long long *flush_count;   // diagnostic build (MNF_SCATTER_COUNT=1): quad atomics issued per level, else NULL
+    unsigned long long *q_table, *q_repl;   // deterministic mode: fixed-point table gradient [entries][4] and replicas, else NULL
+    unsigned long long *q_bad;              // deterministic mode: number of non-finite contributions (they cannot be represented in fixed point)
     float aabb[6];
     LevelMeta levels[16];
 };
@@ -337,6 +383,24 @@ __global__ void __launch_bounds__(256) normalize_kernel(const float *__restrict_
 constexpr int kReplicas = 16;
 constexpr uint32_t kReplMaxEntries = 131072;
 
+__global__ void __launch_bounds__(256) fold_replicas_fixed_kernel(const unsigned long long *__restrict__ repl, uint32_t repl_floats,
+                                                                  unsigned long long *__restrict__ q_table) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= repl_floats) return;
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += repl[(size_t)r * repl_floats + i];
+    if (acc) q_table[i] += acc;
+}
+
+// fixed point -> fp32 gradient (overwrites the table part of the gradient vector)
+__global__ void __launch_bounds__(256) fixed_to_float_kernel(const long long *__restrict__ q, float *__restrict__ g, int64_t n,
+                                                             const unsigned long long *__restrict__ bad) {
+    const bool poisoned = *bad != 0;     // a non-finite contribution was met: the gradient says so (the NaN guard of pipeline.py:520-529 sees it)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x)
+        g[i] = poisoned && i == 0 ? __builtin_nanf("") : (float)((double)q[i] * kFixInv);
+}
+
 __global__ void __launch_bounds__(256) fold_replicas_kernel(const float *__restrict__ repl, uint32_t repl_floats, float *__restrict__ g_table) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= repl_floats) return;
@@ -359,6 +423,7 @@ constexpr int kWalkChunk = 128;
 #define MNF_EXP_SCATTER 0
 #endif
 
+template <bool DET>
 __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs args) {
     const int sub = threadIdx.x & 31;                 // lane inside the half-wave
     const int corner = sub >> 2, feat = sub & 3;
@@ -370,6 +435,7 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
     const int l = blockIdx.y + args.level0;
     const LevelMeta m = args.levels[l];
     float *const g_dst = l < args.repl_levels ? args.repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.g_table;
+    unsigned long long *const q_dst = !DET ? nullptr : (l < args.repl_levels ? args.q_repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.q_table);
     const float *gl = args.dX + ((int64_t)l * args.Np) * 4 + feat;
     const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
 
@@ -388,8 +454,15 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
                 q = (((idx - q) >> 1) + q) >> m.div_shift;
                 idx -= q * m.size;
             }
+#ifdef MNF_DIAG
+            if (args.flush_count && feat == 0) atomicAdd(&args.flush_count[l], 1ull);
+#endif
 #if MNF_EXP_SCATTER != 1      /* timing experiment: 1 = the walk without its atomics */
-            atomicAdd(g_dst + ((size_t)(m.offset + idx) << 2) + feat, acc);
+            if (DET) {
+                if (fabsf(acc) <= 3.0e38f) atomicAdd(q_dst + ((size_t)(m.offset + idx) << 2) + feat, to_fixed(acc));
+                else atomicAdd(args.q_bad, 1ull);          // NaN / Inf: reported through the converted gradient (fixed_to_float_kernel)
+            }
+            else atomicAdd(g_dst + ((size_t)(m.offset + idx) << 2) + feat, acc);
 #else
             if (acc == 123.456f) g_dst[0] = acc;
 #endif
@@ -612,6 +685,10 @@ struct TrainState {
     // on a second stream of the handle: both only depend on the backward-data kernel
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // deterministic mode only (allocated on first use): fixed-point table gradient + replicas, weight-gradient partial slots
+    unsigned long long *d_qtable = nullptr;
+    float *d_partials = nullptr;
+    size_t partials_floats = 0;
 };
 
 static int ensure_train_state(mnf_field_t f) {
@@ -658,6 +735,8 @@ void free_train_state_impl(mnf_field_t f) {
     if (ts->d_fragT) (void)hipFree(ts->d_fragT);
     if (ts->d_jobs) (void)hipFree(ts->d_jobs);
     if (ts->d_groups) (void)hipFree(ts->d_groups);
+    if (ts->d_qtable) (void)hipFree(ts->d_qtable);
+    if (ts->d_partials) (void)hipFree(ts->d_partials);
     if (ts->side) (void)hipStreamDestroy(ts->side);
     if (ts->ev_fork) (void)hipEventDestroy(ts->ev_fork);
     if (ts->ev_join) (void)hipEventDestroy(ts->ev_join);
@@ -714,7 +793,7 @@ int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_
 
 int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb, const float *d_density,
                   const float *d_sem, const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale,
-                  float *g_base, float *g_head, float *g_sem, bool zero_grads, hipStream_t s) {
+                  float *g_base, float *g_head, float *g_sem, bool zero_grads, bool positions_normalized, bool deterministic, hipStream_t s) {
     MNF_REQUIRE(f && f->params_loaded, "field_backward: parameters not loaded");
     MNF_REQUIRE(n >= 0 && loss_scale > 0.f, "field_backward: bad arguments");
     MNF_REQUIRE(g_base && g_head && g_sem, "field_backward: null gradient buffer");
@@ -760,6 +839,12 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     MNF_REQUIRE(ok, "field_backward: unsupported shape");
     rc = launch_status("dgrad_kernel");
     if (rc) return rc;
+    if (!positions_normalized) {   // (the train step's forward hands over normalised positions already: FieldIO::xn_out)
+        const float *ab = f->cfg.aabb;
+        const int64_t blocks = ceil_div(3 * n, 256);
+        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, positions, n, n_dev, ab[0], ab[1], ab[2],
+                           ab[3], ab[4], ab[5], v.xn);
+    }
     // ---- fork: the hash-table scatter goes to the handle's side stream, the weight gradients stay on the caller's
     hipStream_t ss = ts->side;
     MNF_HIP(hipEventRecord(ts->ev_fork, s));
@@ -772,22 +857,30 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     int split = (int)(256 * 12 / n_groups);
     if (split > n_tiles / 16) split = (int)(n_tiles / 16);
     if (split < 1) split = 1;
+    float *partials = nullptr;
+    if (deterministic) {
+        const size_t need = (size_t)n_groups * split * 4 * 1024;
+        if (ts->partials_floats < need) {
+            if (ts->d_partials) (void)hipFree(ts->d_partials);
+            ts->d_partials = nullptr; ts->partials_floats = 0;
+            MNF_HIP(hipMalloc((void **)&ts->d_partials, need * sizeof(float)));
+            ts->partials_floats = need;
+        }
+        partials = ts->d_partials;
+    }
     {
         ProfScope ps("wgrad", s);
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * split, 4)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
-                           split, v.act, n, n_dev, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem);
+                           split, v.act, n, n_dev, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem, partials);
+        if (partials)
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * 4 * 1024, 256)), dim3(256), 0, s, ts->d_jobs, ts->d_groups,
+                               n_groups, split, (const float *)partials, 1.0f / loss_scale, g_base, g_head, g_sem);
     }
     rc = launch_status("wgrad_kernel");
     if (rc) return rc;
     // hash-table gradient (side stream)
     HashBwdArgs hb;
-    {
-        const float *ab = f->cfg.aabb;
-        const int64_t blocks = ceil_div(3 * n, 256);
-        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, ss, positions, n, n_dev, ab[0], ab[1], ab[2],
-                           ab[3], ab[4], ab[5], v.xn);
-    }
-    hb.positions = v.xn; hb.dX = v.dX; hb.Np = v.Np; hb.g_table = g_base + f->n_base_mlp; hb.n = n; hb.n_dev = n_dev;
+    hb.positions = positions_normalized ? positions : v.xn; hb.dX = v.dX; hb.Np = v.Np; hb.g_table = g_base + f->n_base_mlp; hb.n = n; hb.n_dev = n_dev;
     std::memcpy(hb.aabb, f->cfg.aabb, sizeof(hb.aabb));
     std::memcpy(hb.levels, f->levels, sizeof(hb.levels));
     int n_levels = 16;
@@ -804,17 +897,56 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     hb.repl_floats = repl_entries * 4;
     hb.repl = v.repl;
     const size_t repl_bytes = (size_t)kReplicas * hb.repl_floats * sizeof(float);
+    hb.flush_count = nullptr;
+    hb.q_table = nullptr; hb.q_repl = nullptr; hb.q_bad = nullptr;
+    const size_t q_table_words = (size_t)f->table_entries * 4, q_repl_words = (size_t)kReplicas * kReplMaxEntries * 4;
+    if (deterministic) {
+        if (!ts->d_qtable) MNF_HIP(hipMalloc((void **)&ts->d_qtable, (q_table_words + q_repl_words + 8) * sizeof(unsigned long long)));
+        hb.q_table = ts->d_qtable; hb.q_repl = ts->d_qtable + q_table_words; hb.q_bad = hb.q_repl + q_repl_words;
+    }
+#ifdef MNF_DIAG
+    static unsigned long long *d_flush = nullptr;
+    if (diag_env("MNF_SCATTER_COUNT")) {
+        if (!d_flush) MNF_HIP(hipMalloc((void **)&d_flush, 16 * sizeof(unsigned long long)));
+        MNF_HIP(hipMemsetAsync(d_flush, 0, 16 * sizeof(unsigned long long), ss));
+        hb.flush_count = d_flush;
+    }
+#endif
     const int prof_scatter = prof_start("hash_scatter", ss);
-    if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.repl, 0, repl_bytes, ss));
     static const bool simple = diag_env("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane, corner and feature
-    if (simple) hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, ss, hb);
-    else hipLaunchKernelGGL(hash_bwd_walk_kernel, dim3((unsigned)ceil_div(ceil_div(n, kWalkChunk) * 32, 256), n_levels), dim3(256), 0, ss, hb);
+    const dim3 walk_grid((unsigned)ceil_div(ceil_div(n, kWalkChunk) * 32, 256), n_levels);
+    if (deterministic) {
+        MNF_HIP(hipMemsetAsync(hb.q_table, 0, q_table_words * sizeof(unsigned long long), ss));
+        if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.q_repl, 0, (size_t)kReplicas * hb.repl_floats * sizeof(unsigned long long), ss));
+        MNF_HIP(hipMemsetAsync(hb.q_bad, 0, sizeof(unsigned long long), ss));
+        hipLaunchKernelGGL(hash_bwd_walk_kernel<true>, walk_grid, dim3(256), 0, ss, hb);
+        if (hb.repl_levels)
+            hipLaunchKernelGGL(fold_replicas_fixed_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, ss, (const unsigned long long *)hb.q_repl,
+                               hb.repl_floats, hb.q_table);
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3(4096), dim3(256), 0, ss, reinterpret_cast<const long long *>(hb.q_table), hb.g_table,
+                           (int64_t)q_table_words, (const unsigned long long *)hb.q_bad);
+    } else {
+        if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.repl, 0, repl_bytes, ss));
+        if (simple) hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, ss, hb);
+        else hipLaunchKernelGGL(hash_bwd_walk_kernel<false>, walk_grid, dim3(256), 0, ss, hb);
+        if (hb.repl_levels)
+            hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, ss, hb.repl, hb.repl_floats, hb.g_table);
+    }
     rc = launch_status("hash_bwd_walk_kernel");
     if (rc) return rc;
-    if (hb.repl_levels)
-        hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, ss, hb.repl, hb.repl_floats, hb.g_table);
     prof_stop(prof_scatter, ss);
     rc = launch_status("fold_replicas_kernel");
+#ifdef MNF_DIAG
+    if (hb.flush_count) {      // quad atomics per level of this backward (synchronises: diagnostic only)
+        unsigned long long h[16];
+        MNF_HIP(hipMemcpyAsync(h, hb.flush_count, sizeof(h), hipMemcpyDeviceToHost, ss));
+        MNF_HIP(hipStreamSynchronize(ss));
+        unsigned long long tot = 0;
+        fprintf(stderr, "[mnf scatter] quad atomics per level:");
+        for (int l = 0; l < 16; ++l) { fprintf(stderr, " %llu", h[l]); tot += h[l]; }
+        fprintf(stderr, "  total %llu (upper bound n = %lld samples)\n", tot, (long long)n);
+    }
+#endif
     // ---- join
     MNF_HIP(hipEventRecord(ts->ev_join, ss));
     MNF_HIP(hipStreamWaitEvent(s, ts->ev_join, 0));
@@ -888,12 +1020,12 @@ int forward_train(mnf_field_t f, const FieldIO &io, void *workspace, int64_t wor
 }
 int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb, const float *d_density, const float *d_sem,
              const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale, float *g_base, float *g_head,
-             float *g_sem, bool zero_grads, hipStream_t stream) {
+             float *g_sem, bool zero_grads, bool positions_normalized, bool deterministic, hipStream_t stream) {
     MNF_REQUIRE(f, "field_backward: null handle");
     return f->cfg.mfma_bf16 ? bf16::backward_impl(f, positions, n, n_dev, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale,
-                                                  g_base, g_head, g_sem, zero_grads, stream)
+                                                  g_base, g_head, g_sem, zero_grads, positions_normalized, deterministic, stream)
                             : f16::backward_impl(f, positions, n, n_dev, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale,
-                                                 g_base, g_head, g_sem, zero_grads, stream);
+                                                 g_base, g_head, g_sem, zero_grads, positions_normalized, deterministic, stream);
 }
 }  // namespace mnf
 
@@ -937,7 +1069,7 @@ extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t
                                   float *g_base, float *g_head, float *g_sem, mnf_stream_t stream) {
     MNF_REQUIRE(f, "field_backward: null handle");
     return backward(f, positions, n, nullptr, d_rgb, d_density, d_sem, rgb, density, workspace, workspace_bytes, loss_scale, g_base, g_head, g_sem, true,
-                    as_stream(stream));
+                    false, false, as_stream(stream));
 }
 
 extern "C" int mnf_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,

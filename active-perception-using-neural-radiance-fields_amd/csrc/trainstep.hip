@@ -19,6 +19,7 @@
 // Build with -ffp-contract=off (the marcher's near planes feed bit-exact t values).
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "field.h"
 
@@ -322,7 +323,7 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
         FieldIO io = {};
         io.mode = 1; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = w.k_ray; io.t_starts = w.k_ts; io.t_ends = w.k_te;
         io.n = max_kept; io.n_dev64 = eff + 1;
-        io.rgb = w.k_rgb; io.density = w.k_sigma; io.sem = w.k_sem; io.positions_out = w.k_pos;
+        io.rgb = w.k_rgb; io.density = w.k_sigma; io.sem = w.k_sem; io.xn_out = w.k_pos;        // aabb-normalised: what the backward's scatter reads
         rc = forward_train(f, io, w.field_ws, w.field_ws_bytes, s);
         if (rc) return rc;
     }
@@ -344,14 +345,23 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
                                       w.o_dep, w.g_rgb, nullptr, w.g_dep, w.g_sem, w.k_dsig, w.k_drgb, w.k_dsem, stream);
     if (rc) return rc;
     return backward(f, w.k_pos, max_kept, eff + 1, w.k_drgb, w.k_dsig, w.k_dsem, w.k_rgb, w.k_sigma, w.field_ws, w.field_ws_bytes, opts->loss_scale, g_base,
-                    g_head, g_sem, false, s);
+                    g_head, g_sem, false, true, opts->deterministic != 0, s);
 }
+
+// view groups per member of a scoring call.  Two render jobs in flight is the measured optimum (profiles/r03_split_experiment.txt): with
+// two or more members each member is one job; a single member's pose list is cut into two halves, so that one half's marcher runs beside
+// the other half's field kernel.
+static inline int score_groups(int32_t n_views, int32_t n_members = 1) { return n_members >= 2 || n_views < 2 ? 1 : 2; }
+static inline int32_t group_lo(int32_t n_views, int g, int G) { return (int32_t)((int64_t)n_views * g / G); }
 
 extern "C" int64_t mnf_score_poses_workspace_bytes(int32_t n_members, int32_t n_views, int32_t n_pix, int32_t n_classes) {
     if (n_members <= 0 || n_views <= 0 || n_pix <= 0 || n_classes <= 0) return -1;
     const int64_t R = (int64_t)n_views * n_pix;
     const int64_t per_member = R * (3 + 1 + 1 + n_classes + 3 + 1) * 4 + 8 * 256;
-    return R * 24 + 512 + n_members * per_member + 64 + mnf_render_workspace_bytes(R, n_pix) + 4096;
+    const int G = score_groups(n_views, n_members);
+    int64_t render = 0;
+    for (int g = 0; g < G; ++g) render += mnf_render_workspace_bytes((int64_t)(group_lo(n_views, g + 1, G) - group_lo(n_views, g, G)) * n_pix, n_pix) + 256;
+    return R * 24 + 512 + n_members * (per_member + render + 64 * G + 256) + 4096;
 }
 
 extern "C" int mnf_score_poses(const mnf_field_t *fields_host, const uint8_t *const *binaries_host, const uint32_t *const *bitgrids_host,
@@ -359,7 +369,7 @@ extern "C" int mnf_score_poses(const mnf_field_t *fields_host, const uint8_t *co
                                int32_t n_views, int32_t width, int32_t height, float focal, const int64_t *pix_idx, int64_t n_pix,
                                const mnf_render_opts *opts, double *terms, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
     MNF_REQUIRE(fields_host && binaries_host && aabb_host && c2w && opts && terms && workspace && pix_idx, "score_poses: null pointer");
-    MNF_REQUIRE(n_members >= 1 && n_views >= 1 && n_pix >= 1, "score_poses: bad sizes");
+    MNF_REQUIRE(n_members >= 1 && n_members <= 16 && n_views >= 1 && n_pix >= 1, "score_poses: bad sizes");
     const int C = fields_host[0]->cfg.num_semantic_classes;
     for (int m = 1; m < n_members; ++m) MNF_REQUIRE(fields_host[m]->cfg.num_semantic_classes == C, "score_poses: members disagree on the class count");
     const int64_t need = mnf_score_poses_workspace_bytes(n_members, n_views, (int32_t)n_pix, C);
@@ -372,19 +382,31 @@ extern "C" int mnf_score_poses(const mnf_field_t *fields_host, const uint8_t *co
     // member-major stacks, exactly what mnf_score_views reads
     float *rgb_var = (float *)take((size_t)n_members * R * 12), *depth_var = (float *)take((size_t)n_members * R * 4);
     float *acc = (float *)take((size_t)n_members * R * 4), *sem = (float *)take((size_t)n_members * R * C * 4);
-    float *rgb = (float *)take(R * 12), *depth = (float *)take(R * 4);
-    int64_t *totals = (int64_t *)take(64);
-    void *rws = take(0);
-    const int64_t rws_bytes = workspace_bytes - (int64_t)off;
     int rc = mnf_generate_rays(c2w, n_views, width, height, focal, pix_idx, n_pix, o, d, stream);
     if (rc) return rc;
     mnf_render_opts ro = *opts;
-    ro.probabilistic = 1; ro.rays_per_view = (int32_t)n_pix; ro.view_order = nullptr;
+    ro.probabilistic = 1; ro.rays_per_view = (int32_t)n_pix; ro.bitgrid = nullptr;      // (the caller's view_order, if any, applies to every view)
+    // every (member, half of the pose list) is a render job of its own: they advance side by side (mnf_render_jobs)
+    const int G = score_groups(n_views, n_members);
+    std::vector<mnf_render_job> jobs;
     for (int m = 0; m < n_members; ++m) {
-        ro.bitgrid = bitgrids_host ? bitgrids_host[m] : nullptr;
-        rc = mnf_render_test(fields_host[m], binaries_host[m], res_x, res_y, res_z, aabb_host, o, d, R, &ro, rgb, acc + (size_t)m * R, depth,
-                             sem + (size_t)m * R * C, rgb_var + (size_t)m * R * 3, depth_var + (size_t)m * R, totals, rws, rws_bytes, stream);
-        if (rc) return rc;
+        float *rgb = (float *)take(R * 12), *depth = (float *)take(R * 4);          // outputs the scorer does not read
+        for (int g = 0; g < G; ++g) {
+            const int64_t r0 = (int64_t)group_lo(n_views, g, G) * n_pix, r1 = (int64_t)group_lo(n_views, g + 1, G) * n_pix;
+            mnf_render_job j = {};
+            j.field = fields_host[m]; j.binaries = binaries_host[m]; j.bitgrid = bitgrids_host ? bitgrids_host[m] : nullptr;
+            j.rays_o = o + 3 * r0; j.rays_d = d + 3 * r0; j.n_rays = r1 - r0;
+            j.rgb = rgb + 3 * r0; j.depth = depth + r0;
+            j.acc = acc + (size_t)m * R + r0; j.sem = sem + ((size_t)m * R + r0) * C;
+            j.rgb_var = rgb_var + ((size_t)m * R + r0) * 3; j.depth_var = depth_var + (size_t)m * R + r0;
+            j.total_samples = (int64_t *)take(64);
+            j.workspace_bytes = mnf_render_workspace_bytes(r1 - r0, (int32_t)n_pix);
+            j.workspace = take((size_t)j.workspace_bytes);
+            jobs.push_back(j);
+        }
     }
+    MNF_REQUIRE((int64_t)off <= workspace_bytes, "score_poses: internal workspace accounting error");
+    rc = mnf_render_jobs(jobs.data(), (int32_t)jobs.size(), res_x, res_y, res_z, aabb_host, &ro, stream);
+    if (rc) return rc;
     return mnf_score_views(rgb_var, depth_var, acc, sem, n_members, n_views, (int32_t)n_pix, C, terms, stream);
 }

@@ -25,10 +25,12 @@ Rays = collections.namedtuple("Rays", ("origins", "viewdirs"))
 _WORKSPACES = {}
 
 
-def _workspace(device, nbytes: int) -> torch.Tensor:
-    ws = _WORKSPACES.get(device)
+def _workspace(key, nbytes: int) -> torch.Tensor:
+    """Cached scratch buffer; `key` is a device or (device, slot) — concurrent render jobs of one call use one slot each."""
+    device = key[0] if isinstance(key, tuple) else key
+    ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
-        _WORKSPACES[device] = ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return ws
 
 
@@ -66,8 +68,91 @@ def _view_order(h: int, w: int, device, block: int = 8) -> torch.Tensor:
     return t
 
 
+def _render_jobs(specs, rpv, max_samples, near_plane, far_plane, render_step_size, render_bkgd, cone_angle, alpha_thre, early_stop_eps,
+                 probabilistic, sync_every=8, image_hw=None, n_split=2):
+    """`specs`: list of (radiance_field, estimator, origins [n,3], viewdirs [n,3]) sharing rays_per_view `rpv` and every option (the
+    members of an ensemble looking at the same poses, or one model).  Every spec is cut into up to `n_split` contiguous groups of
+    whole views, and all (spec, group) pairs advance side by side as render jobs of ONE C call (`mnf_render_jobs`): while one job's
+    marcher or the tail of its field launch leaves compute units idle, the other jobs' kernels use them.  A view's result does not
+    depend on the grouping (its round schedule and its sample tiles are its own).  Returns one dict of device tensors per spec."""
+    lib = L.load_library()
+    opts = L.RenderOpts()
+    opts.near_plane, opts.far_plane, opts.render_step_size = near_plane, far_plane, render_step_size
+    opts.cone_angle, opts.alpha_thre, opts.early_stop_eps = cone_angle, alpha_thre, early_stop_eps
+    bk = [0.0, 0.0, 0.0] if render_bkgd is None else [float(x) for x in render_bkgd.detach().cpu().reshape(-1)[:3]]
+    for i in range(3):
+        opts.render_bkgd[i] = bk[i]
+    opts.max_samples, opts.probabilistic, opts.rays_per_view, opts.sync_every = int(max_samples), int(probabilistic), int(rpv), sync_every
+    dev = specs[0][2].device
+    order = None
+    if image_hw is not None and image_hw[0] * image_hw[1] == rpv and min(image_hw) >= 16:
+        order = _view_order(image_hw[0], image_hw[1], dev)
+    opts.view_order = None if order is None else order.data_ptr()
+    opts.bitgrid = None
+    jobs, keep, outs = [], [], []
+    grid0 = None
+    for radiance_field, estimator, o, d in specs:
+        L.require_gpu(o, d)
+        n = o.shape[0]
+        if n % rpv:
+            raise L.MnfError(f"n_rays ({n}) must be a positive multiple of rays_per_view ({rpv})")
+        C = radiance_field.num_semantic_classes
+        handle = radiance_field._ensure_handle()
+        binaries, aabb = _single_level(estimator)
+        L.require_gpu(binaries)
+        if grid0 is None:
+            grid0 = (tuple(binaries.shape[1:]), tuple(aabb))
+        elif grid0 != (tuple(binaries.shape[1:]), tuple(aabb)):
+            raise L.MnfError("render jobs of one call must share the occupancy grid resolution and aabb")
+        bits = estimator.bitgrid() if hasattr(estimator, "bitgrid") else None     # the estimator's packed grid (no per-call packing)
+        rgb = torch.empty(n, 3, device=dev); acc = torch.empty(n, 1, device=dev); depth = torch.empty(n, 1, device=dev)
+        sem = torch.empty(n, C, device=dev)
+        rgb_var = torch.empty(n, 3, device=dev) if probabilistic else None
+        depth_var = torch.empty(n, 1, device=dev) if probabilistic else None
+        V = n // rpv
+        G = max(1, min(int(n_split), V))
+        totals = torch.zeros(G, 2, dtype=torch.int64, device=dev)   # per job: [kept (reference total_samples), evaluated]
+        keep += [binaries, bits, o, d, totals]
+        for g in range(G):
+            r0, r1 = (V * g // G) * rpv, (V * (g + 1) // G) * rpv
+            if r1 == r0:
+                continue
+            nbytes = lib.mnf_render_workspace_bytes(r1 - r0, rpv)
+            ws = _workspace((dev, len(jobs)), nbytes)
+            j = L.RenderJob()
+            j.field, j.binaries, j.bitgrid = handle, binaries.data_ptr(), (None if bits is None else bits.data_ptr())
+            j.rays_o, j.rays_d, j.n_rays = o[r0:].data_ptr(), d[r0:].data_ptr(), r1 - r0
+            j.rgb, j.acc, j.depth, j.sem = rgb[r0:].data_ptr(), acc[r0:].data_ptr(), depth[r0:].data_ptr(), sem[r0:].data_ptr()
+            j.rgb_var = rgb_var[r0:].data_ptr() if probabilistic else None
+            j.depth_var = depth_var[r0:].data_ptr() if probabilistic else None
+            j.total_samples = totals[g].data_ptr()
+            j.workspace, j.workspace_bytes = ws.data_ptr(), nbytes
+            jobs.append(j)
+            keep.append(ws)
+        out = dict(rgb=rgb, acc=acc, depth=depth, sem=sem, _totals=totals)
+        if probabilistic:
+            out.update(rgb_var=rgb_var, depth_var=depth_var)
+        outs.append(out)
+    if jobs:
+        arr = (L.RenderJob * len(jobs))(*jobs)
+        res, aabb = grid0
+        anchor = L.ptr(specs[0][2])                  # device guard + stream of the GPU that owns the rays
+        L.launch(lib.mnf_render_jobs, arr, len(jobs), res[0], res[1], res[2], (ctypes.c_float * 6)(*aabb), ctypes.byref(opts), _Anchor(anchor))
+    for out in outs:
+        out["total"] = out.pop("_totals").sum(0)
+    return outs
+
+
+class _Anchor:
+    """Carries a DevPtr through `L.launch` without adding an argument to the C call: launch() derives the device guard and the
+    stream from the first DevPtr among its arguments; mnf_render_jobs takes its device pointers inside the job array."""
+
+    def __init__(self, p):
+        self.p = p
+
+
 def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane, render_step_size, render_bkgd,
-                 cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view=None, sync_every=8, image_hw=None):
+                 cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view=None, sync_every=8, image_hw=None, n_split=2):
     rays_shape = rays.origins.shape
     if image_hw is None and rays_per_view is None and len(rays_shape) == 3:
         image_hw = (int(rays_shape[0]), int(rays_shape[1]))      # [H,W,3] rays (utils.py:574-580): one image
@@ -77,44 +162,21 @@ def _render_test(max_samples, radiance_field, estimator, rays, near_plane, far_p
     n = o.shape[0]
     C = radiance_field.num_semantic_classes
     dev = o.device
-    handle = radiance_field._ensure_handle()
-    binaries, aabb = _single_level(estimator)
-    L.require_gpu(binaries)
-    rpv = n if rays_per_view is None else int(rays_per_view)
-    opts = L.RenderOpts()
-    opts.near_plane, opts.far_plane, opts.render_step_size = near_plane, far_plane, render_step_size
-    opts.cone_angle, opts.alpha_thre, opts.early_stop_eps = cone_angle, alpha_thre, early_stop_eps
-    bk = [0.0, 0.0, 0.0] if render_bkgd is None else [float(x) for x in render_bkgd.detach().cpu().reshape(-1)[:3]]
-    for i in range(3):
-        opts.render_bkgd[i] = bk[i]
-    opts.max_samples, opts.probabilistic, opts.rays_per_view, opts.sync_every = int(max_samples), int(probabilistic), rpv, sync_every
-    order = None
-    if image_hw is not None and image_hw[0] * image_hw[1] == rpv and min(image_hw) >= 16:
-        order = _view_order(image_hw[0], image_hw[1], dev)
-    opts.view_order = None if order is None else order.data_ptr()
-    bits = estimator.bitgrid() if hasattr(estimator, "bitgrid") else None     # the estimator's packed grid (no per-call packing)
-    opts.bitgrid = None if bits is None else bits.data_ptr()
-    rgb = torch.empty(n, 3, device=dev); acc = torch.empty(n, 1, device=dev); depth = torch.empty(n, 1, device=dev)
-    sem = torch.empty(n, C, device=dev)
-    rgb_var = torch.empty(n, 3, device=dev) if probabilistic else None
-    depth_var = torch.empty(n, 1, device=dev) if probabilistic else None
-    total = torch.zeros(2, dtype=torch.int64, device=dev)   # [kept (reference total_samples), evaluated]
-    lib = L.load_library()
-    if n:
-        nbytes = lib.mnf_render_workspace_bytes(n, rpv)
-        if nbytes < 0:
-            raise L.MnfError(f"n_rays ({n}) must be a positive multiple of rays_per_view ({rpv})")
-        ws = _workspace(dev, nbytes)
-        aabb_host = (ctypes.c_float * 6)(*aabb)
-        res = binaries.shape[1:]
-        L.launch(lib.mnf_render_test, handle, L.ptr(binaries), res[0], res[1], res[2], aabb_host, L.ptr(o), L.ptr(d), n,
-                                    ctypes.byref(opts), L.ptr(rgb), L.ptr(acc), L.ptr(depth), L.ptr(sem), L.ptr(rgb_var),
-                                    L.ptr(depth_var), L.ptr(total), L.ptr(ws), nbytes)
     shp = tuple(rays_shape[:-1])
-    out = dict(rgb=rgb.view(*shp, -1), acc=acc.view(*shp, -1), depth=depth.view(*shp, -1), sem=sem.view(*shp, -1), total=total)
+    if n == 0:
+        z = lambda *s_: torch.empty(*s_, device=dev)
+        out = dict(rgb=z(n, 3), acc=z(n, 1), depth=z(n, 1), sem=z(n, C), total=torch.zeros(2, dtype=torch.int64, device=dev))
+        if probabilistic:
+            out.update(rgb_var=z(n, 3), depth_var=z(n, 1))
+    else:
+        rpv = n if rays_per_view is None else int(rays_per_view)
+        out = _render_jobs([(radiance_field, estimator, o, d)], rpv, max_samples, near_plane, far_plane, render_step_size, render_bkgd,
+                           cone_angle, alpha_thre, early_stop_eps, probabilistic, sync_every, image_hw, n_split)[0]
+    res = dict(rgb=out["rgb"].view(*shp, -1), acc=out["acc"].view(*shp, -1), depth=out["depth"].view(*shp, -1), sem=out["sem"].view(*shp, -1),
+               total=out["total"])
     if probabilistic:
-        out.update(rgb_var=rgb_var.view(*shp, -1), depth_var=depth_var.view(*shp, -1))
-    return out
+        res.update(rgb_var=out["rgb_var"].view(*shp, -1), depth_var=out["depth_var"].view(*shp, -1))
+    return res
 
 
 @torch.no_grad()
@@ -147,13 +209,14 @@ def render_probablistic_image_with_occgrid_test(max_samples: int, radiance_field
 @torch.no_grad()
 def render_views(radiance_field, estimator, rays_o, rays_d, rays_per_view, max_samples=1024, near_plane=0.0,
                  far_plane=1e10, render_step_size=1e-3, render_bkgd=None, cone_angle=0.0, alpha_thre=0.0,
-                 early_stop_eps=1e-4, probabilistic=False, sync_every=8, image_hw=None):
+                 early_stop_eps=1e-4, probabilistic=False, sync_every=8, image_hw=None, n_split=2):
     """Batched form: rays_o/rays_d [V*rays_per_view, 3]; every group of rays_per_view rays is rendered exactly as one
-    call of the reference function (own round schedule), all views in the same launches.  `image_hw=(H, W)` says that the
-    rays of a view are the row-major pixels of an H x W image (a speed hint only: see `_view_order`).
+    call of the reference function (own round schedule).  `image_hw=(H, W)` says that the rays of a view are the row-major
+    pixels of an H x W image (a speed hint only: see `_view_order`).  `n_split`: the views are rendered as up to this many
+    groups advancing side by side (`_render_jobs`; a speed choice only: results do not depend on it).
     Returns a dict of device tensors."""
     return _render_test(max_samples, radiance_field, estimator, Rays(rays_o, rays_d), near_plane, far_plane, render_step_size,
-                        render_bkgd, cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view, sync_every, image_hw)
+                        render_bkgd, cone_angle, alpha_thre, early_stop_eps, probabilistic, rays_per_view, sync_every, image_hw, n_split)
 
 
 # ------------------------------------------------------------------ train-mode forward (utils.py:63-219, :362-461)
@@ -253,7 +316,8 @@ def _check_status(status):
 
 @torch.no_grad()
 def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, sem, render_bkgd=None, near_plane=0.1, far_plane=1e10,
-                           render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, early_stop_eps=1e-4, stratified=None, sync=True):
+                           render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, early_stop_eps=1e-4, stratified=None, sync=True,
+                           deterministic=False):
     """scripts/pipeline.py:472-518 for one model as ONE C call (`mnf_train_step`, csrc/trainstep.hip): train render (occupancy
     sampling + density pre-pass + visibility filter + sem_rendering), the three-term loss and its backward.  Fills `.grad` of
     the three flat parameter vectors.  The call itself never waits for the GPU: the sample counts stay on the device.
@@ -291,6 +355,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         opts.render_bkgd_dev = None
     opts.stratified = int(radiance_field.training if stratified is None else stratified)
     opts.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    opts.deterministic = int(bool(deterministic))      # bitwise reproducible gradient accumulation (include/mi355nerf.h: mnf_train_opts)
     params = [radiance_field.mlp_base.params, radiance_field.mlp_head.params, radiance_field.mlp_sem.params]
     for p_ in params:
         if p_.grad is None or p_.grad.shape != p_.shape or not p_.grad.is_contiguous():
@@ -351,7 +416,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
 
 def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, sem, render_bkgd, step: int,
                near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-3, scheduler=None,
-               data_parallel_group=None, data_parallel=False, fused=True, sync=True, stratified=None):
+               data_parallel_group=None, data_parallel=False, fused=True, sync=True, stratified=None, deterministic=False):
     """One model's training iteration exactly as scripts/pipeline.py:447-532 sequences it: occupancy refresh every 16th
     step (:447-470), train render (:472-489), loss 10*smoothL1(rgb) + smoothL1(depth)/5 + CE(sem)/2 (:506-511),
     backward (:518), NaN-gradient guard (:520-529), optimizer and scheduler step (:531-532).  `data_parallel=True`
@@ -368,7 +433,9 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
       sync=False  no round trip at all: n_rendering_samples and skipped are device tensors, the scheduler advances every call.
     Any other optimizer is stepped from the host after reading the flag (sync=True only).
     `stratified` (fused path): None = jitter the near planes as the reference does in training mode (occ_grid.py:187-189);
-    False = no jitter (reproducible sample sets: parity tests).
+    False = no jitter (reproducible sample sets: parity tests).  `deterministic=True` (fused path): gradients are accumulated in an
+    order-independent way (64-bit fixed-point integer atomics for the hash table, ordered partial sums for the weights): with a
+    seeded torch generator the whole training run is bitwise reproducible.
     Returns dict(loss, loss_rgb, loss_dep, loss_sem as device tensors, n_rendering_samples, skipped)."""
     import torch.nn.functional as F
     from .optim import FusedAdam, count_nan_gradients
@@ -385,7 +452,7 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     if fused:
         out = fused_forward_backward(radiance_field, estimator, rays, pixels, dep, sem, render_bkgd, near_plane=near_plane,
                                      render_step_size=render_step_size, cone_angle=cone_angle, alpha_thre=alpha_thre, sync=sync,
-                                     stratified=stratified)
+                                     stratified=stratified, deterministic=deterministic)
     if out is not None:
         n_rendering_samples = out["n_rendering_samples"]
         loss, loss_rgb, loss_dep, loss_sem = out["loss"], out["loss_rgb"], out["loss_dep"], out["loss_sem"]
@@ -571,14 +638,16 @@ def score_views(radiance_fields, estimators, poses, width, height, focal, near_p
     terms_local = torch.zeros(per, 4, dtype=torch.float64, device=device)
     if hi > lo:
         o, d, h, w = _pose_rays(poses[lo:hi], width, height, focal, scale, device)
-        rv, dv, ac, sm, totals = [], [], [], [], []
         n = hi - lo
-        for rf, est in zip(radiance_fields, estimators):
-            r = render_views(rf, est, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
-                             render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, probabilistic=True)
-            totals.append(r["total"])
-            rv.append(r["rgb_var"].reshape(n, h * w, 3)); dv.append(r["depth_var"].reshape(n, h * w))
-            ac.append(r["acc"].reshape(n, h * w)); sm.append(r["sem"].reshape(n, h * w, -1))
+        # every ensemble member renders the same rays: the members advance side by side as render jobs of one call (two jobs in
+        # flight is the measured optimum: a single member is cut into two groups of views; rays stay in row-major march order —
+        # the 8x8-block order of full images buys nothing on 64x64 sub-sampled views: profiles/r03_split_experiment.txt)
+        M = len(radiance_fields)
+        outs = _render_jobs([(rf, est, o, d) for rf, est in zip(radiance_fields, estimators)], h * w, 1024, near_plane, 1e10, render_step_size,
+                            torch.zeros(3), cone_angle, alpha_thre, 1e-4, True, 8, None, max(1, 2 // M))
+        totals = [r["total"] for r in outs]
+        rv = [r["rgb_var"].reshape(n, h * w, 3) for r in outs]; dv = [r["depth_var"].reshape(n, h * w) for r in outs]
+        ac = [r["acc"].reshape(n, h * w) for r in outs]; sm = [r["sem"].reshape(n, h * w, -1) for r in outs]
         terms_local[:n] = score_view_terms(torch.stack(rv), torch.stack(dv), torch.stack(ac), torch.stack(sm))
         LAST_SCORE_TOTALS[:] = totals           # per member: device int64 [kept, evaluated] samples of this rank's views (measurement aid)
     terms = terms_local[:V] if group is False else gather_view_terms(terms_local, V, group)
@@ -605,6 +674,7 @@ def score_poses(radiance_fields, estimators, poses, width, height, focal, near_p
     opts.near_plane, opts.far_plane, opts.render_step_size = near_plane, 1e10, render_step_size
     opts.cone_angle, opts.alpha_thre, opts.early_stop_eps = cone_angle, alpha_thre, 1e-4
     opts.max_samples, opts.probabilistic, opts.rays_per_view, opts.sync_every = 1024, 1, h * w, 8
+    opts.view_order = None                                # row-major march order, as `score_views`
     C = radiance_fields[0].num_semantic_classes
     nbytes = int(lib.mnf_score_poses_workspace_bytes(M, V, h * w, C))
     ws = _workspace(torch.device(device), nbytes)

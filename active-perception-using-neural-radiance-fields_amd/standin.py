@@ -77,7 +77,7 @@ def _free_space_poses(scene, n, seed):
     return out
 
 
-PROTOCOL_VERSION = 3      # bump when the training protocol or anything it runs through changes what a given tag would produce
+PROTOCOL_VERSION = 4      # bump when the training protocol or anything it runs through changes what a given tag would produce
 
 
 def default_cache_dir() -> str:
@@ -100,8 +100,10 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
                   n_poses=64, verbose=False, lr_final=2e-4):
     """-> (NGPRadianceField, OccGridEstimator, info dict), trained as described in the module docstring with
     `render.train_step` + `optim.FusedAdam`; the learning rate stays at `lr` for the first half and decays geometrically to
-    `lr_final` over the second (training is not deterministic -- float atomics -- and with a constant rate four runs of one box
-    differed by 23 % in samples per ray of the resulting scene; with the decay by 9 %: tools/exp_standin_variance.py).  `scene` is `tests/helpers.make_scene`-shaped (aabb, res, occ, neurons, layers, C,
+    `lr_final` over the second.  Training is bitwise reproducible: every random draw comes from generators seeded here and the
+    train step runs in its deterministic mode (order-independent gradient accumulation, `mnf_train_opts.deterministic`), so the
+    stand-in — and with it the samples per ray of the benchmark views — is the same on every box and in every run of one build
+    (rounds 1-2 trained with float atomics and unseeded jitter: 91-137 samples per ray across boxes).  `scene` is `tests/helpers.make_scene`-shaped (aabb, res, occ, neurons, layers, C,
     log2_hashmap_size)."""
     from .ngp import NGPRadianceField
     from .optim import FusedAdam
@@ -139,6 +141,8 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
     K = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
     opt = FusedAdam(field.parameters(), lr=lr, eps=1e-15).bind_field(field)
     gen = torch.Generator().manual_seed(seed)
+    rng_state = torch.random.get_rng_state()
+    torch.manual_seed(1000 + seed)          # the near-plane jitter and the occupancy refresh draw their device seeds from torch's CPU generator
     n_rays, t0, losses, skipped, n_samp = 1024, time.perf_counter(), [], 0, 0
     bk = torch.zeros(3, device=device)
     for step in range(steps):
@@ -152,7 +156,7 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
         rays = RD.generate_image_rays(torch.from_numpy(c2w[k:k + 1]), 640, 640, K, device, idx)
         pix, dep, lab = analytic_targets(proc, scene["aabb"], rays.origins, rays.viewdirs)
         out = RD.train_step(field, est, opt, rays, pix, dep, lab, bk, step=step, near_plane=0.1, render_step_size=1e-3,
-                            cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-2)
+                            cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-2, deterministic=True)
         n_samp = out["n_rendering_samples"]
         skipped += int(out["skipped"])
         if n_samp > 0:                                                         # pipeline.py:494-504: keep the sample batch near the target
@@ -163,6 +167,7 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
                 print(f"[standin] step {step}: loss {losses[-1]:.4f}, rays {n_rays}, samples {n_samp}, "
                       f"occupied {int(est.binaries.sum())}", flush=True)
     torch.cuda.synchronize(device)
+    torch.random.set_rng_state(rng_state)
     info = dict(steps=steps, seconds=time.perf_counter() - t0, loss_first=losses[0] if losses else None,
                 loss_last=losses[-1] if losses else None, skipped_steps=skipped, final_rays=n_rays, final_samples=n_samp,
                 occupied_cells=int(est.binaries.sum()), cells=int(est.binaries.numel()), cached=False)

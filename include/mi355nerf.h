@@ -360,6 +360,11 @@ typedef struct {
     uint64_t seed;
     const float *render_bkgd_dev;   /* optional: 3 device floats used instead of render_bkgd (pipeline.py:437 draws the colour on
                                        the GPU: no host copy of it is needed) */
+    int32_t deterministic;          /* 0 (default): gradients accumulate with float atomics (the reference's index_add_ / tcnn atomics: the
+                                       result depends on arrival order in the last bits).  1: bitwise reproducible — the hash-table gradient
+                                       accumulates in 64-bit fixed point (integer atomics), the weight gradients' partial sums are added in
+                                       a fixed order.  Same kernels otherwise; used for stand-in scenes that must come out the same on
+                                       every box (apnrf_amd.standin) and for regression tests. */
 } mnf_train_opts;
 int64_t mnf_train_step_workspace_bytes(mnf_field_t f, int32_t n_rays, int64_t max_marched, int64_t max_kept);
 int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
@@ -409,6 +414,25 @@ int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32
                     const mnf_render_opts *opts,
                     float *rgb, float *acc, float *depth, float *sem, float *rgb_var, float *depth_var,
                     int64_t *total_samples, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
+
+/* Several independent render calls advancing side by side (the members of an ensemble rendering the same candidate views,
+ * pipeline.py:697-711 called once per member; or groups of views of one pose list, habitat_to_data.py:304-549): every job is what
+ * one mnf_render_test call is, with its own field / grid / rays / outputs / workspace; job 0 runs on `stream`, the others on
+ * streams of the library that fork from and join `stream`.  While one job's short kernels leave compute units idle the others'
+ * launches use them.  Results are those of separate mnf_render_test calls, bit for bit.  `opts->bitgrid` is ignored (per job). */
+typedef struct {
+    mnf_field_t field;
+    const uint8_t *binaries;      /* [1,X,Y,Z] u8 */
+    const uint32_t *bitgrid;      /* optional packed form of `binaries` (see mnf_render_opts.bitgrid) */
+    const float *rays_o, *rays_d; /* [n_rays,3] */
+    int64_t n_rays;               /* a multiple of opts->rays_per_view; 0 = nothing to do */
+    float *rgb, *acc, *depth, *sem, *rgb_var, *depth_var;
+    int64_t *total_samples;       /* 2 x int64 (device) */
+    void *workspace;              /* mnf_render_workspace_bytes(n_rays, rays_per_view), not shared between jobs */
+    int64_t workspace_bytes;
+} mnf_render_job;
+int mnf_render_jobs(const mnf_render_job *jobs_host, int32_t n_jobs, int32_t res_x, int32_t res_y, int32_t res_z,
+                    const float *aabb_host, const mnf_render_opts *opts, mnf_stream_t stream);
 
 /* ---------------------------------------------------------------- planner hand-off
  * The only perception artefact the planner reads (scripts/pipeline.py:1043-1049, planning/planning_funcs.py:243-261):

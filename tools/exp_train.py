@@ -1,0 +1,67 @@
+"""Train-step timing experiment (GPU box): ms per step for the synchronous (reference semantics: one host round trip at the end)
+and the fully asynchronous form, at BASELINE config 5's shape (8192 rays) and at the reference yaml's (2000 rays / ~262 k samples).
+    python tools/exp_train.py [f16|bf16] [steps]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import apnrf_amd  # noqa: F401
+from apnrf_amd import render as RD
+from apnrf_amd import scenes as SC
+from apnrf_amd import standin as SI
+from apnrf_amd.optim import FusedAdam
+
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f16"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+lr = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0          # 0: the parameters (hence the sample counts) stay put across the timed steps
+shapes = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [8192, 2000]
+modes = [bool(int(x)) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [True, False]
+dev = "cuda:0"
+scene = SC.make_scene("102344280", n_poses=40)
+field, est, info = SI.train_standin(scene, dev, seed=11)
+if dtype == "bf16":
+    f2 = SC.hip_field(scene, dev, mfma_bf16=True)
+    f2.load_state_dict(field.state_dict())
+    field = f2
+field.train(); est.train()
+proc = SI._procedural_estimator(scene, dev)
+c2w = np.stack([RD.pose_to_c2w(p) for p in scene["poses"][:8]]).astype(np.float32)
+K6 = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
+
+
+def batches(R):
+    g = torch.Generator(device="cpu").manual_seed(100)
+    out = []
+    for k in range(8):
+        idx = torch.randint(0, 640 * 640, (R,), generator=g).numpy()
+        ys, xs = idx // 640, idx % 640
+        idx = idx[np.argsort((ys // 32) * 20 + xs // 32, kind="stable")]
+        r = RD.generate_image_rays(torch.from_numpy(c2w[k:k + 1]), 640, 640, K6, dev, idx)
+        out.append((r,) + SI.analytic_targets(proc, scene["aabb"], r.origins, r.viewdirs))
+    return out
+
+
+for R in shapes:
+    bs = batches(R)
+    for sync in modes:
+        opt = FusedAdam(field.parameters(), lr=lr, eps=1e-15).bind_field(field)
+        bk = torch.rand(3, device=dev)
+        outs = []
+        for i in range(5):
+            r, pix, dep_, lab = bs[i % 8]
+            RD.train_step(field, est, opt, r, pix, dep_, lab, bk, step=1001 + i, sync=sync, **SC.RENDER_KW)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            r, pix, dep_, lab = bs[i % 8]
+            outs.append(RD.train_step(field, est, opt, r, pix, dep_, lab, bk, step=1001 + i, sync=sync, **SC.RENDER_KW))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kept = np.mean([int(o["n_rendering_samples"]) for o in outs])
+        skipped = sum(int(o["skipped"]) for o in outs)
+        print(f"[exp_train] {dtype} rays {R} sync={sync}: {1e3 * dt:.3f} ms/step, kept {kept:.0f}, skipped {skipped}", flush=True)

@@ -1,7 +1,7 @@
 """Per-round log of ONE scoring pass (BASELINE config 4: 256 candidate views x 4096 rays, one ensemble member at a time):
 columns, field-kernel and marcher time, active views and surviving rays of every render round (MNF_ROUND_LOG=1, which
 synchronises every round: the times are per-launch times, not pass times).  Usage (GPU box):
-    MNF_ROUND_LOG=1 python tools/score_roundlog.py [n_views] 2> gpurun_out/score_roundlog.txt"""
+    MNF_LIB_PATH=<repo>/active-perception-using-neural-radiance-fields_amd/libmi355nerf_diag.so MNF_ROUND_LOG=1 python tools/score_roundlog.py [n_views] 2> gpurun_out/score_roundlog.txt"""
 import os
 import sys
 import time
