@@ -364,12 +364,15 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
     key = (id(radiance_field), R)
     st = _TRAIN_STATE.get(key)
     if st is None:
-        st = _TRAIN_STATE[key] = dict(cap_m=R * 384, cap_k=R * 192, pending=None)
-    pend = st["pending"]
-    if pend is not None and (sync or pend[1].query()):           # counts of an earlier lazy step: adapt the bounds, surface its errors
-        pend[1].synchronize()
-        c = pend[0].tolist()
-        st["pending"] = None
+        st = _TRAIN_STATE[key] = dict(cap_m=R * 384, cap_k=R * 192, pending=[])
+    # counts of earlier lazy steps (copied to pinned memory behind each step): adapt the bounds, surface their errors.  Everything that
+    # has arrived is read; the step enqueued two calls ago is waited for (the host is at least a step ahead of the GPU: no stall), so a
+    # bound that is too small is corrected at most two steps late.
+    pending = st["pending"]
+    while pending and (sync or len(pending) > 1 or pending[0][1].query()):
+        host, ev = pending.pop(0)
+        ev.synchronize()
+        c = host.tolist()
         _check_status(c[3])
         if c[3] & _ST_ROW:
             raise L.MnfError("train_step: a ray has more samples than a scratch row holds (use the autograd path: fused=False)")
@@ -408,7 +411,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         host.copy_(counts, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        st["pending"] = (host, ev)
+        st["pending"].append((host, ev))
         estimator.last_sampling = {"n_marched": counts[0]}
         out.update(n_rendering_samples=counts[1], n_marched=counts[0])
     return out

@@ -77,7 +77,7 @@ def _free_space_poses(scene, n, seed):
     return out
 
 
-PROTOCOL_VERSION = 4      # bump when the training protocol or anything it runs through changes what a given tag would produce
+PROTOCOL_VERSION = 5      # bump when the training protocol or anything it runs through changes what a given tag would produce
 
 
 def default_cache_dir() -> str:
@@ -97,14 +97,15 @@ def default_cache_dir() -> str:
 
 
 def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 21, lr=2e-3, seed=9, cache_dir=None,
-                  n_poses=64, verbose=False, lr_final=2e-4):
+                  n_poses=64, verbose=False, lr_final=2e-4, keep_optimizer=False):
     """-> (NGPRadianceField, OccGridEstimator, info dict), trained as described in the module docstring with
     `render.train_step` + `optim.FusedAdam`; the learning rate stays at `lr` for the first half and decays geometrically to
     `lr_final` over the second.  Training is bitwise reproducible: every random draw comes from generators seeded here and the
     train step runs in its deterministic mode (order-independent gradient accumulation, `mnf_train_opts.deterministic`), so the
     stand-in — and with it the samples per ray of the benchmark views — is the same on every box and in every run of one build
     (rounds 1-2 trained with float atomics and unseeded jitter: 91-137 samples per ray across boxes).  `scene` is `tests/helpers.make_scene`-shaped (aabb, res, occ, neurons, layers, C,
-    log2_hashmap_size)."""
+    log2_hashmap_size).  `keep_optimizer=True` also returns (and caches) the optimizer's state_dict in info["optimizer_state"], so that a
+    caller can continue the training run where it stopped (Adam moments warm, learning rate `lr_final`)."""
     from .ngp import NGPRadianceField
     from .optim import FusedAdam
     from . import _lib as L
@@ -115,7 +116,7 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
             lib_id = hashlib.md5(fh.read()).hexdigest()[:12]
     except OSError:
         lib_id = "nolib"
-    tag = (f"v{PROTOCOL_VERSION}_{scene.get('name')}_{tuple(np.round(scene['aabb'], 3))}_{tuple(scene['res'])}_{scene['neurons']}x{scene['layers']}_C{scene['C']}"
+    tag = (("opt_" if keep_optimizer else "") + f"v{PROTOCOL_VERSION}_{scene.get('name')}_{tuple(np.round(scene['aabb'], 3))}_{tuple(scene['res'])}_{scene['neurons']}x{scene['layers']}_C{scene['C']}"
            f"_T{scene['log2_hashmap_size']}_s{steps}_r{max_rays}_t{target_samples}_p{n_poses}_lr{lr}_lrf{lr_final}_seed{seed}_lib{lib_id}")
     cache_dir = default_cache_dir() if cache_dir is None else cache_dir
     path = os.path.join(cache_dir, "mnf_standin_" + hashlib.md5(tag.encode()).hexdigest()[:16] + ".pt")
@@ -130,7 +131,10 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
         if ck.get("tag") == tag:
             field.load_state_dict(ck["model"])
             est.occs.copy_(ck["occs"]); est.binaries = ck["binaries"].to(device)
-            return field.eval(), est.eval(), dict(ck["info"], cached=True)
+            info = dict(ck["info"], cached=True)
+            if keep_optimizer:
+                info["optimizer_state"] = ck["optimizer_state"]
+            return field.eval(), est.eval(), info
     proc = _procedural_estimator(scene, device)
     # the captures of the reference's first phase (a yaw sweep about the start pose, pipeline.py:252-264) plus views from
     # elsewhere in the free space, so that the trained region is the one the benchmark's views look at
@@ -155,6 +159,7 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
         k = step % n_poses
         rays = RD.generate_image_rays(torch.from_numpy(c2w[k:k + 1]), 640, 640, K, device, idx)
         pix, dep, lab = analytic_targets(proc, scene["aabb"], rays.origins, rays.viewdirs)
+        bk = torch.rand(3, generator=gen).to(device)                # habitat_to_data.py:189-191: a random background colour per training batch
         out = RD.train_step(field, est, opt, rays, pix, dep, lab, bk, step=step, near_plane=0.1, render_step_size=1e-3,
                             cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-2, deterministic=True)
         n_samp = out["n_rendering_samples"]
@@ -174,9 +179,14 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
     info["saved"] = False
     try:
         tmp = f"{path}.{os.getpid()}.tmp"
-        torch.save({"tag": tag, "model": field.state_dict(), "occs": est.occs, "binaries": est.binaries, "info": info}, tmp)
+        blob = {"tag": tag, "model": field.state_dict(), "occs": est.occs, "binaries": est.binaries, "info": dict(info)}
+        if keep_optimizer:                                        # Adam moments and step count: training can CONTINUE from here (bench.py's train leg)
+            blob["optimizer_state"] = opt.state_dict()
+        torch.save(blob, tmp)
         os.replace(tmp, path)                                     # atomic: a reader never sees a half-written file
         info["saved"] = True
     except OSError:
         pass                                                      # callers with several ranks broadcast the model instead (bench.py)
+    if keep_optimizer:
+        info["optimizer_state"] = opt.state_dict()
     return field.eval(), est.eval(), info

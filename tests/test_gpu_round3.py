@@ -111,12 +111,13 @@ def test_train_step_flags_bad_labels_and_recovers_from_small_bounds():
     RD._TRAIN_STATE[key].update(cap_m=2048, cap_k=1024)
     lazy = RD.fused_forward_backward(hip, est, RD.Rays(o, d), pix, dep, lab, None, stratified=False, sync=False, **H.RENDER_KW)
     assert int(lazy["skip"]) > 0 and int(lazy["counts"][3]) & 1 and float(hip.mlp_head.params.grad.abs().max()) == 0.0
-    for _ in range(3):                                            # marched bound first, then (if still too small) the surviving bound
-        torch.cuda.synchronize()
+    # WITHOUT any synchronisation by the caller the bounds are corrected at most two calls late (per bound: marched, then surviving)
+    skips = []
+    for _ in range(6):
         lazy = RD.fused_forward_backward(hip, est, RD.Rays(o, d), pix, dep, lab, None, stratified=False, sync=False, **H.RENDER_KW)
-        if int(lazy["skip"]) == 0:
-            break
-    assert int(lazy["skip"]) == 0 and int(lazy["n_rendering_samples"]) == n_ok
+        skips.append(lazy["skip"])
+    skips = [int(x) for x in skips]
+    assert skips[-1] == 0 and skips[-2] == 0 and int(lazy["n_rendering_samples"]) == n_ok, skips
     # rays that miss the grid: no sample, skip raised with status bit 16, zero gradients (pipeline.py:491 `continue`)
     up = torch.zeros_like(d); up[:, 1] = 1.0
     far_o = o + torch.tensor([0.0, 100.0, 0.0], device=DEV)
