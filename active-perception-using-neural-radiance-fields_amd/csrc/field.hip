@@ -50,6 +50,15 @@
 #define MNF_NT_FROM 99      /* experiment: hash levels >= this are fetched with non-temporal loads */
 #endif
 
+#if (MNF_PK == 4 || MNF_PK == 5) && !defined(MNF_BF16)
+#include "field_dev.h"
+extern "C" int mnf_debug_pk_read(unsigned int *host, int clear) {      // root-cause builds only (tools/debug_pk.py)
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(mnf::f16::g_pk_dbg), sizeof(unsigned int) * (8 * 512 + 8)) != hipSuccess) return -1;
+    if (clear) { static unsigned int zero[8 * 512 + 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(mnf::f16::g_pk_dbg), zero, sizeof(zero)); }
+    return 0;
+}
+#endif
+
 MNF_DT_BEGIN
 
 // ------------------------------------------------------------------ sample fetch (shared by the kernels below)

@@ -281,6 +281,11 @@ __device__ __forceinline__ LevelMeta level_meta(LevelsPtr lv, int l) {
                                multiplies of the blend weights (VGPR operands only) are not affected and stay on. */
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // arithmetic on it is v_pk_{mul,add,fma}_f32: two fp32 results per issue slot
+#if MNF_PK == 4 || MNF_PK == 5
+// root-cause instrumentation (tools/r03_pk.sh): [0] = number of records, then records of 8 words:
+// lane, level scale bits, x bits, y bits, packed result lo, packed result hi, scalar result hi, workgroup
+static __device__ unsigned int g_pk_dbg[8 * 512 + 8];      // (one copy per translation unit: the reader lives in field.hip's fp16 unit)
+#endif
 
 struct LevelPrep {
     uint32_t base;   // first entry of the level (wave-uniform): folded into the scalar base address of the gathers, not into every offset
@@ -292,7 +297,30 @@ struct LevelPrep {
 __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], LevelPrep &o, bool all_in_box = false) {
     // x and y as one packed pair (same operations, same rounding as the scalar form), z alone
 #if MNF_PK
-    const f32x2 pxy = __builtin_elementwise_fma(f32x2{m.scale, m.scale}, f32x2{xn[0], xn[1]}, f32x2{0.5f, 0.5f});
+    f32x2 sc2 = {m.scale, m.scale};
+#if MNF_PK == 2
+    asm volatile("" : "+v"(sc2));       // root-cause variant: the scale pair lives in VGPRs (no scalar operand on the packed op)
+#elif MNF_PK == 3
+    asm volatile("" : "+s"(sc2));       // root-cause variant: an SGPR pair with BOTH halves written (no op_sel broadcast of the low half)
+#endif
+#if MNF_PK == 5
+    asm volatile("s_nop 7\n\ts_nop 7");    // variant: 16 wait states between the scalar load of the scale and the packed instruction
+#endif
+    const f32x2 pxy = __builtin_elementwise_fma(sc2, f32x2{xn[0], xn[1]}, f32x2{0.5f, 0.5f});
+#if MNF_PK == 4 || MNF_PK == 5
+    {   // the same two products with scalar-operand v_fma_f32: any difference is recorded
+        float sx = m.scale, rx, ry;
+        asm volatile("v_fma_f32 %0, %2, %3, 0.5\n\tv_fma_f32 %1, %2, %4, 0.5" : "=&v"(rx), "=&v"(ry) : "s"(sx), "v"(xn[0]), "v"(xn[1]));
+        if (rx != pxy.x || ry != pxy.y) {
+            const unsigned k = atomicAdd(&g_pk_dbg[0], 1u);
+            if (k < 512) {
+                unsigned *r = g_pk_dbg + 8 + 8 * k;
+                r[0] = threadIdx.x & 63; r[1] = __builtin_bit_cast(unsigned, m.scale); r[2] = __builtin_bit_cast(unsigned, xn[0]); r[3] = __builtin_bit_cast(unsigned, xn[1]);
+                r[4] = __builtin_bit_cast(unsigned, pxy.x); r[5] = __builtin_bit_cast(unsigned, pxy.y); r[6] = __builtin_bit_cast(unsigned, ry); r[7] = blockIdx.x;
+            }
+        }
+    }
+#endif
     const float pz = __builtin_fmaf(m.scale, xn[2], 0.5f);
     const f32x2 fxy = {floorf(pxy.x), floorf(pxy.y)};
     const float fz = floorf(pz);

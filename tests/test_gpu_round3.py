@@ -305,3 +305,34 @@ def test_deterministic_training_is_bitwise_reproducible():
     for a, b, c in zip(*grads):
         assert torch.equal(a, c)                                   # deterministic mode: bit-identical from call to call
         assert float((a - b).norm() / a.norm().clamp_min(1e-30)) < 1e-4
+
+
+def test_field_kernels_are_bitwise_repeatable():
+    """Guard against the class of fault behind -DMNF_PK=1 (profiles/r03_pk_rootcause.txt: a timing-dependent miscompute in lanes 48..63 whose
+    hazard was not identified; the packed instruction itself was exonerated).  The inference kernels are deterministic, so any such fault shows up as
+    a run-to-run difference: every instantiation the benchmarks use (explicit positions, packed samples, density only, the renderer with fused
+    compositing, fp16 and bf16 operands) is run 40 times on the same inputs and must give bit-identical outputs."""
+    from apnrf_amd import render as RD
+    sc = H.make_scene()
+    rng = np.random.default_rng(1)
+    n = 5037
+    a = sc["aabb"]
+    pos = torch.from_numpy((rng.random((n, 3)) * (a[3:] - a[:3]) * 1.1 + a[:3] - 0.05 * (a[3:] - a[:3])).astype(np.float32)).to(DEV)
+    d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    d = torch.from_numpy(d).to(DEV)
+    o_v, d_v = H.view_rays(sc, 2, h=48, w=48)
+    o_v, d_v = o_v.to(DEV), d_v.to(DEV)
+    est = H.hip_estimator(sc)
+    for bf16 in (False, True):
+        f = H.hip_field(sc, mfma_bf16=bf16)
+        with torch.no_grad():
+            ref_f = [t.clone() for t in f(pos, d)]
+            ref_d = f.query_density(pos).clone()
+            ref_r = RD.render_views(f, est, o_v, d_v, o_v.shape[0], 1024, render_bkgd=torch.zeros(3), probabilistic=True, **H.RENDER_KW)
+            for rep in range(40):
+                got = f(pos, d)
+                assert all(torch.equal(x, y) for x, y in zip(got, ref_f)), (bf16, rep, "forward")
+                assert torch.equal(f.query_density(pos), ref_d), (bf16, rep, "density")
+                if rep % 4 == 0:
+                    r = RD.render_views(f, est, o_v, d_v, o_v.shape[0], 1024, render_bkgd=torch.zeros(3), probabilistic=True, **H.RENDER_KW)
+                    assert all(torch.equal(r[k], ref_r[k]) for k in ("rgb", "acc", "depth", "sem", "rgb_var", "depth_var", "total")), (bf16, rep, "render")

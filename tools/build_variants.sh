@@ -10,7 +10,7 @@ for spec in "$@"; do
   MNF_EXTRA_FLAGS="-DMNF_DEV_ONLY_128x2 $*" python - <<PY
 import importlib.util, os, shutil
 spec = importlib.util.spec_from_file_location("b", "$PKG/build.py"); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-m.LIB = os.path.abspath("gpurun_exp/lib_$name.so"); m.OBJ = os.path.abspath("gpurun_exp/obj_$name"); m.build(force=True)
+m.LIB = os.path.abspath("gpurun_exp/lib_$name.so"); m.LIB_DIAG = os.path.abspath("gpurun_exp/lib_${name}_diag.so"); m.OBJ = os.path.abspath("gpurun_exp/obj_$name"); m.build(force=True)
 print("built", m.LIB)
 PY
 done
