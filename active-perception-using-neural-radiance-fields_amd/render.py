@@ -291,9 +291,12 @@ def allreduce_gradients(parameters, group=None, skip=None):
     if world < 2:
         return
     for p_ in parameters:
-        if p_.grad is not None:
-            dist.all_reduce(p_.grad, op=dist.ReduceOp.SUM, group=group)
-            p_.grad.div_(world)
+        if p_.numel() == 0:
+            continue                                   # (the reference's `direction_encoding` has no parameters)
+        if p_.grad is None:                            # every rank issues the same collectives, whatever its own backward produced
+            p_.grad = torch.zeros_like(p_)
+        dist.all_reduce(p_.grad, op=dist.ReduceOp.SUM, group=group)
+        p_.grad.div_(world)
     if skip is not None:
         dist.all_reduce(skip, op=dist.ReduceOp.SUM, group=group)
 
@@ -472,7 +475,8 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
             # it contributes zero gradients and a raised skip flag.
             skip += 1
             for p_ in radiance_field.parameters():
-                p_.grad = torch.zeros_like(p_)
+                if p_.numel():
+                    p_.grad = torch.zeros_like(p_)
             loss = loss_rgb = loss_dep = loss_sem = torch.zeros((), device=dev)
         else:
             loss_rgb = F.smooth_l1_loss(rgb, pixels)

@@ -513,6 +513,11 @@ def main():
             res = {"ms_per_step": 1e3 * dt_t / steps, "steps": steps, "rays_per_step": R_, "dtype": dtype,
                    "host_round_trips_per_step": 1 if sync else 0, "rendering_samples_per_step": kept, "marched_samples_per_step": marched,
                    "skipped_steps": int(sum(int(o["skipped"]) for o in outs))}
+            # how sparse the hash-table gradient of one step is (decides whether a touched-rows exchange could beat the dense all-reduce of
+            # ray-data-parallel training): fraction of the table's entries with a non-zero gradient after the last step
+            n_mlp = tf.mlp_base.params.numel() - 4 * tf._table_entries()
+            g_tab = tf.mlp_base.params.grad[n_mlp:].view(-1, 4)
+            res["table_entries_touched_fraction"] = float((g_tab != 0).any(dim=1).float().mean())
             algo = TRAIN_BYTES_KEPT * kept + TRAIN_BYTES_MARCHED * marched
             res["roofline"] = {"bound": "hbm", "achieved": algo / (dt_t / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": algo / (dt_t / steps) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": algo,

@@ -83,7 +83,7 @@ def _grad_worker(rank, world, port, out_dir):
         p.grad = torch.randn(p.shape, generator=g)          # the third parameter has no gradient on any rank
     RD.allreduce_gradients(params)
     np.save(os.path.join(out_dir, f"grads_{rank}.npy"), torch.cat([p.grad for p in params[:2]]).numpy())
-    assert params[2].grad is None
+    assert params[2].grad is not None and float(params[2].grad.abs().max()) == 0.0      # a parameter without a gradient takes part as zeros (every rank issues the same collectives)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -160,3 +160,41 @@ def test_sharded_render_exchange_broadcast_and_placement_gloo(tmp_path):
             assert (sh["tiles_per_view"] == 1) == (V >= W)
         assert covered == list(range(V * R))
     assert DD.ensemble_placement(2, 8) == [0, 1] and DD.ensemble_placement(5, 2) == [0, 1, 0, 1, 0]
+
+
+# ------------------------------------------------------------------ every rank reaches every collective of a data-parallel step
+def _uneven_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import apnrf_amd  # noqa: F401
+    from apnrf_amd import render as RD
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # three parameter vectors + one without elements (the reference's direction_encoding); rank 1's backward "produced nothing": its
+    # gradients are None (the autograd path when a rank's rays give no sample) — it must still take part in the same collectives
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (0, 1000, 37, 5)]
+    skip = torch.zeros((), dtype=torch.int32)
+    if rank == 0:
+        g = torch.Generator().manual_seed(7)
+        for p in params:
+            if p.numel():
+                p.grad = torch.randn(p.shape, generator=g)
+    else:
+        skip += 1                                   # "no sample survived": this rank raises the step's skip flag
+    RD.allreduce_gradients(params, None, skip)
+    np.save(os.path.join(out_dir, f"uneven_{rank}.npy"), np.concatenate([p.grad.numpy() for p in params if p.numel()] + [np.array([float(skip)])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_collectives_with_an_empty_rank_two_ranks_gloo(tmp_path):
+    """`allreduce_gradients` when one rank has no gradients at all (its batch rendered no sample): both ranks issue the same collectives
+    (round 2's train_step returned early on the empty rank and left the other one inside dist.all_reduce), the averaged gradient is
+    half of rank 0's, and the summed skip flag is raised on BOTH ranks, so both leave the optimizer step out together."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_uneven_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(7)
+    want = np.concatenate([(torch.randn(n, generator=g) / 2).numpy() for n in (1000, 37, 5)] + [np.array([1.0])])
+    g0, g1 = np.load(tmp_path / "uneven_0.npy"), np.load(tmp_path / "uneven_1.npy")
+    np.testing.assert_array_equal(g0, g1)
+    np.testing.assert_allclose(g0, want, rtol=1e-6, atol=1e-7)

@@ -269,7 +269,7 @@ def test_data_parallel_step_with_an_empty_rank_does_not_hang():
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=300)[0])
+            outs.append(p.communicate(timeout=150)[0])
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
