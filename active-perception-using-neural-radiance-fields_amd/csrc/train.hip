@@ -684,7 +684,7 @@ struct TrainState {
     // the hash-table scatter (float atomics, memory-side) runs beside the weight-gradient GEMMs (matrix cores + streaming loads)
     // on a second stream of the handle: both only depend on the backward-data kernel
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_entry = nullptr;
     // deterministic mode only (allocated on first use): fixed-point table gradient + replicas, weight-gradient partial slots
     unsigned long long *d_qtable = nullptr;
     float *d_partials = nullptr;
@@ -719,6 +719,7 @@ static int ensure_train_state(mnf_field_t f) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_entry, hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error("train: %s", hipGetErrorString(e));
         delete ts;
@@ -740,6 +741,7 @@ void free_train_state_impl(mnf_field_t f) {
     if (ts->side) (void)hipStreamDestroy(ts->side);
     if (ts->ev_fork) (void)hipEventDestroy(ts->ev_fork);
     if (ts->ev_join) (void)hipEventDestroy(ts->ev_join);
+    if (ts->ev_entry) (void)hipEventDestroy(ts->ev_entry);
     delete ts;
     f->train_state = nullptr;
 }
@@ -812,6 +814,18 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         set_error("field_backward: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)v.bytes);
         return MNF_ERR_WORKSPACE;
     }
+    // The scatter's replica buffers are zeroed on the side stream while the backward-data kernel runs (behind the caller's earlier work:
+    // the workspace may have served another call on this stream a moment ago), not between that kernel and the scatter.
+    uint32_t repl_entries = 0;
+    int repl_levels = 0;
+    for (int l = 0; l < 16; ++l) {   // the leading dense levels while they stay small
+        if (f->levels[l].hashed || f->levels[l].offset != repl_entries || repl_entries + f->levels[l].size > kReplMaxEntries) break;
+        repl_entries += f->levels[l].size;
+        repl_levels = l + 1;
+    }
+    MNF_HIP(hipEventRecord(ts->ev_entry, s));
+    MNF_HIP(hipStreamWaitEvent(ts->side, ts->ev_entry, 0));
+    if (repl_levels && !deterministic) MNF_HIP(hipMemsetAsync(v.repl, 0, (size_t)kReplicas * repl_entries * 4 * sizeof(float), ts->side));
     // transposed fp16 weight fragments from the handle's forward fragments (the parameters of the last set_params)
     const int64_t n_frag = (int64_t)ts->tt.fragT.size();
     hipLaunchKernelGGL(gather_fragsT_kernel, dim3((unsigned)ceil_div(n_frag, 256)), dim3(256), 0, s, ts->d_fragT_src,
@@ -886,14 +900,8 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     int n_levels = 16;
     hb.level0 = 0;
     if (const char *e = diag_env("MNF_HASH_BWD_LEVELS")) { int lo = 0, hi = 16; if (sscanf(e, "%d,%d", &lo, &hi) == 2) { hb.level0 = lo; n_levels = hi - lo; } }
-    // replicated coarse levels: the leading dense levels while they stay small (their own region of the workspace)
-    uint32_t repl_entries = 0;
-    hb.repl_levels = 0;
-    for (int l = 0; l < 16; ++l) {
-        if (f->levels[l].hashed || f->levels[l].offset != repl_entries || repl_entries + f->levels[l].size > kReplMaxEntries) break;
-        repl_entries += f->levels[l].size;
-        hb.repl_levels = l + 1;
-    }
+    // replicated coarse levels (their own region of the workspace, zeroed above)
+    hb.repl_levels = repl_levels;
     hb.repl_floats = repl_entries * 4;
     hb.repl = v.repl;
     const size_t repl_bytes = (size_t)kReplicas * hb.repl_floats * sizeof(float);
@@ -926,7 +934,6 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         hipLaunchKernelGGL(fixed_to_float_kernel, dim3(4096), dim3(256), 0, ss, reinterpret_cast<const long long *>(hb.q_table), hb.g_table,
                            (int64_t)q_table_words, (const unsigned long long *)hb.q_bad);
     } else {
-        if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.repl, 0, repl_bytes, ss));
         if (simple) hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, ss, hb);
         else hipLaunchKernelGGL(hash_bwd_walk_kernel<false>, walk_grid, dim3(256), 0, ss, hb);
         if (hb.repl_levels)
@@ -1095,6 +1102,27 @@ extern "C" int mnf_adam_step_guarded(float *params, const float *grads, float *e
     hipLaunchKernelGGL(adam_guarded_kernel, dim3((unsigned)(blocks < 8192 ? (blocks < 1 ? 1 : blocks) : 8192)), dim3(256), 0, s, params, grads, exp_avg,
                        exp_avg_sq, n, beta1, beta2, eps, (const float *)hyper_dev, reinterpret_cast<_Float16 *>(half_out), half_from);
     return launch_status("adam_guarded_kernel");
+}
+
+// pipeline.py:520-532 for one model as ONE call: the non-finite-gradient guard over the three parameter vectors, the three Adam updates
+// (skipped on the device when the flag is raised) with the fp16 table mirror, and the handle's MLP fragments re-derived.
+extern "C" int mnf_field_optimizer_step(mnf_field_t f, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                                        float *const *exp_avg_sq_host, float *const *step_dev_host, float lr, float beta1, float beta2, float eps,
+                                        int32_t *skip_dev, int32_t count_nonfinite, float *hyper_dev, mnf_stream_t stream) {
+    MNF_REQUIRE(f && params_host && grads_host && exp_avg_host && exp_avg_sq_host && step_dev_host && hyper_dev, "field_optimizer_step: null argument");
+    MNF_REQUIRE(f->params_loaded, "field_optimizer_step: the handle holds no parameters yet (mnf_field_set_params)");
+    const int64_t n[3] = {f->n_base, f->n_head, f->n_sem};
+    int rc;
+    if (count_nonfinite) {
+        MNF_REQUIRE(skip_dev, "field_optimizer_step: counting non-finite gradients needs the skip flag");
+        for (int k = 0; k < 3; ++k) { rc = mnf_count_nan(grads_host[k], n[k], skip_dev, stream); if (rc) return rc; }
+    }
+    for (int k = 0; k < 3; ++k) {
+        rc = mnf_adam_step_guarded(params_host[k], grads_host[k], exp_avg_host[k], exp_avg_sq_host[k], n[k], lr, beta1, beta2, eps, step_dev_host[k], skip_dev,
+                                   hyper_dev + 4 * k, k == 0 ? f->d_table : nullptr, k == 0 ? f->n_base_mlp : 0, stream);
+        if (rc) return rc;
+    }
+    return mnf_field_refresh_weights(f, params_host[0], params_host[1], params_host[2], stream);
 }
 
 extern "C" int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf_stream_t stream) {

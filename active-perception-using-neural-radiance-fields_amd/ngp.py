@@ -205,6 +205,10 @@ class NGPRadianceField(torch.nn.Module):
         over the 25 M table entries), and the handle counts as current for the new parameter versions."""
         lib = L.load_library()
         L.launch(lib.mnf_field_refresh_weights, self._handle, L.ptr(self.mlp_base.params), L.ptr(self.mlp_head.params), L.ptr(self.mlp_sem.params))
+        self._mark_current()
+
+    def _mark_current(self):
+        """The handle's fp16 table and weight fragments match the parameters as they are now."""
         self._loaded_versions = (self.mlp_base.params._version, self.mlp_head.params._version, self.mlp_sem.params._version,
                                  self.mlp_base.params.data_ptr())
 

@@ -36,15 +36,53 @@ class FusedAdam(torch.optim.Optimizer):
         self._field = field
         return self
 
+    def _state_for(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if not st["step"].is_cuda or st["step"].device != p.device:      # a state_dict loaded from torch.optim.Adam keeps it on the host
+            st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+        return st
+
+    def _step_field(self, field, skip, count_nonfinite):
+        """The bound field's three vectors in ONE C call (`mnf_field_optimizer_step`): guard, three updates, fragment refresh."""
+        lib = L.load_library()
+        ps = [field.mlp_base.params, field.mlp_head.params, field.mlp_sem.params]
+        group = next(g for g in self.param_groups if any(q is ps[0] for q in g["params"]))
+        handle = field._ensure_handle()                          # holds the CURRENT parameters before they change
+        sts = [self._state_for(p) for p in ps]
+        grads = [p.grad.contiguous() for p in ps]
+        dev = ps[0].device
+        hy = self._scratch.get("field")
+        if hy is None or hy.device != dev:
+            hy = self._scratch["field"] = torch.zeros(12, dtype=torch.float32, device=dev)
+        arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        beta1, beta2 = group["betas"]
+        L.launch(lib.mnf_field_optimizer_step, handle, arr(ps), arr(grads), arr([s_["exp_avg"] for s_ in sts]), arr([s_["exp_avg_sq"] for s_ in sts]),
+                 arr([s_["step"] for s_ in sts]), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), L.ptr(skip), int(count_nonfinite), L.ptr(hy))
+        for p in ps:
+            torch.autograd.graph.increment_version(p)
+        field._mark_current()
+
     @torch.no_grad()
-    def step(self, closure=None, skip=None):
-        """`skip`: optional device int32 scalar; non-zero = leave every parameter, moment and step count untouched."""
+    def step(self, closure=None, skip=None, count_nonfinite=False):
+        """`skip`: optional device int32 scalar; non-zero = leave every parameter, moment and step count untouched.
+        `count_nonfinite=True` (needs `skip`): the NaN / Inf count of the gradients is added to `skip` first (pipeline.py:520-529)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = L.load_library()
         field = self._field
+        if field is not None and field.mlp_base.params.is_cuda and len(self.param_groups) == 1 and all(
+                p.grad is not None and p.dtype == torch.float32 and p.is_contiguous() for p in (field.mlp_base.params, field.mlp_head.params, field.mlp_sem.params)) and all(
+                q.numel() == 0 or any(q is p for p in (field.mlp_base.params, field.mlp_head.params, field.mlp_sem.params)) for q in self.param_groups[0]["params"]):
+            self._step_field(field, skip, count_nonfinite)
+            return loss
+        if count_nonfinite:
+            count_nan_gradients([p for g_ in self.param_groups for p in g_["params"]], out=skip)
         mirror, mirror_from, touched_field = None, 0, False
         if field is not None and field.mlp_base.params.is_cuda:
             handle = field._ensure_handle()                      # the handle holds the CURRENT parameters before they change
@@ -58,13 +96,7 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise L.MnfError("FusedAdam needs contiguous fp32 parameters on the GPU")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if not st["step"].is_cuda or st["step"].device != p.device:      # a state_dict loaded from torch.optim.Adam keeps it on the host
-                    st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+                st = self._state_for(p)
                 hy = self._scratch.get(p)
                 if hy is None or hy.device != p.device:
                     hy = self._scratch[p] = torch.zeros(4, dtype=torch.float32, device=p.device)

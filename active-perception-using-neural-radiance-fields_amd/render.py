@@ -376,6 +376,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         host, ev = pending.pop(0)
         ev.synchronize()
         c = host.tolist()
+        st.setdefault("pinned", []).append((host, ev))
         _check_status(c[3])
         if c[3] & _ST_ROW:
             raise L.MnfError("train_step: a ray has more samples than a scratch row holds (use the autograd path: fused=False)")
@@ -410,9 +411,9 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         estimator.last_sampling = {"n_marched": int(c[0])}
         out.update(n_rendering_samples=int(c[1]), n_marched=int(c[0]))
     else:
-        host = torch.empty(4, dtype=torch.int64).pin_memory()
+        pool = st.setdefault("pinned", [])                         # (pinned host buffer, event) pairs are recycled: at most 3 are in flight
+        host, ev = pool.pop() if pool else (torch.empty(4, dtype=torch.int64).pin_memory(), torch.cuda.Event())
         host.copy_(counts, non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         st["pending"].append((host, ev))
         estimator.last_sampling = {"n_marched": counts[0]}
@@ -486,9 +487,10 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
             loss.backward()
     if data_parallel:
         allreduce_gradients(radiance_field.parameters(), data_parallel_group, skip)
-    count_nan_gradients(radiance_field.parameters(), out=skip)                 # pipeline.py:520-529, added to the same flag
     if device_guard:
-        optimizer.step(skip=skip)                                              # leaves everything untouched when skip != 0
+        # pipeline.py:520-532: the non-finite count is added to the same flag and the update leaves everything untouched when it is
+        # raised — one C call for guard + three updates + handle refresh when the optimizer is bound to the field (`bind_field`)
+        optimizer.step(skip=skip, count_nonfinite=True)
         if not sync:
             if scheduler is not None:
                 scheduler.step()
@@ -496,6 +498,7 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
                         n_rendering_samples=n_rendering_samples, skipped=skip)
         skipped = bool(skip.item() > 0)                                        # one host round trip per iteration
     else:
+        count_nan_gradients(radiance_field.parameters(), out=skip)             # pipeline.py:520-529
         skipped = bool(skip.item() > 0)
         if skipped:
             optimizer.zero_grad()

@@ -178,6 +178,7 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
                 occupied_cells=int(est.binaries.sum()), cells=int(est.binaries.numel()), cached=False)
     info["saved"] = False
     try:
+        os.makedirs(cache_dir, mode=0o700, exist_ok=True)
         tmp = f"{path}.{os.getpid()}.tmp"
         blob = {"tag": tag, "model": field.state_dict(), "occs": est.occs, "binaries": est.binaries, "info": dict(info)}
         if keep_optimizer:                                        # Adam moments and step count: training can CONTINUE from here (bench.py's train leg)
@@ -185,7 +186,7 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
         torch.save(blob, tmp)
         os.replace(tmp, path)                                     # atomic: a reader never sees a half-written file
         info["saved"] = True
-    except OSError:
+    except (OSError, RuntimeError):
         pass                                                      # callers with several ranks broadcast the model instead (bench.py)
     if keep_optimizer:
         info["optimizer_state"] = opt.state_dict()

@@ -587,11 +587,16 @@ def main():
         group = dist.group.WORLD if distributed else None
         t_parts = {"compute": 0.0, "gather": 0.0, "n": 0}
 
-        def score_args(p):
-            return ([f0, f1], [e0, e1], p, 640, 640, 320.0, 0.1, 1e-3, 0.1, 0.004, 0.01, dev)
+        score_samples = torch.zeros((), dtype=torch.int64, device=dev)       # every sample this process evaluated while scoring (PMC sums cover all launches)
+
+        def score_call(p, group):
+            r = RD.score_views([f0, f1], [e0, e1], p, 640, 640, 320.0, 0.1, 1e-3, 0.1, 0.004, 0.01, dev, group=group)
+            for t in RD.LAST_SCORE_TOTALS:
+                score_samples.add_(t[1])
+            return r
 
         def sstep(i):
-            return RD.score_views(*score_args(poses256), group=group)
+            return score_call(poses256, group)
 
         def sstep_parts(i):
             """the same pass with the two phases timed apart on this rank (synchronises between them: diagnosis, not the headline)"""
@@ -599,7 +604,7 @@ def main():
             lo, hi, per = RD.shard_views(256, world, rank)
             local = torch.zeros(per, 4, dtype=torch.float64, device=dev)
             if hi > lo:
-                terms, _ = RD.score_views(*score_args(poses256[lo:hi]), group=False)
+                terms, _ = score_call(poses256[lo:hi], False)
                 local[:hi - lo] = terms
             torch.cuda.synchronize(); t1 = time.perf_counter()
             RD.gather_view_terms(local, 256, group)
@@ -627,7 +632,7 @@ def main():
                           "space, 64x64 rays each (linspace sub-sample of 640x640), probabilistic render + predictive-information terms; the two "
                           "ensemble members advance side by side as render jobs of one call"}
         if world > 1:
-            full, _ = RD.score_views(*score_args(poses256), group=False)
+            full, _ = score_call(poses256, False)
             same = bool(torch.equal(full, terms))
             sc["bit_identical_to_single_gpu"] = same
             if not same:
@@ -638,7 +643,7 @@ def main():
             lo, hi, _ = RD.shard_views(256, 8, 0)
 
             def shard_step(i):
-                return RD.score_views(*score_args(poses256[lo:hi]), group=False)
+                return score_call(poses256[lo:hi], False)
             dt8 = timed(shard_step, ssteps, 1, False)
             t8, _ = shard_step(0)
             ev8 = float(sum(int(t[1]) for t in RD.LAST_SCORE_TOTALS))
@@ -646,6 +651,7 @@ def main():
                                        "ratio_to_full_over_8": (dt8 / ssteps) / (dt_s / ssteps / 8),
                                        "bit_identical_to_full_pass_rows": bool(torch.equal(t8, terms[lo:hi])),
                                        "note": "views 0..31 of the same pass on one GPU = the per-rank work of --gpus 8; predicted 8-GPU pass = this + one 8 KB all-gather"}
+        sc["process_samples"] = int(score_samples.item())
         if not want("render800") and not want("train"):
             line.update({"metric": "candidate-view scoring rays/s", "value": sc["rays_per_s"], "ms_per_step": sc["ms_per_pass"], "scaling": "strong"})
             line["config"]["workload"] = sc["workload"]

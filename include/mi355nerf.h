@@ -135,6 +135,14 @@ int mnf_adam_step_guarded(float *params, const float *grads, float *exp_avg, flo
                           float beta2, float eps, float *step_dev, const int32_t *skip_dev, float *hyper_dev, void *half_out,
                           int64_t half_from, mnf_stream_t stream);
 
+/* scripts/pipeline.py:520-532 for one model as ONE call: non-finite-gradient guard over the three parameter vectors of a field (added to
+ * *skip_dev when count_nonfinite != 0), the three mnf_adam_step_guarded updates (mlp_base / mlp_head / mlp_sem, in that order: host arrays
+ * of 3 device pointers each; the hash table's fp16 mirror in the handle is written by the update), then the handle's MLP weight fragments
+ * are re-derived: after the call the handle is current for the new parameters.  hyper_dev: 12 device floats of scratch. */
+int mnf_field_optimizer_step(mnf_field_t f, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                             float *const *exp_avg_sq_host, float *const *step_dev_host, float lr, float beta1, float beta2, float eps,
+                             int32_t *skip_dev, int32_t count_nonfinite, float *hyper_dev, mnf_stream_t stream);
+
 /* Adds the number of NaN / Inf entries of `values` to *count (device int32): the gradient guard of pipeline.py:520-529. */
 int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf_stream_t stream);
 
