@@ -46,7 +46,12 @@ class Dataset(torch.utils.data.Dataset):
 
     def update_data(self, images, depths, semantics, camtoworlds):
         """habitat_to_data.py:89-153 (uint8 images [N,H,W,C], f32 depths, int64 semantics, f32 poses, on device)."""
-        new_images = torch.from_numpy(np.asarray(images)).to(torch.uint8).to(self.device)
+        img_np = np.asarray(images)
+        if img_np.ndim != 4 or img_np.shape[-1] != 3:
+            # the pixel gather reads 3 bytes per pixel (mnf_gather_pixels); an RGBA capture (Habitat's colour sensor before pipeline.py's
+            # [..., :3] slice) would be read with the wrong stride and give garbage colours without any error
+            raise ValueError(f"Dataset.update_data expects uint8 images [N,H,W,3] (got shape {tuple(img_np.shape)}): slice RGBA captures with [..., :3]")
+        new_images = torch.from_numpy(img_np).to(torch.uint8).to(self.device)
         new_depths = torch.from_numpy(np.asarray(depths)).to(torch.float16 if self.packed else torch.float32).to(self.device)
         sem_np = np.asarray(semantics)
         if self.packed and (sem_np.min() < 0 or sem_np.max() > 255):

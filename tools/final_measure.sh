@@ -22,19 +22,20 @@ fi
 pmc() {   # pmc <tag> <workload args> -- <counters...>
   tag=$1; shift; args=(); while [[ "$1" != "--" ]]; do args+=("$1"); shift; done; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/pmc_$tag -- python3 bench.py "${args[@]}" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-views1 > $out/pmc_$tag.json 2> $out/pmc_$tag.err
-  find $out/pmc_$tag -name "*counter_collection.csv" -exec cp {} $out/pmc_${tag}_counter_collection.csv \;
+  find $out/pmc_$tag -name "*counter_collection.csv" -exec cp {} /tmp/pmc_${tag}_counter_collection.csv \;      # raw rows stay on the box (tens of MB)
+  python tools/sum_pmc.py /tmp/pmc_${tag}_counter_collection.csv > $out/pmc_${tag}_per_kernel.csv
   rm -rf $out/pmc_$tag
 }
 if has pmc; then
   pmc fetch --workload render800 -- FETCH_SIZE
   pmc write --workload render800 -- WRITE_SIZE
   pmc sq --workload render800 -- SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY
-  python tools/reduce_pmc.py $out/pmc_fetch_counter_collection.csv $out/pmc_write_counter_collection.csv $out/pmc_fetch.json $out/r03_pmc.json "field_kernel<128, 2, 2, false, false" field_kernel
+  python tools/reduce_pmc.py /tmp/pmc_fetch_counter_collection.csv /tmp/pmc_write_counter_collection.csv $out/pmc_fetch.json $out/r03_pmc.json "field_kernel<128, 2, 2, false, false" field_kernel
 fi
 if has pmc_score; then
   pmc score_fetch --workload score256 -- FETCH_SIZE
   pmc score_write --workload score256 -- WRITE_SIZE
   pmc score_sq --workload score256 -- SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY
-  python tools/reduce_pmc.py $out/pmc_score_fetch_counter_collection.csv $out/pmc_score_write_counter_collection.csv $out/pmc_score_fetch.json $out/r03_pmc.json "field_kernel<128, 2, 2, false, false" field_kernel_scoring
+  python tools/reduce_pmc.py /tmp/pmc_score_fetch_counter_collection.csv /tmp/pmc_score_write_counter_collection.csv $out/pmc_score_fetch.json $out/r03_pmc.json "field_kernel<128, 2, 2, false, false" field_kernel_scoring
 fi
 ls $out
