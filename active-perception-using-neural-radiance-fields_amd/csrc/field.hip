@@ -757,6 +757,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
 int launch_field_impl(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train) {
     MNF_REQUIRE(f && f->params_loaded, "field: parameters not loaded (call mnf_field_set_params first)");
     int grid = 256;  // one persistent workgroup per CU (LDS-limited), grid-stride over 64-sample tiles
+    if (io.mode == 2 && io.grid_limit > 0 && io.grid_limit < grid) grid = io.grid_limit;
     if (io.mode != 2 && io.mode != 3) {
         const int64_t tiles = ceil_div(io.n, kWaveSamples);
         if (tiles == 0) return MNF_OK;

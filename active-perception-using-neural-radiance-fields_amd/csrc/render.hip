@@ -600,6 +600,18 @@ int run_jobs(std::vector<RenderJob> &jobs) {
     int block = jobs[0].opts.sync_every > 0 ? jobs[0].opts.sync_every : 1 << 30;
     if (round_log()) block = 1 << 30;
     bool any = true;
+    // Negative result kept as a diagnostic (MNF_JOB_SHARE=1, profiles/r03_split_experiment.txt): giving every job's field launch 256 / (jobs running)
+    // workgroups, so that the jobs' field kernels run BESIDE each other, is slower everywhere (800x800 x4: 61.2 -> 65.8 ms with two jobs, 111 ms with four;
+    // scoring 106.9 -> 114.1 ms; 32 views 22.7 -> 23.7 ms): the half-sized launches take twice as long and do not overlap accordingly.
+    auto share = [&]() {
+        static const bool on = diag_env("MNF_JOB_SHARE") != nullptr;
+        if (!on) return;
+        int running = 0;
+        for (auto &j : jobs) running += !j.done;
+        int g = running > 1 ? 256 / running : 0;
+        g = g ? (g / 8) * 8 : 0;
+        for (auto &j : jobs) j.io.grid_limit = g && g < 32 ? 32 : g;
+    };
 #ifdef MNF_DIAG
     const bool host_log = diag_env("MNF_HOST_LOG") != nullptr;     // host time spent enqueuing vs waiting (diagnostic)
     double t_enq = 0.0, t_wait = 0.0; int n_rounds = 0;
@@ -610,6 +622,7 @@ int run_jobs(std::vector<RenderJob> &jobs) {
         const double t0 = now();
         for (auto &j : jobs) n_rounds -= j.round;
 #endif
+        share();
         for (auto &j : jobs) if (!j.done) { int rc = job_enqueue_block(j, block); if (rc) return rc; }
 #ifdef MNF_DIAG
         const double t1 = now();
