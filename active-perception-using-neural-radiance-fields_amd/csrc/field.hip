@@ -849,7 +849,7 @@ extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
     f->frag_src_host = table;
     f->d_table = nullptr; f->d_frags = nullptr; f->d_frag_src = nullptr; f->params_loaded = false; f->d_counter = nullptr;
     f->train_state = nullptr;
-    hipError_t e = hipMalloc(&f->d_table, (size_t)f->table_entries * 4 * sizeof(uint16_t) );
+    hipError_t e = hipMalloc(&f->d_table, (size_t)f->table_entries * 4 * sizeof(uint16_t) + 64);   // (+ slack: a paired 16-byte gather may start at a level's last entry)
     if (e == hipSuccess) e = hipMalloc(&f->d_frags, table.size() * sizeof(uint16_t) + sizeof(LevelMeta) * 16);
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_frag_src, table.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(f->d_frag_src, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice);

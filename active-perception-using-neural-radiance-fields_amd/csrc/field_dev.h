@@ -287,7 +287,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));   // arithmetic on it i
 static __device__ unsigned int g_pk_dbg[8 * 512 + 8];      // (one copy per translation unit: the reader lives in field.hip's fp16 unit)
 #endif
 
+#ifndef MNF_PAIR_DENSE
+#define MNF_PAIR_DENSE 0     /* 1: dense levels fetch the two x-neighbour corners of a cell (adjacent table entries) with ONE 16-byte gather per pair: 4 instead of 8
+                               lane-loads per dense level, 108 instead of 128 per sample.  Measured on MI355X (round 3, tools/r03_ab.sh): no change -- 800x800 render
+                               37.86 vs 37.63 M rays/s, random-weight leg 148.95 vs 149.4, field kernel 0.7139 vs 0.7117 ms per launch; results bit-identical.  The L1's
+                               divergent-lane rate is not what limits the kernel.  Kept off (8 % more code). */
+#endif
+typedef _Float16 tab8 __attribute__((ext_vector_type(8), aligned(8)));      // two adjacent entries: a 16-byte load that is only 8-byte aligned
+
 struct LevelPrep {
+    uint32_t paired; // wave-uniform: this level's corners are fetched as four x-neighbour pairs (dense level, every pair contiguous)
     uint32_t base;   // first entry of the level (wave-uniform): folded into the scalar base address of the gathers, not into every offset
     uint32_t off[8]; // byte offset of each corner's entry inside the level
     f32x2 wxy[2];    // {wx0*wy0, wx1*wy0}, {wx0*wy1, wx1*wy1}
@@ -344,6 +353,7 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
     // ONE wave-uniform branch per level (hashed levels: size is 2^k; dense levels wrap the index as tcnn does).  Written as
     // two corner loops: with the test inside a single loop the compiler kept a scalar branch per corner.
     o.base = m.offset;
+    o.paired = 0;
     if (m.hashed) {
         const uint32_t ty0 = cell[1] * 2654435761u, ty1 = ty0 + 2654435761u;   // per-axis terms, shared by the four corners that use them
         const uint32_t tz0 = cell[2] * 805459861u, tz1 = tz0 + 805459861u;
@@ -368,6 +378,12 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
                 const uint32_t idx = cell[0] + (uint32_t)(corner & 1) + ((corner >> 1) & 1 ? ty1 : ty0) + ((corner >> 2) ? tz1 : tz0);
                 o.off[corner] = min(idx, idx - m.size) * 8u;
             }
+#if MNF_PAIR_DENSE
+            // corners (x, y, z) and (x+1, y, z) are entries idx and idx+1 unless the index wraps between them (only at the far corner of the level):
+            // when no lane of the wave has such a pair the level is fetched as four 16-byte gathers
+            const bool split = (o.off[1] != o.off[0] + 8u) | (o.off[3] != o.off[2] + 8u) | (o.off[5] != o.off[4] + 8u) | (o.off[7] != o.off[6] + 8u);
+            o.paired = __ballot(split) == 0ull ? 1u : 0u;
+#endif
         } else {
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
@@ -383,6 +399,17 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
 
 __device__ __forceinline__ void hash_load(const tab4 *__restrict__ table, const LevelPrep &p, tab4 (&v)[8], bool stream = false) {
     const char *level = reinterpret_cast<const char *>(table + p.base);      // uniform: scalar address arithmetic
+#if MNF_PAIR_DENSE
+    if (p.paired) {   // wave-uniform
+#pragma unroll
+        for (int pair = 0; pair < 4; ++pair) {
+            const tab8 two = *reinterpret_cast<const tab8 *>(level + p.off[2 * pair]);
+            v[2 * pair] = {two[0], two[1], two[2], two[3]};
+            v[2 * pair + 1] = {two[4], two[5], two[6], two[7]};
+        }
+        return;
+    }
+#endif
     if (stream) {   // wave-uniform: a level whose lines are not worth keeping in L2 (experiment: MNF_NT_FROM)
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner)
