@@ -37,7 +37,7 @@ class RenderOpts(ctypes.Structure):
     _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float),
                 ("cone_angle", c_float), ("alpha_thre", c_float), ("early_stop_eps", c_float),
                 ("render_bkgd", c_float * 3), ("max_samples", c_int32), ("probabilistic", c_int32),
-                ("rays_per_view", c_int32), ("sync_every", c_int32), ("view_order", c_void_p), ("bitgrid", c_void_p)]
+                ("rays_per_view", c_int32), ("sync_every", c_int32), ("view_order", c_void_p), ("bitgrid", c_void_p), ("n_levels", c_int32)]
 
 
 class RenderJob(ctypes.Structure):

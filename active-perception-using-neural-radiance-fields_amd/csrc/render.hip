@@ -172,26 +172,31 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
 }
 
 // bit-pack the [X,Y,Z] byte grid once per call: word w holds cells 32w .. 32w+31
-__global__ void __launch_bounds__(256) pack_grid_kernel(const uint8_t *__restrict__ binaries, int64_t cells, uint32_t *__restrict__ bits, int n_words) {
+// (per level: n_words = levels * words_per_level, level l's cells start at binaries + l * cells and at word l * words_per_level)
+__global__ void __launch_bounds__(256) pack_grid_kernel(const uint8_t *__restrict__ binaries, int64_t cells, uint32_t *__restrict__ bits, int n_words, int words_per_level) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
+    const int lvl = w / words_per_level, wl = w - lvl * words_per_level;
     uint32_t v = 0;
     for (int b = 0; b < 32; ++b) {
-        const int64_t c = (int64_t)w * 32 + b;
-        if (c < cells && binaries[c]) v |= 1u << b;
+        const int64_t c = (int64_t)wl * 32 + b;
+        if (c < cells && binaries[(int64_t)lvl * cells + c]) v |= 1u << b;
     }
     bits[w] = v;
 }
 
+// aabbs of the occupancy levels, by value (<= 4 levels)
+struct LevelBoxes { float ab[4][6]; int32_t n, words_per_level; };
+
 // utils.py:674-696: one traversal of <= n_samples steps per alive ray (over-allocated mode of grid.cu:364-404).
 // The occupancy grid is read from a bit-packed copy staged in LDS (<= 64 KB) once per workgroup.
-template <bool LDS_GRID>
+template <bool LDS_GRID, bool MULTI>
 __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_rays, int32_t rays_per_view,
                                                                     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                                     const uint8_t *__restrict__ binaries, I3 res, int n_words,
                                                                     float a0, float a1, float a2, float a3, float a4, float a5,
                                                                     float far_plane, float step_size, float cone_angle, RenderWs ws,
-                                                                    const int32_t *__restrict__ view_order, int32_t blocks_per_view) {
+                                                                    const int32_t *__restrict__ view_order, int32_t blocks_per_view, LevelBoxes boxes) {
     __shared__ int s_wave_tot[kMarchThreads / 64], s_wave_max[kMarchThreads / 64];
     __shared__ int s_base, s_stride, s_total;
     __shared__ uint32_t s_bits[LDS_GRID ? kMaxGridWords : 1];
@@ -287,7 +292,41 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
     const float near_plane = ray_near;
     MarchState st = {near_plane, false, 0};
     RoundSink sink = {ws.col_ts, ws.col_te, col0};
-    if (ray_hit) {   // single grid level: the only interval is [t_min, t_max] (grid.cu:125-151 with n_grids == 1)
+    if (MULTI) {
+        // several occupancy levels (grid.cu:125-151): the 2L entry / exit distances of the level boxes, sorted (stable: ties keep the order
+        // [t_min of level 0.., t_max of level 0..], as the oracle's argsort), cut the ray into segments; a segment that begins where a level is
+        // entered is marched on that level, one that begins where a level is left is marched on the level left next — if the ray is inside it
+        const int L = boxes.n;
+        const int64_t cells = (int64_t)res.x * res.y * res.z;
+        float tv[8]; int ti[8]; bool lhit[4];
+        for (int l = 0; l < L; ++l) {
+            float t0, t1;
+            lhit[l] = ray_aabb(org, inv, -INFINITY, INFINITY, boxes.ab[l], t0, t1);   // utils.py:658 (default near / far), misses -> +inf
+            tv[l] = lhit[l] ? t0 : INFINITY; tv[L + l] = lhit[l] ? t1 : INFINITY;
+            ti[l] = l; ti[L + l] = L + l;
+        }
+        for (int a = 1; a < 2 * L; ++a) {   // stable insertion sort of <= 8 values
+            const float v = tv[a]; const int id = ti[a];
+            int b = a - 1;
+            while (b >= 0 && tv[b] > v) { tv[b + 1] = tv[b]; ti[b + 1] = ti[b]; --b; }
+            tv[b + 1] = v; ti[b + 1] = id;
+        }
+        for (int i = 0; i < 2 * L - 1; ++i) {
+            const bool is_entering = ti[i] < L;
+            int level = ti[i] % L;
+            if (!lhit[level]) continue;
+            if (!is_entering) {
+                if (ti[i + 1] < L) continue;
+                level = ti[i + 1] % L;
+                if (!lhit[level]) continue;
+            }
+            const float this_tmin = fmaxf(tv[i], near_plane);
+            const float this_tmax = fminf(tv[i + 1], far_plane);
+            if (this_tmin >= this_tmax) continue;
+            if (LDS_GRID) march_segment(org, dir, inv, this_tmin, this_tmax, boxes.ab[level], res, BitGrid{s_bits + level * boxes.words_per_level}, step_size, cone_angle, ns, st, sink);
+            else march_segment(org, dir, inv, this_tmin, this_tmax, boxes.ab[level], res, ByteGrid{binaries + level * cells}, step_size, cone_angle, ns, st, sink);
+        }
+    } else if (ray_hit) {   // single grid level: the only interval is [t_min, t_max] (grid.cu:125-151 with n_grids == 1)
         const float this_tmin = fmaxf(ray_tmin, near_plane);
         const float this_tmax = fminf(ray_tmax, far_plane);
         if (this_tmin < this_tmax) {
@@ -453,6 +492,7 @@ struct RenderJob {
     JobRes *res;
     I3 grid;
     float ab[6];
+    LevelBoxes boxes;
     int n_words, max_rounds, round;
     bool lds_grid, done, flags_pending;
     int32_t n_views, bpv, min_samples, C;
@@ -482,18 +522,24 @@ int job_begin(RenderJob &j, mnf_field_t f, const uint8_t *binaries, int32_t res_
     j.n_views = (int32_t)(n_rays / opts->rays_per_view);
     j.C = f->cfg.num_semantic_classes;
     const int ray_blocks = (int)ceil_div(n_rays > j.n_views ? n_rays : j.n_views, kRayThreads);
+    const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
+    MNF_REQUIRE(n_levels <= 4, "render_test: at most 4 occupancy levels (got %d)", n_levels);
     for (int k = 0; k < 6; ++k) j.ab[k] = aabb_host[k];
+    for (int l = 0; l < n_levels; ++l)
+        for (int k = 0; k < 6; ++k) j.boxes.ab[l][k] = aabb_host[6 * l + k];
+    j.boxes.n = n_levels;
     const float *ab = j.ab;
     j.grid = {res_x, res_y, res_z};
     j.min_samples = opts->cone_angle == 0.f ? 1 : 4;                                  // utils.py:645
     if (const char *e = diag_env("MNF_MIN_SAMPLES")) j.min_samples = atoi(e);   // diagnostic only (locality experiments): NOT the reference's schedule
     const float opc_thre = 1.0f - opts->early_stop_eps;                                // utils.py:664
     const int64_t cells = (int64_t)res_x * res_y * res_z;
-    j.n_words = (int)ceil_div(cells, 32);
+    j.boxes.words_per_level = (int)ceil_div(cells, 32);
+    j.n_words = j.boxes.words_per_level * n_levels;          // every level's bits side by side in LDS
     j.lds_grid = j.n_words <= kMaxGridWords;
     if (j.lds_grid) {
         if (opts->bitgrid) j.ws.bitgrid = const_cast<uint32_t *>(opts->bitgrid);   // the estimator's own packed grid: nothing to build
-        else hipLaunchKernelGGL(pack_grid_kernel, dim3((int)ceil_div(j.n_words, 256)), dim3(256), 0, s, binaries, cells, j.ws.bitgrid, j.n_words);
+        else hipLaunchKernelGGL(pack_grid_kernel, dim3((int)ceil_div(j.n_words, 256)), dim3(256), 0, s, binaries, cells, j.ws.bitgrid, j.n_words, j.boxes.words_per_level);
     }
     MNF_HIP(hipMemsetAsync(sem, 0, (size_t)n_rays * j.C * sizeof(float), s));   // [R,C] accumulators: one streaming fill
     hipLaunchKernelGGL(init_kernel, dim3(ray_blocks), dim3(kRayThreads), 0, s, n_rays, opts->rays_per_view, j.C, rays_o, rays_d,
@@ -535,14 +581,12 @@ int job_enqueue_block(RenderJob &j, int block) {
             j.flags_pending = true;
         }
         if (round_log()) MNF_HIP(hipEventRecord(log_events()[2], s));
-        if (j.lds_grid)
-            hipLaunchKernelGGL(round_march_kernel<true>, dim3(march_grid), dim3(kMarchThreads), 0, s, j.n_rays,
-                               opts->rays_per_view, j.rays_o, j.rays_d, j.binaries, j.grid, j.n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
-                               opts->far_plane, opts->render_step_size, opts->cone_angle, j.ws, opts->view_order, j.bpv);
-        else
-            hipLaunchKernelGGL(round_march_kernel<false>, dim3(march_grid), dim3(kMarchThreads), 0, s, j.n_rays,
-                               opts->rays_per_view, j.rays_o, j.rays_d, j.binaries, j.grid, j.n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5],
-                               opts->far_plane, opts->render_step_size, opts->cone_angle, j.ws, opts->view_order, j.bpv);
+#define MNF_MARCH(LDS, ML) hipLaunchKernelGGL((round_march_kernel<LDS, ML>), dim3(march_grid), dim3(kMarchThreads), 0, s, j.n_rays, opts->rays_per_view, j.rays_o, \
+                                             j.rays_d, j.binaries, j.grid, j.n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], opts->far_plane,                  \
+                                             opts->render_step_size, opts->cone_angle, j.ws, opts->view_order, j.bpv, j.boxes)
+        if (j.boxes.n > 1) { if (j.lds_grid) MNF_MARCH(true, true); else MNF_MARCH(false, true); }
+        else { if (j.lds_grid) MNF_MARCH(true, false); else MNF_MARCH(false, false); }
+#undef MNF_MARCH
         if (round_log()) MNF_HIP(hipEventRecord(log_events()[3], s));
         int rc;
         {

@@ -39,15 +39,26 @@ def release_workspaces():
     _WORKSPACES.clear()
 
 
-def _single_level(estimator):
-    """-> (binaries u8 [1,X,Y,Z] on device, aabb as 6 host floats).  The host copy of the aabb lives on the estimator
-    and is refreshed when the tensor changes (`OccGridEstimator.aabb_host`), so a render call does not synchronise."""
-    if estimator.binaries.shape[0] != 1:
-        raise NotImplementedError("the fused renderer supports one occupancy level (the reference configs use "
-                                  "main_grid_nlvl: 1); use nerfacc.traverse_grids for multi-level grids")
+def _grid_levels(estimator, max_levels=4):
+    """-> (binaries u8 [L,X,Y,Z] on device, the L aabbs as one flat list of 6 L host floats).  The host copy of the aabbs lives on the
+    estimator and is refreshed when the tensor changes (`OccGridEstimator.aabb_host`), so a render call does not synchronise."""
+    L_ = int(estimator.binaries.shape[0])
+    if L_ > max_levels:
+        raise NotImplementedError(f"the fused renderer supports up to {max_levels} occupancy levels (got {L_}); use nerfacc.traverse_grids")
     b = estimator.binaries
     b = b.contiguous().view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8).contiguous()
-    return b, estimator.aabb_host(0)
+    aabb = []
+    for lvl in range(L_):
+        aabb += list(estimator.aabb_host(lvl))
+    return b, aabb
+
+
+def _single_level(estimator):
+    """One-level form (the fused train step and `mnf_score_poses` take one level: the reference configs use main_grid_nlvl: 1)."""
+    if estimator.binaries.shape[0] != 1:
+        raise NotImplementedError("this fused path supports one occupancy level (the reference configs use main_grid_nlvl: 1); "
+                                  "multi-level grids: the fused renderer (render_views / render_image_with_occgrid_test) and the autograd training route")
+    return _grid_levels(estimator, 1)
 
 
 _VIEW_ORDERS = {}
@@ -98,7 +109,7 @@ def _render_jobs(specs, rpv, max_samples, near_plane, far_plane, render_step_siz
             raise L.MnfError(f"n_rays ({n}) must be a positive multiple of rays_per_view ({rpv})")
         C = radiance_field.num_semantic_classes
         handle = radiance_field._ensure_handle()
-        binaries, aabb = _single_level(estimator)
+        binaries, aabb = _grid_levels(estimator)
         L.require_gpu(binaries)
         if grid0 is None:
             grid0 = (tuple(binaries.shape[1:]), tuple(aabb))
@@ -136,8 +147,9 @@ def _render_jobs(specs, rpv, max_samples, near_plane, far_plane, render_step_siz
     if jobs:
         arr = (L.RenderJob * len(jobs))(*jobs)
         res, aabb = grid0
+        opts.n_levels = len(aabb) // 6
         anchor = L.ptr(specs[0][2])                  # device guard + stream of the GPU that owns the rays
-        L.launch(lib.mnf_render_jobs, arr, len(jobs), res[0], res[1], res[2], (ctypes.c_float * 6)(*aabb), ctypes.byref(opts), _Anchor(anchor))
+        L.launch(lib.mnf_render_jobs, arr, len(jobs), res[0], res[1], res[2], (ctypes.c_float * len(aabb))(*aabb), ctypes.byref(opts), _Anchor(anchor))
     for out in outs:
         out["total"] = out.pop("_totals").sum(0)
     return outs

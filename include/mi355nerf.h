@@ -404,7 +404,11 @@ typedef struct {
                                 neighbours in this order (e.g. 8x8 pixel blocks instead of one-pixel-high strips) so that
                                 a tile's samples share hash-table lines. */
     const uint32_t *bitgrid; /* optional (NULL = packed from `binaries` at the start of the call): the bit-packed form of
-                                `binaries` that mnf_occ_binarize / mnf_pack_bitgrid maintain (bit c & 31 of word c >> 5) */
+                                `binaries` that mnf_occ_binarize / mnf_pack_bitgrid maintain (bit c & 31 of word c >> 5;
+                                [n_levels][ceil(cells / 32)] words) */
+    int32_t n_levels;        /* occupancy levels (occ_grid.py:37-55: level l covers the roi enlarged 2^l times); 0 or 1 = one level.
+                                With n_levels > 1 `binaries` is [n_levels,X,Y,Z], `aabb_host` holds n_levels x 6 floats
+                                (estimator.aabbs) and a ray's segments are taken level by level as grid.cu:125-151 does (<= 4 levels) */
 } mnf_render_opts;
 
 /* bytes of workspace mnf_render_test needs for n_rays rays */
