@@ -225,7 +225,7 @@ __device__ __forceinline__ void fused_composite_slots(const FusedRender &fr, int
     const float w = expf(-excl) * (1.0f - opac0) * alpha;
     const bool keep = sm.valid && !(fr.alpha_thre > 0.f && !(alpha >= fr.alpha_thre));
     const float wk = keep ? w : 0.0f;
-    const float tmid = (sm.ts + sm.te) / 2.0f;
+    const float tmid = sm.valid ? (sm.ts + sm.te) / 2.0f : 0.0f;   // an unused column holds whatever the workspace held before: 0 * NaN would poison the depth of its ray
     float tot[6] = {wk, wk * rgb[0], wk * rgb[1], wk * rgb[2], wk * tmid, sm.valid ? 1.0f : 0.0f};
     slot_totals<6>(tot, stride);
     const int cnt = (int)(tot[5] + 0.5f);
@@ -313,7 +313,7 @@ __device__ __forceinline__ void fused_composite(const FusedRender &fr, int C, in
     const float w = expf(-excl) * (1.0f - opac0) * alpha;               // volrend.py:258-267, :361-365; utils.py:712
     const bool keep = sm.valid && !(fr.alpha_thre > 0.f && !(alpha >= fr.alpha_thre));   // utils.py:714-725
     const float wk = keep ? w : 0.0f;
-    const float tmid = (sm.ts + sm.te) / 2.0f;
+    const float tmid = sm.valid ? (sm.ts + sm.te) / 2.0f : 0.0f;   // an unused column holds whatever the workspace held before: 0 * NaN would poison the depth of its ray
     // ---- per-ray sums of the lane=sample quantities ----
     float acc5[7] = {wk, wk * rgb[0], wk * rgb[1], wk * rgb[2], wk * tmid, keep ? 1.0f : 0.0f, sm.valid ? 1.0f : 0.0f};
     seg_scan_dpp<7>(acc5, heads, lane, maxlen);

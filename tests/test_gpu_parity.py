@@ -1414,7 +1414,7 @@ def test_fused_train_step_equals_call_by_call_path():
     out = RD.fused_forward_backward(b, est, rays, pix, dep, lab, bk, stratified=False, **H.RENDER_KW)
     assert out is not None and out["n_rendering_samples"] == n and out["n_marched"] >= n
     for got, want in ((out["loss_rgb"], l_rgb), (out["loss_dep"], l_dep), (out["loss_sem"], l_sem), (out["loss"], l_rgb * 10 + l_dep / 5 + l_sem / 2)):
-        np.testing.assert_allclose(float(got), float(want), rtol=2e-5)
+        np.testing.assert_allclose(float(got.detach()), float(want.detach()), rtol=2e-5)
     for pa, pb, name in zip(a.parameters(), b.parameters(), ("dir", "base", "head", "sem")):
         if pa.numel():
             _grad_close(pb.grad, pa.grad.cpu(), name, rel=2e-3, cos=0.99999)

@@ -365,6 +365,8 @@ def test_multi_level_occupancy_render_matches_oracle(levels, prob):
     assert ref["total_samples"] > 5000 and len(ref["rounds"]) > 3
     assert abs(int(out["total"][0]) - ref["total_samples"]) <= max(3, 2e-3 * ref["total_samples"])
     for k in ("rgb", "acc", "depth", "sem") + (("rgb_var", "depth_var") if prob else ()):
+        assert bool(torch.isfinite(out[k]).all()) and bool(torch.isfinite(ref[k]).all()), (k, "non-finite", int((~torch.isfinite(out[k])).sum()), int((~torch.isfinite(ref[k])).sum()),
+                                                                                          (~torch.isfinite(out[k].cpu().reshape(o.shape[0], -1))).any(1).nonzero().flatten().tolist()[:8])
         err = (out[k].cpu() - ref[k]).abs().reshape(o.shape[0], -1).max(dim=1).values
         assert int((err > 1e-3).sum()) <= 2 and float(err.max()) < 5e-2, (k, float(err.max()), int((err > 1e-3).sum()))
     # samples come from more than one level: rays that start inside level 0 and leave it keep marching through level 1
@@ -373,3 +375,40 @@ def test_multi_level_occupancy_render_matches_oracle(levels, prob):
     one.binaries = torch.from_numpy(occ[:1]); one = one.to(DEV).eval()
     near_only = RD.render_views(H.hip_field(field_scene), one, o.to(DEV), d.to(DEV), o.shape[0], 1024, render_bkgd=bk, **H.RENDER_KW)
     assert int(far["total"][1]) > int(near_only["total"][1])
+
+
+def test_results_do_not_depend_on_stale_workspace_contents():
+    """The cached scratch buffers are never cleared between calls and their layout changes with the call's size, so an unused column can hold
+    anything: all-ones bytes are NaN as floats and -1 as ray ids.  Found by the multi-level test when it ran after the rest of the suite: a depth of
+    0 * NaN.  Render (both modes), scoring and the fused train step (deterministic accumulation) are run, every cached workspace is overwritten
+    with 0xFF, and the same calls must give bit-identical, finite results."""
+    from apnrf_amd import render as RD
+    sc = H.make_scene(log2_hashmap_size=15)
+    hip, est = H.hip_field(sc), H.hip_estimator(sc)
+    o, d = H.view_rays(sc, 1, h=40, w=40)
+    o, d = o.to(DEV), d.to(DEV)
+    o3 = torch.cat([H.view_rays(sc, i, h=20, w=20)[0] for i in range(3)]).to(DEV)
+    d3 = torch.cat([H.view_rays(sc, i, h=20, w=20)[1] for i in range(3)]).to(DEV)
+    tb = [t.to(DEV) for t in _train_batch(sc, 3, 24, 24, 0)]
+
+    def run():
+        res = []
+        for prob in (False, True):
+            out = RD.render_views(hip, est, o, d, o.shape[0], 1024, probabilistic=prob, **H.RENDER_KW)
+            res += [out[k].clone() for k in ("rgb", "acc", "depth", "sem") + (("rgb_var", "depth_var") if prob else ())]
+        out = RD.render_views(hip, est, o3, d3, 400, 1024, probabilistic=True, **H.RENDER_KW)
+        res += [out[k].clone() for k in ("rgb", "depth", "depth_var")]
+        hip.train()
+        fb = RD.fused_forward_backward(hip, est, RD.Rays(tb[0], tb[1]), tb[2], tb[3], tb[4], None, stratified=False, deterministic=True, **H.RENDER_KW)
+        hip.eval()
+        res += [fb["loss"].detach().clone()] + [p.grad.clone() for p in hip.parameters() if p.numel()]
+        return res
+
+    first = run()
+    assert len(RD._WORKSPACES) > 0
+    for ws in RD._WORKSPACES.values():
+        ws.fill_(0xFF)
+    second = run()
+    for i, (a, b) in enumerate(zip(first, second)):
+        assert bool(torch.isfinite(b).all()), i
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
