@@ -518,6 +518,199 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
     flush();
 }
 
+// ---- the large hashed levels: binned scatter -------------------------------------------------------------------------------------
+// The walk above is bound by the memory-side atomic unit (~21 G 64-byte requests/s whatever they carry, profiles/r03_atomic_microbench.txt),
+// and on the fine levels nearly every corner of every sample is a request of its own (hashed neighbours are not neighbours in memory).
+// Those levels go through memory instead: a level's table (2^k entries) is cut into bins of kBinEntries consecutive entries whose fp32
+// gradient fits in LDS.  Pass A (bin_items_kernel) writes one 16-byte item per (sample, corner) — the four feature gradients with the entry's
+// index inside its bin kept in their lowest mantissa bits — to the bin's list (slots reserved per workgroup: one returning atomic per bin
+// and workgroup).  Pass B (bin_accumulate_kernel), one workgroup per (level, bin), streams its list, adds into LDS and adds
+// the bin's sums to the gradient with plain 16-byte read-modify-writes: it is the only writer of those entries at that time.  The LDS sums
+// are DOUBLES: ds_add_f32 retires about one lane every 2.5 clocks per CU (4 x slower than the loads feed it), ds_add_f64 and the integer
+// adds run at the rate of the loads (tools/bin_bench.hip, profiles/r03_bin_bench.txt).  A list that
+// is full sends its items to the gradient with float atomics as before, so the bins only need to be sized for a uniform hash.
+constexpr int kBinEntriesLog2 = 12;
+constexpr uint32_t kBinEntries = 1u << kBinEntriesLog2;     // x 4 features x 8 bytes = 128 KB of LDS per workgroup of pass B
+constexpr int kMaxBins = 512;                                // per level: tables up to 2^21 entries
+constexpr int kBinThreadsB = 1024;
+
+struct BinArgs {
+    const float *positions;   // normalised positions [N,3]
+    const float *dX;          // [16][Np][4]
+    int64_t Np, n;
+    const int64_t *n_dev;
+    int level0, n_levels;     // levels level0 .. level0 + n_levels - 1, all hashed with size a multiple of kBinEntries
+    float4 *items;            // [n_levels][bins of that level][cap]: level k's lists start at item_base[k]
+    uint32_t *cursors;        // [n_levels][kMaxBins] items handed out per list (may exceed cap: the excess went to the atomics)
+    uint32_t cap;             // items per list
+    float *g_table;           // fp32 [entries][4]
+    LevelMeta levels[16];
+};
+
+// index bits into / out of the lowest 3 mantissa bits of each of the four values (round to nearest on the remaining 20 bits; a non-finite
+// value stays non-finite, so the NaN guard of the step still sees it)
+__device__ __forceinline__ float4 pack_item(const float v[4], uint32_t idx) {
+    float4 o;
+    float *po = &o.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t b = __builtin_bit_cast(uint32_t, v[k]);
+        if ((b & 0x7f800000u) != 0x7f800000u) b += 4u;          // (Inf / NaN: no carry out of the exponent)
+        b = (b & ~7u) | ((idx >> (3 * k)) & 7u);
+        po[k] = __builtin_bit_cast(float, b);
+    }
+    return o;
+}
+
+static_assert(kBinEntriesLog2 <= 12, "pack_item keeps 3 index bits per value");
+
+constexpr int kBinChunk = 2;                                 // sub-chunks of 256 samples per workgroup of pass A
+constexpr int kBinStage = kBinChunk * 256 * 8;               // items staged in LDS per workgroup (64 KB)
+
+__global__ void __launch_bounds__(256) bin_items_kernel(const BinArgs args) {
+    __shared__ uint32_t s_cnt[kMaxBins], s_off[kMaxBins];
+    __shared__ float4 s_stage[kBinStage];
+    __shared__ uint16_t s_binof[kBinStage];
+    __shared__ uint32_t s_total;
+    // level fastest: neighbouring workgroups reserve in different levels' cursors
+    const int lk = (int)(blockIdx.x % (unsigned)args.n_levels), l = lk + args.level0;
+    const int64_t chunk = blockIdx.x / (unsigned)args.n_levels;
+    const LevelMeta m = args.levels[l];
+    const uint32_t nb = m.size >> kBinEntriesLog2;
+    const int64_t n_all = count_here(args.n, args.n_dev);
+    const int64_t first = chunk * (kBinChunk * 256);
+    if (first >= n_all) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
+    __syncthreads();
+    // 1. this thread's samples: entries, blend weights, gradient; rank of every item among the workgroup's items of its list
+    uint32_t idx[kBinChunk][8], rank[kBinChunk][8];
+    float w[kBinChunk][8];
+    float4 g[kBinChunk];
+#pragma unroll
+    for (int sc = 0; sc < kBinChunk; ++sc) {
+        const int64_t i = first + sc * 256 + threadIdx.x;
+        if (i < n_all) {
+            float xn[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xn[d] = args.positions[3 * i + d];
+            LevelPrep p;
+            hash_prep(m, xn, p);
+            g[sc] = reinterpret_cast<const float4 *>(args.dX)[(int64_t)l * args.Np + i];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                idx[sc][c] = p.off[c] >> 3;                          // entry inside the level
+                w[sc][c] = ((c & 1) ? p.wxy[(c >> 1) & 1].y : p.wxy[(c >> 1) & 1].x) * p.wz[c >> 2];
+                rank[sc][c] = atomicAdd(&s_cnt[idx[sc][c] >> kBinEntriesLog2], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // 2. where each list's run starts in the staging buffer (exclusive scan, one wave) ...
+    if (threadIdx.x < 64) {
+        uint32_t run = 0;
+        for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+            const uint32_t b = b0 + threadIdx.x;
+            const uint32_t c = b < nb ? s_cnt[b] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if ((int)threadIdx.x >= d) incl += t;
+            }
+            if (b < nb) s_off[b] = run + incl - c;
+            run += __shfl(incl, 63, 64);
+        }
+        if (threadIdx.x == 0) s_total = run;
+    }
+    __syncthreads();
+    // ... and in the list itself: one returning add per list and workgroup; s_cnt becomes (slot in the list) - (position in the staging buffer)
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+        const uint32_t c = s_cnt[b];
+        const uint32_t base = c ? atomicAdd(&args.cursors[(size_t)lk * kMaxBins + b], c) : 0u;
+        s_cnt[b] = base - s_off[b];
+    }
+    // 3. items into the staging buffer, list by list
+#pragma unroll
+    for (int sc = 0; sc < kBinChunk; ++sc) {
+        const int64_t i = first + sc * 256 + threadIdx.x;
+        if (i < n_all) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t b = idx[sc][c] >> kBinEntriesLog2, pos = s_off[b] + rank[sc][c];
+                const float v[4] = {w[sc][c] * g[sc].x, w[sc][c] * g[sc].y, w[sc][c] * g[sc].z, w[sc][c] * g[sc].w};
+                s_stage[pos] = pack_item(v, idx[sc][c] & (kBinEntries - 1u));
+                s_binof[pos] = (uint16_t)b;
+            }
+        }
+    }
+    __syncthreads();
+    // 4. out: consecutive lanes write consecutive slots of a list
+    float4 *const lists = args.items + (size_t)lk * nb * args.cap;      // every binned level has the same size (2^k, checked by the host)
+    const uint32_t total = s_total;
+    for (uint32_t p = threadIdx.x; p < total; p += 256) {
+        const uint32_t b = s_binof[p], slot = s_cnt[b] + p;
+        const float4 it = s_stage[p];
+        if (slot < args.cap) {
+            lists[(size_t)b * args.cap + slot] = it;
+        } else {                                                 // the list is full: straight to the gradient
+            const uint32_t bits[4] = {__float_as_uint(it.x), __float_as_uint(it.y), __float_as_uint(it.z), __float_as_uint(it.w)};
+            const uint32_t e = (bits[0] & 7u) | ((bits[1] & 7u) << 3) | ((bits[2] & 7u) << 6) | ((bits[3] & 7u) << 9);
+            float *dst = args.g_table + ((size_t)(m.offset + b * kBinEntries + e) << 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = __uint_as_float(bits[k] & ~7u);
+                if (v != 0.f) atomicAdd(dst + k, v);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBinThreadsB) bin_accumulate_kernel(const BinArgs args) {
+    __shared__ double s_sum[kBinEntries * 4];
+    const int lk = blockIdx.y, l = lk + args.level0;
+    const LevelMeta m = args.levels[l];
+    const uint32_t nb = m.size >> kBinEntriesLog2, b = blockIdx.x;
+    if (b >= nb) return;
+    uint32_t count = args.cursors[(size_t)lk * kMaxBins + b];
+    if (count == 0) return;
+    if (count > args.cap) count = args.cap;
+    for (uint32_t e = threadIdx.x; e < kBinEntries * 4; e += kBinThreadsB) s_sum[e] = 0.0;
+    __syncthreads();
+    const float4 *list = args.items + ((size_t)lk * nb + b) * args.cap;
+    constexpr int U = 4;                                         // items in flight per lane
+    for (uint32_t i0 = threadIdx.x; i0 < count; i0 += kBinThreadsB * U) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f it[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = i0 + u * kBinThreadsB;
+            it[u] = reinterpret_cast<const v4f *>(list)[i < count ? i : count - 1u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * kBinThreadsB >= count) break;
+            const float f0 = it[u][0], f1 = it[u][1], f2 = it[u][2], f3 = it[u][3];     // (__builtin_bit_cast straight from a vector element reads element 0)
+            const uint32_t b0 = __float_as_uint(f0), b1 = __float_as_uint(f1), b2 = __float_as_uint(f2), b3 = __float_as_uint(f3);
+            const uint32_t e = (b0 & 7u) | ((b1 & 7u) << 3) | ((b2 & 7u) << 6) | ((b3 & 7u) << 9);
+            double *dst = s_sum + e * 4;
+            atomicAdd(dst, (double)__uint_as_float(b0 & ~7u));
+            atomicAdd(dst + 1, (double)__uint_as_float(b1 & ~7u));
+            atomicAdd(dst + 2, (double)__uint_as_float(b2 & ~7u));
+            atomicAdd(dst + 3, (double)__uint_as_float(b3 & ~7u));
+        }
+    }
+    __syncthreads();
+    float4 *const out = reinterpret_cast<float4 *>(args.g_table) + (size_t)m.offset + (size_t)b * kBinEntries;
+    for (uint32_t e = threadIdx.x; e < kBinEntries; e += kBinThreadsB) {
+        const float4 a = {(float)s_sum[e * 4], (float)s_sum[e * 4 + 1], (float)s_sum[e * 4 + 2], (float)s_sum[e * 4 + 3]};
+        if (a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f) {
+            float4 o = out[e];
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            out[e] = o;
+        }
+    }
+}
+
 // Reference form of the scatter (MNF_HASH_BWD_SIMPLE=1, debugging and A/B timing): one lane per sample, one atomic per
 // corner and feature, no run merging.
 __global__ void __launch_bounds__(256) hash_bwd_simple_kernel(const HashBwdArgs args) {
@@ -685,10 +878,17 @@ struct TrainState {
     // on a second stream of the handle: both only depend on the backward-data kernel
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_entry = nullptr;
+    // ... and the binned part of the scatter (streams through HBM and LDS) beside the walk (memory-side atomics) on a third
+    hipStream_t side2 = nullptr;
+    hipEvent_t ev_join2 = nullptr;
     // deterministic mode only (allocated on first use): fixed-point table gradient + replicas, weight-gradient partial slots
     unsigned long long *d_qtable = nullptr;
     float *d_partials = nullptr;
     size_t partials_floats = 0;
+    // binned scatter of the large hashed levels (allocated on first use, grows with the sample bound): item lists + list cursors
+    float4 *d_bin_items = nullptr;
+    size_t bin_items = 0;
+    uint32_t *d_bin_cursors = nullptr;
 };
 
 static int ensure_train_state(mnf_field_t f) {
@@ -716,10 +916,16 @@ static int ensure_train_state(mnf_field_t f) {
     if (e == hipSuccess) e = hipMemcpy(ts->d_groups, ts->tt.groups.data(), ts->tt.groups.size() * sizeof(WgradGroup), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_fragT_src, ts->tt.fragT.data(), ts->tt.fragT.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_jobs, ts->tt.jobs.data(), ts->tt.jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking);
+    // the walk only needs enough waves in flight to keep the atomic unit fed: lowest priority, so that the kernels of the other two streams
+    // (weight gradients, binned scatter) get the wave slots its short workgroups free
+    int prio_lo = 0, prio_hi = 0;
+    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ts->side, hipStreamNonBlocking, prio_lo);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_entry, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ts->side2, hipStreamNonBlocking, prio_hi);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_join2, hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error("train: %s", hipGetErrorString(e));
         delete ts;
@@ -738,10 +944,14 @@ void free_train_state_impl(mnf_field_t f) {
     if (ts->d_groups) (void)hipFree(ts->d_groups);
     if (ts->d_qtable) (void)hipFree(ts->d_qtable);
     if (ts->d_partials) (void)hipFree(ts->d_partials);
+    if (ts->d_bin_items) (void)hipFree(ts->d_bin_items);
+    if (ts->d_bin_cursors) (void)hipFree(ts->d_bin_cursors);
     if (ts->side) (void)hipStreamDestroy(ts->side);
     if (ts->ev_fork) (void)hipEventDestroy(ts->ev_fork);
     if (ts->ev_join) (void)hipEventDestroy(ts->ev_join);
     if (ts->ev_entry) (void)hipEventDestroy(ts->ev_entry);
+    if (ts->side2) (void)hipStreamDestroy(ts->side2);
+    if (ts->ev_join2) (void)hipEventDestroy(ts->ev_join2);
     delete ts;
     f->train_state = nullptr;
 }
@@ -882,7 +1092,8 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         }
         partials = ts->d_partials;
     }
-    {
+    static const bool no_wgrad = diag_env("MNF_NO_WGRAD") != nullptr;    // timing experiments: the scatter alone on the chip
+    if (!no_wgrad) {
         ProfScope ps("wgrad", s);
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * split, 4)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
                            split, v.act, n, n_dev, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem, partials);
@@ -920,9 +1131,42 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         hb.flush_count = d_flush;
     }
 #endif
-    const int prof_scatter = prof_start("hash_scatter", ss);
     static const bool simple = diag_env("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane, corner and feature
-    const dim3 walk_grid((unsigned)ceil_div(ceil_div(n, kWalkChunk) * 32, 256), n_levels);
+    // levels [first_binned, 16): through the bins (all of them hashed tables of one size that whole bins tile); the rest: the walk
+    int first_binned = 16;
+    if (!deterministic && !simple && n_levels == 16 && n >= 8192) {     // (small batches: the walk alone; pass B costs ~20 us whatever it is given)
+        int want = 11;       // measured on MI355X (tools/r03_bins_step.sh, profiles/r03_bins_step.txt): step time is flat from 10 to 12, worse below (runs of samples share
+                             // cells on the coarser levels: the walk merges them, the bins cannot) and above
+        if (const char *e = diag_env("MNF_BIN_LEVEL0")) want = atoi(e);
+        first_binned = 16;
+        for (int l = 15; l >= want && l >= 0; --l) {
+            const LevelMeta &lm = f->levels[l];
+            if (!lm.hashed || lm.size < kBinEntries || (lm.size & (lm.size - 1u)) || lm.size != f->levels[15].size || (lm.size >> kBinEntriesLog2) > (uint32_t)kMaxBins) break;
+            first_binned = l;
+        }
+    }
+    BinArgs ba;
+    const int n_binned = 16 - first_binned;
+    if (n_binned > 0) {
+        const uint32_t nb = f->levels[15].size >> kBinEntriesLog2;
+        const uint64_t per_list = (uint64_t)n * 8 / nb;
+        uint32_t cap = (uint32_t)(per_list + per_list / 8 + 2048);                // a uniform hash fills the lists evenly; the excess of a full one goes to the atomics
+        if (const char *e = diag_env("MNF_BIN_CAP")) cap = (uint32_t)atoi(e);     // tests: force the full-list path
+        const size_t need = (size_t)n_binned * nb * cap;
+        if (ts->bin_items < need) {
+            if (ts->d_bin_items) { MNF_HIP(hipStreamSynchronize(ts->side2)); (void)hipFree(ts->d_bin_items); }
+            ts->d_bin_items = nullptr; ts->bin_items = 0;
+            MNF_HIP(hipMalloc((void **)&ts->d_bin_items, need * sizeof(float4)));
+            ts->bin_items = need;
+        }
+        if (!ts->d_bin_cursors) MNF_HIP(hipMalloc((void **)&ts->d_bin_cursors, (size_t)16 * kMaxBins * sizeof(uint32_t)));
+        ba.positions = hb.positions; ba.dX = hb.dX; ba.Np = hb.Np; ba.n = n; ba.n_dev = n_dev; ba.level0 = first_binned; ba.n_levels = n_binned;
+        ba.items = ts->d_bin_items; ba.cursors = ts->d_bin_cursors; ba.cap = cap; ba.g_table = hb.g_table;
+        std::memcpy(ba.levels, f->levels, sizeof(ba.levels));
+        n_levels = first_binned;
+    }
+    const int prof_scatter = prof_start("hash_scatter", ss);
+    const dim3 walk_grid((unsigned)ceil_div(ceil_div(n, kWalkChunk) * 32, 256), n_levels > 0 ? n_levels : 1);
     if (deterministic) {
         MNF_HIP(hipMemsetAsync(hb.q_table, 0, q_table_words * sizeof(unsigned long long), ss));
         if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.q_repl, 0, (size_t)kReplicas * hb.repl_floats * sizeof(unsigned long long), ss));
@@ -934,8 +1178,21 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         hipLaunchKernelGGL(fixed_to_float_kernel, dim3(4096), dim3(256), 0, ss, reinterpret_cast<const long long *>(hb.q_table), hb.g_table,
                            (int64_t)q_table_words, (const unsigned long long *)hb.q_bad);
     } else {
+        if (n_binned > 0) {
+            const uint32_t nb = f->levels[15].size >> kBinEntriesLog2;
+            static const bool same_stream = diag_env("MNF_BIN_SAME_STREAM") != nullptr;     // timing experiments: bins in front of the walk on one stream
+            hipStream_t s2 = same_stream ? ss : ts->side2;
+            MNF_HIP(hipStreamWaitEvent(s2, ts->ev_fork, 0));
+            const int prof_bins = prof_start("hash_scatter_bins", s2);
+            MNF_HIP(hipMemsetAsync(ba.cursors, 0, (size_t)n_binned * kMaxBins * sizeof(uint32_t), s2));
+            hipLaunchKernelGGL(bin_items_kernel, dim3((unsigned)(ceil_div(n, kBinChunk * 256) * n_binned)), dim3(256), 0, s2, ba);
+            hipLaunchKernelGGL(bin_accumulate_kernel, dim3(nb, n_binned), dim3(kBinThreadsB), 0, s2, ba);
+            prof_stop(prof_bins, s2);
+            MNF_HIP(hipEventRecord(ts->ev_join2, s2));
+            MNF_HIP(hipStreamWaitEvent(s, ts->ev_join2, 0));
+        }
         if (simple) hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, ss, hb);
-        else hipLaunchKernelGGL(hash_bwd_walk_kernel<false>, walk_grid, dim3(256), 0, ss, hb);
+        else if (n_levels > 0) hipLaunchKernelGGL(hash_bwd_walk_kernel<false>, walk_grid, dim3(256), 0, ss, hb);
         if (hb.repl_levels)
             hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, ss, hb.repl, hb.repl_floats, hb.g_table);
     }

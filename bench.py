@@ -529,7 +529,7 @@ def main():
                 kernels, total_ms = {}, 0.0
                 per_sample = {"field_density": ("marched", 1036), "field_train_forward": ("kept", 1036)}
                 for label in ("sample_rays", "field_density", "field_train_forward", "composite_train_forward", "composite_train_backward",
-                              "dgrad", "wgrad", "hash_scatter"):
+                              "dgrad", "wgrad", "hash_scatter", "hash_scatter_bins"):
                     ms, n = prof(label)
                     if not n:
                         continue
@@ -542,8 +542,9 @@ def main():
                     kernels[label] = e
                     total_ms += ms / steps
                 if "hash_scatter" in kernels:
-                    kernels["hash_scatter"]["note"] = ("bound by the memory-side atomic unit: ~21 G requests/s whatever the width of an add up to 64 B "
-                                                       "(profiles/r03_atomic_microbench.txt); runs on a second stream beside wgrad, so its time overlaps")
+                    kernels["hash_scatter"]["note"] = ("levels 0-10: the walk, bound by the memory-side atomic unit: ~21 G 64-byte requests/s whatever they carry "
+                                                       "(profiles/r03_atomic_microbench.txt), on a second stream beside wgrad; levels 11-15 (hash_scatter_bins): per-bin "
+                                                       "item lists through HBM + LDS sums, on a third stream; the three overlap, so their times do not add up")
                 res["kernels"] = kernels
                 res["timed_kernels_ms_per_step"] = total_ms
                 res["instrumented_step_ms"] = 1e3 * dt_e / steps

@@ -412,3 +412,52 @@ def test_results_do_not_depend_on_stale_workspace_contents():
     for i, (a, b) in enumerate(zip(first, second)):
         assert bool(torch.isfinite(b).all()), i
         assert torch.equal(a, b), (i, float((a - b).abs().max()))
+
+
+def test_binned_scatter_equals_walk():
+    """The table gradient of the fine hashed levels goes through per-bin item lists and LDS sums (csrc/train.hip bin_items_kernel /
+    bin_accumulate_kernel) instead of memory-side float atomics.  Same contributions, 21 significant bits per item, another summation order: the
+    result equals the walk's to 2e-6 relative L2, also when the lists are made so short that nearly every item takes the full-list route.  The knobs
+    that select the routes exist only in the diag build: child process (tests/diag_bins.py)."""
+    import subprocess
+    import sys
+    from apnrf_amd import build as B
+    here = os.path.dirname(os.path.abspath(__file__))
+    assert os.path.exists(B.LIB_DIAG), "libmi355nerf_diag.so missing: run `python __graft_entry__.py build`"
+    env = dict(os.environ, MNF_LIB_PATH=B.LIB_DIAG)
+    r = subprocess.run([sys.executable, os.path.join(here, "diag_bins.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIAG_BINS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_field_backward_matches_oracle_binned_levels():
+    """test_field_backward_matches_oracle at a batch large enough (>= 8192 samples) for the product library to send levels 11..15 through the bins:
+    dL/d(params) against torch autograd through the oracle, same tolerances."""
+    from test_gpu_parity import _grad_close
+    sc = H.make_scene(neurons=128, layers=2, C=29, log2_hashmap_size=15, head_gain=2.0)
+    hip = H.hip_field(sc).train()
+    orc = H.oracle_field(sc, requires_grad=True)
+    rng = np.random.default_rng(17)
+    n = 12000 + 37
+    a = sc["aabb"]
+    pos = (rng.random((n, 3)) * (a[3:] - a[:3]) * 0.98 + a[:3] + 0.01 * (a[3:] - a[:3])).astype(np.float32)
+    pos[:7] = a[:3] - 1.0
+    d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    g_rgb = (rng.normal(size=(n, 3)) * 1e-3).astype(np.float32)
+    g_sig = (rng.normal(size=(n, 1)) * 1e-5).astype(np.float32)
+    g_sem = (rng.normal(size=(n, 29)) * 1e-3).astype(np.float32)
+    cu = lambda x: torch.from_numpy(x).to(DEV)
+    rgb, sigma, sem = hip(cu(pos), cu(d))
+    torch.autograd.backward([rgb, sigma, sem], [cu(g_rgb), cu(g_sig), cu(g_sem)])
+    r_rgb, r_sigma, r_sem = orc(torch.from_numpy(pos), torch.from_numpy(d))
+    torch.autograd.backward([r_rgb, r_sigma, r_sem], [torch.from_numpy(g_rgb), torch.from_numpy(g_sig), torch.from_numpy(g_sem)])
+    n_mlp = sum(o * i for o, i in orc.shapes["base"])
+    _grad_close(hip.mlp_base.params.grad[:n_mlp], orc.p_base.grad[:n_mlp], "base mlp")
+    _grad_close(hip.mlp_base.params.grad[n_mlp:], orc.p_base.grad[n_mlp:], "hash table")
+    # per level of the table: the binned levels are as close as the walked ones
+    got, want = hip.mlp_base.params.grad[n_mlp:].double().cpu().view(-1, 4), orc.p_base.grad[n_mlp:].double().view(-1, 4)
+    size = 1 << 15
+    for first in (got.shape[0] - size, got.shape[0] - 3 * size):             # levels 15 and 13
+        e = float((got[first:first + size] - want[first:first + size]).norm() / want[first:first + size].norm())
+        assert e < 2e-2, (first, e)
+    untouched = (orc.p_base.grad[n_mlp:] == 0).numpy()
+    assert (hip.mlp_base.params.grad[n_mlp:].cpu().numpy()[untouched] == 0).all()
