@@ -415,8 +415,8 @@ typedef struct {
 int64_t mnf_render_workspace_bytes(int64_t n_rays, int32_t rays_per_view);
 
 /* render_image_with_occgrid_test (perception/models/utils.py:555-779) and
- * render_probablistic_image_with_occgrid_test (utils.py:782-1032), single occupancy level.
- * binaries [1,X,Y,Z] u8, aabb[6] = estimator.aabbs[0].
+ * render_probablistic_image_with_occgrid_test (utils.py:782-1032).
+ * binaries [L,X,Y,Z] u8, aabb_host[6 L] = estimator.aabbs, L = opts->n_levels (0 or 1: one level; <= 4).
  * Outputs: rgb [n,3], acc [n,1], depth [n,1], sem [n,C]; rgb_var [n,3], depth_var [n,1] (probabilistic only,
  * may be NULL otherwise); total_samples: TWO int64 (device): [0] = the reference's total_samples (samples kept
  * after the alpha threshold, utils.py:757), [1] = samples evaluated by the field (all marched samples).
@@ -434,7 +434,7 @@ int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32
  * launches use them.  Results are those of separate mnf_render_test calls, bit for bit.  `opts->bitgrid` is ignored (per job). */
 typedef struct {
     mnf_field_t field;
-    const uint8_t *binaries;      /* [1,X,Y,Z] u8 */
+    const uint8_t *binaries;      /* [L,X,Y,Z] u8, L = opts->n_levels */
     const uint32_t *bitgrid;      /* optional packed form of `binaries` (see mnf_render_opts.bitgrid) */
     const float *rays_o, *rays_d; /* [n_rays,3] */
     int64_t n_rays;               /* a multiple of opts->rays_per_view; 0 = nothing to do */

@@ -1,6 +1,6 @@
 // Where does the binned scatter spend its time?  (tools/, not product)  Stand-alone model of csrc/train.hip's bin_items_kernel /
 // bin_accumulate_kernel on pseudo-random entries: N samples x 8 corners x LV levels, tables of 2^19 entries cut into bins of 4096.
-//   pass A variants: 0 ranks + reservation only (no item stores)   1 + 16-byte item stores (as built)   2 stores staged through LDS, whole runs written by consecutive lanes
+//   pass A variants: 0 ranks + reservation only (no item stores)   1 + 16-byte item stores (as built)   2 stores staged through LDS, whole runs written by consecutive lanes (as built)
 //   pass B variants: 0 loads only   1 loads + ds_add_f32 (as built)   2 loads + ds_add_u32   3 ds_add_f32, feature-major LDS   4 loads + one ds_add_f32 per item
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/bin_bench tools/bin_bench.hip && /tmp/bin_bench
 #include <hip/hip_runtime.h>
@@ -204,10 +204,10 @@ int main() {
     };
     const dim3 ga((unsigned)((n + 255) / 256), LV), gb(nb, LV);
     time("pass A: ranks + reservation, no item stores", [&] { pass_a<0><<<ga, 256>>>(n, size, items, cursors, cap); });
-    time("pass A: + one 16-byte store per item (as built)", [&] { pass_a<1><<<ga, 256>>>(n, size, items, cursors, cap); });
-    time("pass A: items staged in LDS, runs written by consecutive lanes", [&] { pass_a<2><<<ga, 256>>>(n, size, items, cursors, cap); });
+    time("pass A: + one 16-byte store per item (first version)", [&] { pass_a<1><<<ga, 256>>>(n, size, items, cursors, cap); });
+    time("pass A: items staged in LDS, runs written by consecutive lanes (as built)", [&] { pass_a<2><<<ga, 256>>>(n, size, items, cursors, cap); });
     time("pass B: loads only, 512 threads", [&] { pass_b<0, 512><<<gb, 512>>>(size, items, cursors, cap, table); });
-    time("pass B: loads + 4 ds_add_f32 per item (as built)", [&] { pass_b<1, 512><<<gb, 512>>>(size, items, cursors, cap, table); });
+    time("pass B: loads + 4 ds_add_f32 per item (first version)", [&] { pass_b<1, 512><<<gb, 512>>>(size, items, cursors, cap, table); });
     time("pass B: loads + 4 ds_add_u32 per item", [&] { pass_b<2, 512><<<gb, 512>>>(size, items, cursors, cap, table); });
     time("pass B: 4 ds_add_f32, feature-major LDS", [&] { pass_b<3, 512><<<gb, 512>>>(size, items, cursors, cap, table); });
     time("pass B: loads + 1 ds_add_f32 per item", [&] { pass_b<4, 512><<<gb, 512>>>(size, items, cursors, cap, table); });
@@ -218,8 +218,8 @@ int main() {
     time("pass A: 4096 samples per workgroup, two-phase", [&] { pass_a_loop<16, true><<<dim3((unsigned)((n + 4095) / 4096 * LV)), 256>>>(n, size, items, cursors, cap, LV); });
     time("pass A: no rank atomics (floor of the rest), no stores", [&] { pass_a<3><<<ga, 256>>>(n, size, items, cursors, cap); });
     time("pass B: 4 ds_add_u64 fixed point per item, 1024 threads, 128 KB", [&] { pass_b64<0><<<gb, 1024>>>(size, items, cursors, cap, table); });
-    time("pass B: 4 ds_add_f64 per item, 1024 threads, 128 KB", [&] { pass_b64<1><<<gb, 1024>>>(size, items, cursors, cap, table); });
-    time("pass B: as built, 1024 threads", [&] { pass_b<1, 1024><<<gb, 1024>>>(size, items, cursors, cap, table); });
-    time("pass B: as built, 256 threads", [&] { pass_b<1, 256><<<gb, 256>>>(size, items, cursors, cap, table); });
+    time("pass B: 4 ds_add_f64 per item, 1024 threads, 128 KB (as built)", [&] { pass_b64<1><<<gb, 1024>>>(size, items, cursors, cap, table); });
+    time("pass B: ds_add_f32, 1024 threads", [&] { pass_b<1, 1024><<<gb, 1024>>>(size, items, cursors, cap, table); });
+    time("pass B: ds_add_f32, 256 threads", [&] { pass_b<1, 256><<<gb, 256>>>(size, items, cursors, cap, table); });
     return 0;
 }
