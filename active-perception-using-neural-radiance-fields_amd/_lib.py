@@ -25,7 +25,7 @@ class FieldConfig(ctypes.Structure):
 class TrainOpts(ctypes.Structure):
     _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float), ("cone_angle", c_float),
                 ("alpha_thre", c_float), ("early_stop_eps", c_float), ("render_bkgd", c_float * 3), ("loss_scale", c_float),
-                ("stratified", c_int32), ("seed", c_uint64), ("render_bkgd_dev", c_void_p), ("deterministic", c_int32)]
+                ("stratified", c_int32), ("seed", c_uint64), ("render_bkgd_dev", c_void_p), ("deterministic", c_int32), ("n_levels", c_int32)]
 
 
 class VanillaConfig(ctypes.Structure):
@@ -60,6 +60,8 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_sample_rays": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                   c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mnf_sample_rays_levels": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                         c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_compact_samples": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_exclusive_sum": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "mnf_render_weight_from_density": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,

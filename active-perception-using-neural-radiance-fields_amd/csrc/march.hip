@@ -124,32 +124,32 @@ struct ScratchSink {
     }
 };
 
-template <bool LDS_GRID>
+template <bool LDS_GRID, bool MULTI>
 __global__ void __launch_bounds__(256) sample_rays_kernel(int32_t n_rays, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                          I3 res, const uint8_t *__restrict__ binaries, float a0, float a1, float a2,
-                                                          float a3, float a4, float a5, const float *__restrict__ near_planes,
+                                                          I3 res, const uint8_t *__restrict__ binaries, const LevelBoxes boxes, const float *__restrict__ near_planes,
                                                           const float *__restrict__ far_planes, float step_size, float cone_angle,
                                                           int32_t cap, float *__restrict__ scratch_ts, float *__restrict__ scratch_te,
                                                           int64_t *__restrict__ counts, const uint32_t *__restrict__ bitgrid) {
     __shared__ uint32_t s_bits[LDS_GRID ? kSamplerGridWords : 1];
     const int64_t cells = (int64_t)res.x * res.y * res.z;
-    if (LDS_GRID) {
-        const int n_words = (int)((cells + 31) / 32);
+    if (LDS_GRID) {   // every level's bits: level l at word l * words_per_level (the layout of mnf_pack_bitgrid)
+        const int wpl = boxes.words_per_level, n_words = wpl * boxes.n;
         if (bitgrid) {   // the estimator's bit-packed grid (kept current by mnf_occ_binarize): 1/8 of the bytes, no packing here
             for (int w = threadIdx.x; w < n_words; w += blockDim.x) s_bits[w] = bitgrid[w];
         } else {
             for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
+                const int lvl = w / wpl, wl = w - lvl * wpl;
                 uint32_t v = 0;
                 for (int b = 0; b < 32; ++b) {
-                    const int64_t c = (int64_t)w * 32 + b;
-                    if (c < cells && binaries[c]) v |= 1u << b;
+                    const int64_t c = (int64_t)wl * 32 + b;
+                    if (c < cells && binaries[(int64_t)lvl * cells + c]) v |= 1u << b;
                 }
                 s_bits[w] = v;
             }
         }
         __syncthreads();
     }
-    const float ab[6] = {a0, a1, a2, a3, a4, a5};
+    const float *ab = boxes.ab[0];
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)blockDim.x * gridDim.x) {
         const F3 org = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
         const F3 dir = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
@@ -158,7 +158,14 @@ __global__ void __launch_bounds__(256) sample_rays_kernel(int32_t n_rays, const 
         MarchState st = {near_plane, false, 0};
         ScratchSink sink = {scratch_ts + (int64_t)r * cap, scratch_te + (int64_t)r * cap, cap};
         float t0, t1;
-        if (ray_aabb(org, inv, -INFINITY, INFINITY, ab, t0, t1)) {   // grid.py:150-160 default planes, then grid.cu:125-151
+        if (MULTI) {
+            if (LDS_GRID) {
+                const uint32_t *bits = s_bits; const int wpl = boxes.words_per_level;
+                march_levels(org, dir, inv, near_plane, far_plane, boxes, res, [=](int level) { return BitGrid{bits + level * wpl}; }, step_size, cone_angle, 0, st, sink);
+            } else {
+                march_levels(org, dir, inv, near_plane, far_plane, boxes, res, [=](int level) { return ByteGrid{binaries + level * cells}; }, step_size, cone_angle, 0, st, sink);
+            }
+        } else if (ray_aabb(org, inv, -INFINITY, INFINITY, ab, t0, t1)) {   // grid.py:150-160 default planes, then grid.cu:125-151
             const float this_tmin = fmaxf(t0, near_plane), this_tmax = fminf(t1, far_plane);
             if (this_tmin < this_tmax) {
                 if (LDS_GRID) march_segment(org, dir, inv, this_tmin, this_tmax, ab, res, BitGrid{s_bits}, step_size, cone_angle, 0, st, sink);
@@ -453,26 +460,39 @@ extern "C" int mnf_traverse_grids(const float *rays_o, const float *rays_d, cons
     return launch_status("traverse_kernel");
 }
 
-extern "C" int mnf_sample_rays(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries, int32_t res_x,
-                               int32_t res_y, int32_t res_z, const float *aabb_host, const float *near_planes, const float *far_planes,
-                               float step_size, float cone_angle, int32_t cap, float *scratch_ts, float *scratch_te, int64_t *counts,
-                               const uint32_t *bitgrid, mnf_stream_t stream) {
+extern "C" int mnf_sample_rays_levels(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries, int32_t n_levels, int32_t res_x,
+                                      int32_t res_y, int32_t res_z, const float *aabb_host, const float *near_planes, const float *far_planes,
+                                      float step_size, float cone_angle, int32_t cap, float *scratch_ts, float *scratch_te, int64_t *counts,
+                                      const uint32_t *bitgrid, mnf_stream_t stream) {
     if (n_rays == 0) return MNF_OK;
     MNF_REQUIRE(rays_o && rays_d && binaries && aabb_host && near_planes && far_planes && scratch_ts && scratch_te && counts,
                 "sample_rays: null pointer");
     MNF_REQUIRE(res_x > 0 && res_y > 0 && res_z > 0 && cap > 0 && step_size > 0.f, "sample_rays: bad sizes");
+    MNF_REQUIRE(n_levels >= 1 && n_levels <= 4, "sample_rays: 1 to 4 occupancy levels");
     const I3 res = {res_x, res_y, res_z};
-    const float *ab = aabb_host;
+    LevelBoxes boxes;
+    LevelBoxes boxes0 = {}; boxes = boxes0;
+    boxes.n = n_levels;
+    boxes.words_per_level = (int32_t)(((int64_t)res_x * res_y * res_z + 31) / 32);
+    for (int l = 0; l < n_levels; ++l)
+        for (int k = 0; k < 6; ++k) boxes.ab[l][k] = aabb_host[6 * l + k];
     ProfScope ps("sample_rays", as_stream(stream));
-    const bool lds = (int64_t)res_x * res_y * res_z <= (int64_t)kSamplerGridWords * 32;
+    const bool lds = (int64_t)boxes.words_per_level * n_levels <= (int64_t)kSamplerGridWords;
     const int grid = grid_for(n_rays, 256);
-    if (lds)
-        hipLaunchKernelGGL(sample_rays_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, ab[0],
-                           ab[1], ab[2], ab[3], ab[4], ab[5], near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts, bitgrid);
-    else
-        hipLaunchKernelGGL(sample_rays_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, ab[0],
-                           ab[1], ab[2], ab[3], ab[4], ab[5], near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts, bitgrid);
+#define MNF_SAMPLE(LDS, ML) hipLaunchKernelGGL((sample_rays_kernel<LDS, ML>), dim3(grid), dim3(256), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, boxes, \
+                                               near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts, bitgrid)
+    if (n_levels > 1) { if (lds) MNF_SAMPLE(true, true); else MNF_SAMPLE(false, true); }
+    else { if (lds) MNF_SAMPLE(true, false); else MNF_SAMPLE(false, false); }
+#undef MNF_SAMPLE
     return launch_status("sample_rays_kernel");
+}
+
+extern "C" int mnf_sample_rays(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries, int32_t res_x,
+                               int32_t res_y, int32_t res_z, const float *aabb_host, const float *near_planes, const float *far_planes,
+                               float step_size, float cone_angle, int32_t cap, float *scratch_ts, float *scratch_te, int64_t *counts,
+                               const uint32_t *bitgrid, mnf_stream_t stream) {
+    return mnf_sample_rays_levels(rays_o, rays_d, n_rays, binaries, 1, res_x, res_y, res_z, aabb_host, near_planes, far_planes, step_size, cone_angle, cap,
+                                  scratch_ts, scratch_te, counts, bitgrid, stream);
 }
 
 extern "C" int mnf_compact_samples(const float *scratch_ts, const float *scratch_te, int32_t cap, const int64_t *chunk_starts,

@@ -195,4 +195,45 @@ __device__ __forceinline__ void march_segment(const F3 org, const F3 dir, const 
     }
 }
 
+// aabbs of the occupancy levels, by value (<= 4 levels); words_per_level: 32-bit words of one level in the bit-packed grid
+struct LevelBoxes { float ab[4][6]; int32_t n, words_per_level; };
+
+// Several occupancy levels (grid.cu:125-151): the 2L entry / exit distances of the level boxes (default near / far, utils.py:658; a miss is
+// +inf twice), sorted (stable: ties keep the order [t_min of level 0.., t_max of level 0..], as the reference's argsort), cut the ray into
+// segments; a segment that begins where a level is entered is marched on that level, one that begins where a level is left is marched on the
+// level left next — if the ray is inside it.  `grid_of(level)` returns the occupancy accessor of that level.
+template <class Sink, class GridOf>
+__device__ __forceinline__ void march_levels(const F3 org, const F3 dir, const F3 inv, float near_plane, float far_plane, const LevelBoxes &boxes,
+                                             const I3 res, const GridOf grid_of, float step_size, float cone_angle, int32_t limit,
+                                             MarchState &st, Sink &sink) {
+    const int L = boxes.n;
+    float tv[8]; int ti[8]; bool lhit[4];
+    for (int l = 0; l < L; ++l) {
+        float t0, t1;
+        lhit[l] = ray_aabb(org, inv, -INFINITY, INFINITY, boxes.ab[l], t0, t1);
+        tv[l] = lhit[l] ? t0 : INFINITY; tv[L + l] = lhit[l] ? t1 : INFINITY;
+        ti[l] = l; ti[L + l] = L + l;
+    }
+    for (int a = 1; a < 2 * L; ++a) {   // stable insertion sort of <= 8 values
+        const float v = tv[a]; const int id = ti[a];
+        int b = a - 1;
+        while (b >= 0 && tv[b] > v) { tv[b + 1] = tv[b]; ti[b + 1] = ti[b]; --b; }
+        tv[b + 1] = v; ti[b + 1] = id;
+    }
+    for (int i = 0; i < 2 * L - 1; ++i) {
+        const bool is_entering = ti[i] < L;
+        int level = ti[i] % L;
+        if (!lhit[level]) continue;
+        if (!is_entering) {
+            if (ti[i + 1] < L) continue;
+            level = ti[i + 1] % L;
+            if (!lhit[level]) continue;
+        }
+        const float this_tmin = fmaxf(tv[i], near_plane);
+        const float this_tmax = fminf(tv[i + 1], far_plane);
+        if (this_tmin >= this_tmax) continue;
+        march_segment(org, dir, inv, this_tmin, this_tmax, boxes.ab[level], res, grid_of(level), step_size, cone_angle, limit, st, sink);
+    }
+}
+
 }  // namespace mnf

@@ -185,9 +185,6 @@ __global__ void __launch_bounds__(256) pack_grid_kernel(const uint8_t *__restric
     bits[w] = v;
 }
 
-// aabbs of the occupancy levels, by value (<= 4 levels)
-struct LevelBoxes { float ab[4][6]; int32_t n, words_per_level; };
-
 // utils.py:674-696: one traversal of <= n_samples steps per alive ray (over-allocated mode of grid.cu:364-404).
 // The occupancy grid is read from a bit-packed copy staged in LDS (<= 64 KB) once per workgroup.
 template <bool LDS_GRID, bool MULTI>
@@ -292,39 +289,13 @@ __global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_ra
     const float near_plane = ray_near;
     MarchState st = {near_plane, false, 0};
     RoundSink sink = {ws.col_ts, ws.col_te, col0};
-    if (MULTI) {
-        // several occupancy levels (grid.cu:125-151): the 2L entry / exit distances of the level boxes, sorted (stable: ties keep the order
-        // [t_min of level 0.., t_max of level 0..], as the oracle's argsort), cut the ray into segments; a segment that begins where a level is
-        // entered is marched on that level, one that begins where a level is left is marched on the level left next — if the ray is inside it
-        const int L = boxes.n;
+    if (MULTI) {   // several occupancy levels: march_dev.h march_levels
         const int64_t cells = (int64_t)res.x * res.y * res.z;
-        float tv[8]; int ti[8]; bool lhit[4];
-        for (int l = 0; l < L; ++l) {
-            float t0, t1;
-            lhit[l] = ray_aabb(org, inv, -INFINITY, INFINITY, boxes.ab[l], t0, t1);   // utils.py:658 (default near / far), misses -> +inf
-            tv[l] = lhit[l] ? t0 : INFINITY; tv[L + l] = lhit[l] ? t1 : INFINITY;
-            ti[l] = l; ti[L + l] = L + l;
-        }
-        for (int a = 1; a < 2 * L; ++a) {   // stable insertion sort of <= 8 values
-            const float v = tv[a]; const int id = ti[a];
-            int b = a - 1;
-            while (b >= 0 && tv[b] > v) { tv[b + 1] = tv[b]; ti[b + 1] = ti[b]; --b; }
-            tv[b + 1] = v; ti[b + 1] = id;
-        }
-        for (int i = 0; i < 2 * L - 1; ++i) {
-            const bool is_entering = ti[i] < L;
-            int level = ti[i] % L;
-            if (!lhit[level]) continue;
-            if (!is_entering) {
-                if (ti[i + 1] < L) continue;
-                level = ti[i + 1] % L;
-                if (!lhit[level]) continue;
-            }
-            const float this_tmin = fmaxf(tv[i], near_plane);
-            const float this_tmax = fminf(tv[i + 1], far_plane);
-            if (this_tmin >= this_tmax) continue;
-            if (LDS_GRID) march_segment(org, dir, inv, this_tmin, this_tmax, boxes.ab[level], res, BitGrid{s_bits + level * boxes.words_per_level}, step_size, cone_angle, ns, st, sink);
-            else march_segment(org, dir, inv, this_tmin, this_tmax, boxes.ab[level], res, ByteGrid{binaries + level * cells}, step_size, cone_angle, ns, st, sink);
+        if (LDS_GRID) {
+            const uint32_t *bits = s_bits; const int wpl = boxes.words_per_level;
+            march_levels(org, dir, inv, near_plane, far_plane, boxes, res, [=](int level) { return BitGrid{bits + level * wpl}; }, step_size, cone_angle, ns, st, sink);
+        } else {
+            march_levels(org, dir, inv, near_plane, far_plane, boxes, res, [=](int level) { return ByteGrid{binaries + level * cells}; }, step_size, cone_angle, ns, st, sink);
         }
     } else if (ray_hit) {   // single grid level: the only interval is [t_min, t_max] (grid.cu:125-151 with n_grids == 1)
         const float this_tmin = fmaxf(ray_tmin, near_plane);

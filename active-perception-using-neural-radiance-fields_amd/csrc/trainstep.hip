@@ -293,10 +293,12 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     hipLaunchKernelGGL(planes_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
                        opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp);
     double *mean_part = reinterpret_cast<double *>(w.totals + 8);          // 128 doubles behind the counters
-    hipLaunchKernelGGL(mean_partial_kernel, dim3(128), dim3(256), 0, s, occs, cells, mean_part);
-    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(64), 0, s, (const double *)mean_part, 128, cells, opts->alpha_thre, w.alpha_thre);
-    int rc = mnf_sample_rays(rays_o, rays_d, n_rays, binaries, res_x, res_y, res_z, aabb_host, w.nearp, w.farp, opts->render_step_size,
-                             opts->cone_angle, cap, w.scratch_ts, w.scratch_te, w.counts, bitgrid, stream);
+    const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
+    MNF_REQUIRE(n_levels <= 4, "train_step: at most 4 occupancy levels");
+    hipLaunchKernelGGL(mean_partial_kernel, dim3(128), dim3(256), 0, s, occs, cells * n_levels, mean_part);          // occ_grid.py:192: the mean over every level
+    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(64), 0, s, (const double *)mean_part, 128, cells * n_levels, opts->alpha_thre, w.alpha_thre);
+    int rc = mnf_sample_rays_levels(rays_o, rays_d, n_rays, binaries, n_levels, res_x, res_y, res_z, aabb_host, w.nearp, w.farp, opts->render_step_size,
+                                    opts->cone_angle, cap, w.scratch_ts, w.scratch_te, w.counts, bitgrid, stream);
     if (rc) return rc;
     rc = mnf_exclusive_scan_i64(w.counts, n_rays, w.starts, w.totals, w.scan, mnf_scan_workspace_bytes(n_rays), stream);
     if (rc) return rc;

@@ -547,9 +547,9 @@ class OccGridEstimator(torch.nn.Module):
     def _sample_single_pass(self, rays_o, rays_d, near_planes, far_planes, step_size, cone_angle, cap=None):
         """One traversal instead of the count + fill pair of `traverse_grids` (csrc/march.hip, sample_rays_kernel): rays
         are marched once into a bounded scratch and the rows are packed afterwards; the result is the one `traverse_grids`
-        gives, bit for bit.  Returns None (caller uses the two-pass path) for multi-level grids, step_size <= 0 or when a ray
+        gives, bit for bit.  Returns None (caller uses the two-pass path) for more than four levels, step_size <= 0 or when a ray
         overflows its scratch row."""
-        if self.levels != 1 or step_size <= 0.0 or rays_o.dim() != 2 or not rays_o.is_cuda:
+        if self.levels > 4 or step_size <= 0.0 or rays_o.dim() != 2 or not rays_o.is_cuda:
             return None
         n = rays_o.shape[0]
         dev = rays_o.device
@@ -560,14 +560,14 @@ class OccGridEstimator(torch.nn.Module):
         b = self.binaries
         b = b.contiguous().view(torch.uint8) if b.dtype == torch.bool else b.to(torch.uint8).contiguous()
         import ctypes
-        aabb_host = (ctypes.c_float * 6)(*self.aabb_host(0))
+        aabb_host = (ctypes.c_float * (6 * self.levels))(*[x for lvl in range(self.levels) for x in self.aabb_host(lvl)])
         rays_o, rays_d = L.contig(rays_o, torch.float32), L.contig(rays_d, torch.float32)
         near_planes, far_planes = L.contig(near_planes, torch.float32), L.contig(far_planes, torch.float32)
         scratch = torch.empty((2, n, cap), device=dev, dtype=torch.float32)
         counts = torch.empty((n,), device=dev, dtype=torch.int64)
         res = [int(x) for x in b.shape[1:]]
         lib = L.load_library()
-        L.launch(lib.mnf_sample_rays, L.ptr(rays_o), L.ptr(rays_d), n, L.ptr(b), res[0], res[1], res[2], aabb_host, L.ptr(near_planes),
+        L.launch(lib.mnf_sample_rays_levels, L.ptr(rays_o), L.ptr(rays_d), n, L.ptr(b), self.levels, res[0], res[1], res[2], aabb_host, L.ptr(near_planes),
                                     L.ptr(far_planes), float(step_size), float(cone_angle), cap, L.ptr(scratch[0]), L.ptr(scratch[1]),
                                     L.ptr(counts), L.ptr(self.bitgrid()[0]))
         starts, total_t = exclusive_scan_counts(counts, want_total=True)

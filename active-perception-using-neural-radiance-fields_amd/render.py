@@ -53,12 +53,6 @@ def _grid_levels(estimator, max_levels=4):
     return b, aabb
 
 
-def _single_level(estimator):
-    """One-level form (the fused train step and `mnf_score_poses` take one level: the reference configs use main_grid_nlvl: 1)."""
-    if estimator.binaries.shape[0] != 1:
-        raise NotImplementedError("this fused path supports one occupancy level (the reference configs use main_grid_nlvl: 1); "
-                                  "multi-level grids: the fused renderer (render_views / render_image_with_occgrid_test) and the autograd training route")
-    return _grid_levels(estimator, 1)
 
 
 _VIEW_ORDERS = {}
@@ -344,19 +338,20 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
       sync=False  nothing is read back: n_rendering_samples / n_marched are 0-d device tensors; the bounds are adapted from the
                   previous call's counts (copied to pinned memory in the background); a step beyond its bounds is skipped on
                   the device (skip != 0) and the bounds grow for the next one.
-    Returns None when this estimator / batch cannot take the fused path (multi-level grid, a ray longer than the single-pass
-    scratch row): the caller then uses the autograd path, which is the same arithmetic in separate calls."""
-    if estimator.levels != 1:
+    Returns None when this estimator / batch cannot take the fused path (more than four occupancy levels, a ray longer than the
+    single-pass scratch row): the caller then uses the autograd path, which is the same arithmetic in separate calls."""
+    if estimator.levels > 4:
         return None
     lib = L.load_library()
     o, d = L.contig(rays.origins.reshape(-1, 3), torch.float32), L.contig(rays.viewdirs.reshape(-1, 3), torch.float32)
     L.require_gpu(o, d, pixels, dep, sem)
     R, dev = o.shape[0], o.device
     handle = radiance_field._ensure_handle()
-    binaries, aabb = _single_level(estimator)
+    binaries, aabb = _grid_levels(estimator)
     bits = estimator.bitgrid()
     res = binaries.shape[1:]
     opts = L.TrainOpts()
+    opts.n_levels = len(aabb) // 6
     opts.near_plane, opts.far_plane, opts.render_step_size, opts.cone_angle = near_plane, far_plane, render_step_size, cone_angle
     opts.alpha_thre, opts.early_stop_eps, opts.loss_scale = alpha_thre, early_stop_eps, float(radiance_field.loss_scale)
     bk_dev = None
@@ -401,7 +396,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         nbytes = int(lib.mnf_train_step_workspace_bytes(handle, R, st["cap_m"], st["cap_k"]))
         ws = _workspace(dev, nbytes)
         L.launch(lib.mnf_train_step, handle, L.ptr(binaries), L.ptr(bits[0]), L.ptr(estimator.occs), res[0], res[1], res[2],
-                 (ctypes.c_float * 6)(*aabb), L.ptr(o), L.ptr(d), R, L.ptr(tp), L.ptr(td), L.ptr(tl), ctypes.byref(opts),
+                 (ctypes.c_float * len(aabb))(*aabb), L.ptr(o), L.ptr(d), R, L.ptr(tp), L.ptr(td), L.ptr(tl), ctypes.byref(opts),
                  L.ptr(params[0].grad), L.ptr(params[1].grad), L.ptr(params[2].grad), L.ptr(losses), L.ptr(counts), L.ptr(skip),
                  st["cap_m"], st["cap_k"], L.ptr(ws), nbytes)
         if not sync:
@@ -689,7 +684,7 @@ def score_poses(radiance_fields, estimators, poses, width, height, focal, near_p
     h, w = int(height * scale), int(width * scale)
     idx = torch.from_numpy(subsample_indices(width * height, h * w)).to(device)
     handles = (ctypes.c_void_p * M)(*[f._ensure_handle() for f in radiance_fields])
-    grids = [_single_level(e) for e in estimators]
+    grids = [_grid_levels(e) for e in estimators]
     bins = (ctypes.c_void_p * M)(*[g[0].data_ptr() for g in grids])
     bits = (ctypes.c_void_p * M)(*[e.bitgrid()[0].data_ptr() for e in estimators])
     opts = L.RenderOpts()
@@ -697,11 +692,12 @@ def score_poses(radiance_fields, estimators, poses, width, height, focal, near_p
     opts.cone_angle, opts.alpha_thre, opts.early_stop_eps = cone_angle, alpha_thre, 1e-4
     opts.max_samples, opts.probabilistic, opts.rays_per_view, opts.sync_every = 1024, 1, h * w, 8
     opts.view_order = None                                # row-major march order, as `score_views`
+    opts.n_levels = len(grids[0][1]) // 6
     C = radiance_fields[0].num_semantic_classes
     nbytes = int(lib.mnf_score_poses_workspace_bytes(M, V, h * w, C))
     ws = _workspace(torch.device(device), nbytes)
     terms = torch.empty(V, 4, dtype=torch.float64, device=device)
     res = grids[0][0].shape[1:]
-    L.launch(lib.mnf_score_poses, handles, bins, bits, M, res[0], res[1], res[2], (ctypes.c_float * 6)(*grids[0][1]), L.ptr(c2w), V, width,
+    L.launch(lib.mnf_score_poses, handles, bins, bits, M, res[0], res[1], res[2], (ctypes.c_float * len(grids[0][1]))(*grids[0][1]), L.ptr(c2w), V, width,
              height, float(np.float32(focal)), L.ptr(idx), h * w, ctypes.byref(opts), L.ptr(terms), L.ptr(ws), nbytes)
     return terms, trajectory_score(terms)

@@ -77,6 +77,12 @@ int mnf_sample_rays(const float *rays_o, const float *rays_d, int32_t n_rays, co
                     int32_t res_y, int32_t res_z, const float *aabb_host, const float *near_planes, const float *far_planes,
                     float step_size, float cone_angle, int32_t cap, float *scratch_ts, float *scratch_te, int64_t *counts,
                     const uint32_t *bitgrid, mnf_stream_t stream);
+/* The same over n_levels (1..4) occupancy levels (occ_grid.py:37-55; grid.cu:125-151 takes a ray's segments level by level):
+ * binaries [n_levels,X,Y,Z], aabb_host n_levels x 6 floats (estimator.aabbs), bitgrid [n_levels][ceil(cells / 32)] words. */
+int mnf_sample_rays_levels(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries, int32_t n_levels,
+                           int32_t res_x, int32_t res_y, int32_t res_z, const float *aabb_host, const float *near_planes,
+                           const float *far_planes, float step_size, float cone_angle, int32_t cap, float *scratch_ts, float *scratch_te,
+                           int64_t *counts, const uint32_t *bitgrid, mnf_stream_t stream);
 
 /* Pack the scratch rows: samples of ray r go to [chunk_starts[r], chunk_starts[r] + counts[r]) of t_starts / t_ends /
  * ray_indices (chunk_starts = exclusive prefix of counts, `RaySegmentsSpec::memalloc_data_from_chunk`, data_spec.hpp:86-96). */
@@ -373,6 +379,8 @@ typedef struct {
                                        accumulates in 64-bit fixed point (integer atomics), the weight gradients' partial sums are added in
                                        a fixed order.  Same kernels otherwise; used for stand-in scenes that must come out the same on
                                        every box (apnrf_amd.standin) and for regression tests. */
+    int32_t n_levels;               /* occupancy levels (0 or 1: one): binaries [n_levels,X,Y,Z], occs [n_levels * cells], aabb_host n_levels x 6 floats,
+                                       bitgrid [n_levels][ceil(cells / 32)]; the field's aabb is the largest level's (pipeline.py:167-172) */
 } mnf_train_opts;
 int64_t mnf_train_step_workspace_bytes(mnf_field_t f, int32_t n_rays, int64_t max_marched, int64_t max_kept);
 int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
