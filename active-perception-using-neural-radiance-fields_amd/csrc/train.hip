@@ -347,6 +347,7 @@ struct HashBwdArgs {
     const float *dX;      // [16][Np][4]
     int64_t Np;
     int level0;           // first level of this launch (experiments; 0 in production)
+    int n_walk_levels;    // levels level0 .. level0 + n_walk_levels - 1
     float *repl;          // [kReplicas][repl_floats]: private copies of the coarsest levels' gradient (see below)
     uint32_t repl_floats;
     int repl_levels;
@@ -427,17 +428,23 @@ template <bool DET>
 __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs args) {
     const int sub = threadIdx.x & 31;                 // lane inside the half-wave
     const int corner = sub >> 2, feat = sub & 3;
-    const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int64_t i0 = chunk * kWalkChunk;
-    const int64_t n_all = count_here(args.n, args.n_dev);
-    if (i0 >= n_all) return;
-    const int64_t i1 = i0 + kWalkChunk < n_all ? i0 + kWalkChunk : n_all;
-    const int l = blockIdx.y + args.level0;
-    const LevelMeta m = args.levels[l];
-    float *const g_dst = l < args.repl_levels ? args.repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.g_table;
-    unsigned long long *const q_dst = !DET ? nullptr : (l < args.repl_levels ? args.q_repl + (size_t)(blockIdx.x % kReplicas) * args.repl_floats : args.q_table);
-    const float *gl = args.dX + ((int64_t)l * args.Np) * 4 + feat;
     const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+    const int64_t n_all = count_here(args.n, args.n_dev);
+    // A bounded number of workgroups walks all (level, chunk) pairs (level by level, so that the workgroups of the moment add into the same few
+    // megabytes): the kernel is bound by the atomic unit, not by waves in flight, and the wave slots it leaves are what lets the binned passes
+    // and the weight gradients run beside it instead of behind it.
+    const int64_t chunks = (n_all + kWalkChunk - 1) / kWalkChunk;
+    const int64_t items = chunks * args.n_walk_levels;
+    for (int64_t item = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5; item < items; item += ((int64_t)gridDim.x * blockDim.x) >> 5) {
+    const int64_t chunk = item % chunks;
+    const int l = (int)(item / chunks) + args.level0;
+    const int64_t i0 = chunk * kWalkChunk;
+    const int64_t i1 = i0 + kWalkChunk < n_all ? i0 + kWalkChunk : n_all;
+    const LevelMeta m = args.levels[l];
+    const uint32_t replica = (uint32_t)((chunk >> 3) % kReplicas);
+    float *const g_dst = l < args.repl_levels ? args.repl + (size_t)replica * args.repl_floats : args.g_table;
+    unsigned long long *const q_dst = !DET ? nullptr : (l < args.repl_levels ? args.q_repl + (size_t)replica * args.repl_floats : args.q_table);
+    const float *gl = args.dX + ((int64_t)l * args.Np) * 4 + feat;
 
     float acc = 0.0f;
     bool open = false;
@@ -516,6 +523,7 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
         }
     }
     flush();
+    }
 }
 
 // ---- the large hashed levels: binned scatter -------------------------------------------------------------------------------------
@@ -700,13 +708,12 @@ __global__ void __launch_bounds__(kBinThreadsB) bin_accumulate_kernel(const BinA
         }
     }
     __syncthreads();
-    float4 *const out = reinterpret_cast<float4 *>(args.g_table) + (size_t)m.offset + (size_t)b * kBinEntries;
-    for (uint32_t e = threadIdx.x; e < kBinEntries; e += kBinThreadsB) {
-        const float4 a = {(float)s_sum[e * 4], (float)s_sum[e * 4 + 1], (float)s_sum[e * 4 + 2], (float)s_sum[e * 4 + 3]};
-        if (a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f) {
-            float4 o = out[e];
-            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-            out[e] = o;
+    // this bin's sums into the gradient: plain read-modify-writes (nothing else touches these entries at this time)
+    float *const out = args.g_table + (((size_t)m.offset + (size_t)b * kBinEntries) << 2);
+    for (uint32_t i = threadIdx.x; i < kBinEntries * 4; i += kBinThreadsB) {
+        const float a = (float)s_sum[i];
+        if (a != 0.f) {
+            out[i] += a;
         }
     }
 }
@@ -1166,7 +1173,11 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         n_levels = first_binned;
     }
     const int prof_scatter = prof_start("hash_scatter", ss);
-    const dim3 walk_grid((unsigned)ceil_div(ceil_div(n, kWalkChunk) * 32, 256), n_levels > 0 ? n_levels : 1);
+    hb.n_walk_levels = n_levels;
+    int walk_wgs = 8;                                                                   // workgroups per CU of the 256 (gfx950 only: as the field kernel)
+    if (const char *e = diag_env("MNF_WALK_WGS")) walk_wgs = atoi(e);
+    const int64_t walk_full = ceil_div(ceil_div(n, kWalkChunk) * 32, 256) * (n_levels > 0 ? n_levels : 1);
+    const dim3 walk_grid((unsigned)(walk_wgs > 0 && walk_full > (int64_t)256 * walk_wgs ? (int64_t)256 * walk_wgs : (walk_full > 0 ? walk_full : 1)));
     if (deterministic) {
         MNF_HIP(hipMemsetAsync(hb.q_table, 0, q_table_words * sizeof(unsigned long long), ss));
         if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.q_repl, 0, (size_t)kReplicas * hb.repl_floats * sizeof(unsigned long long), ss));
@@ -1185,6 +1196,8 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
             MNF_HIP(hipStreamWaitEvent(s2, ts->ev_fork, 0));
             const int prof_bins = prof_start("hash_scatter_bins", s2);
             MNF_HIP(hipMemsetAsync(ba.cursors, 0, (size_t)n_binned * kMaxBins * sizeof(uint32_t), s2));
+            // (Measured and dropped, tools/r03_walk_wgs.sh: pass B level by level or half by half on a fourth stream under the next pass A — 5.8 and 5.6 ms
+            // per step against 5.55-5.6 for one launch each: walk, bins and wgrad together are bound by HBM, the order inside does not matter.)
             hipLaunchKernelGGL(bin_items_kernel, dim3((unsigned)(ceil_div(n, kBinChunk * 256) * n_binned)), dim3(256), 0, s2, ba);
             hipLaunchKernelGGL(bin_accumulate_kernel, dim3(nb, n_binned), dim3(kBinThreadsB), 0, s2, ba);
             prof_stop(prof_bins, s2);
