@@ -42,6 +42,26 @@ hipEvent_t prof_event() {
 }  // namespace
 
 bool prof_on() { return g_prof.on; }
+// ---- the process-wide side streams (common.h)
+hipStream_t shared_side_stream(int slot) {
+    static std::mutex mu;
+    static std::vector<std::vector<hipStream_t>> per_device;
+    if (slot < 0 || slot >= kSharedSideStreams) { set_error("shared_side_stream: bad slot %d", slot); return nullptr; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("shared_side_stream: no current device"); return nullptr; }
+    std::lock_guard<std::mutex> lock(mu);
+    if ((int)per_device.size() <= dev) per_device.resize(dev + 1);
+    std::vector<hipStream_t> &v = per_device[dev];
+    if (v.empty()) {
+        v.assign(kSharedSideStreams, nullptr);
+        for (int k = 0; k < kSharedSideStreams; ++k) {
+            const hipError_t e = hipStreamCreateWithFlags(&v[k], hipStreamNonBlocking);
+            if (e != hipSuccess) { set_error("shared_side_stream: %s", hipGetErrorString(e)); v.clear(); return nullptr; }
+        }
+    }
+    return v[slot];
+}
+
 int prof_start(const char *label, hipStream_t s) {
     if (!g_prof.on || !label) return -1;
     std::lock_guard<std::mutex> lock(g_prof_mutex);

@@ -62,6 +62,14 @@ inline const char *diag_env(const char *name) { return getenv(name); }
 inline const char *diag_env(const char *) { return nullptr; }
 #endif
 
+// The library's side streams (api.cpp): ONE small set per device for the whole process, shared by every user (the train step's scatter streams, the
+// render jobs) and never destroyed.  Measured on MI355X / ROCm 7.2 (tools/exp_after_training3.py, profiles/r03_stream_count.txt): with one more pair of
+// streams alive in the process (a second field that has trained: round 3 first gave every train state its own pair) each SMALL kernel of a train step
+// took ~45 us instead of ~5 and the step 5.2 ms instead of 3.9 — for the rest of the process, also for fields created later.  Users fork from and join
+// the caller's stream with events, so sharing a stream only serialises work that was not meant to overlap anyway.
+hipStream_t shared_side_stream(int slot);          // slot 0 .. kSharedSideStreams - 1 of the current device; NULL on failure (error set)
+constexpr int kSharedSideStreams = 3;
+
 // per-kernel timing for bench.py (api.cpp): a no-op unless mnf_profile_begin() was called on this thread
 bool prof_on();
 int prof_start(const char *label, hipStream_t s);

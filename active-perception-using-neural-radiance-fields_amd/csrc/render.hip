@@ -442,7 +442,8 @@ struct JobPool {
             MNF_HIP(hipHostMalloc((void **)&r.flags, 64, hipHostMallocDefault));
             MNF_HIP(hipEventCreateWithFlags(&r.ev_flags, hipEventDisableTiming));
             MNF_HIP(hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming));
-            MNF_HIP(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
+            r.side = shared_side_stream((int)(res.size() % kSharedSideStreams));     // (job 0 runs on the caller's stream; more than 3 side jobs share)
+            if (!r.side) return MNF_ERR_HIP;
             res.push_back(r);
         }
         return MNF_OK;

@@ -923,15 +923,13 @@ static int ensure_train_state(mnf_field_t f) {
     if (e == hipSuccess) e = hipMemcpy(ts->d_groups, ts->tt.groups.data(), ts->tt.groups.size() * sizeof(WgradGroup), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_fragT_src, ts->tt.fragT.data(), ts->tt.fragT.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_jobs, ts->tt.jobs.data(), ts->tt.jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice);
-    // the walk only needs enough waves in flight to keep the atomic unit fed: lowest priority, so that the kernels of the other two streams
-    // (weight gradients, binned scatter) get the wave slots its short workgroups free
-    int prio_lo = 0, prio_hi = 0;
-    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ts->side, hipStreamNonBlocking, prio_lo);
+    // side streams: the process-wide ones (common.h shared_side_stream), not a pair per train state
+    ts->side = shared_side_stream(0);
+    ts->side2 = shared_side_stream(1);
+    if (!ts->side || !ts->side2) { delete ts; return MNF_ERR_HIP; }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_entry, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ts->side2, hipStreamNonBlocking, prio_hi);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_join2, hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error("train: %s", hipGetErrorString(e));
@@ -953,11 +951,9 @@ void free_train_state_impl(mnf_field_t f) {
     if (ts->d_partials) (void)hipFree(ts->d_partials);
     if (ts->d_bin_items) (void)hipFree(ts->d_bin_items);
     if (ts->d_bin_cursors) (void)hipFree(ts->d_bin_cursors);
-    if (ts->side) (void)hipStreamDestroy(ts->side);
     if (ts->ev_fork) (void)hipEventDestroy(ts->ev_fork);
     if (ts->ev_join) (void)hipEventDestroy(ts->ev_join);
     if (ts->ev_entry) (void)hipEventDestroy(ts->ev_entry);
-    if (ts->side2) (void)hipStreamDestroy(ts->side2);
     if (ts->ev_join2) (void)hipEventDestroy(ts->ev_join2);
     delete ts;
     f->train_state = nullptr;

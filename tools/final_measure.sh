@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end measurement set (run on the GPU box from the repo root); results land in gpurun_out/final/.
-# usage: bash tools/final_measure.sh [tests] [bench] [prof] [pmc] [pmc_score]   (default: all)
+# usage: bash tools/final_measure.sh [tests] [bench] [prof] [pmc] [pmc_score] [pmc_train]   (default: all but pmc_train)
 export TMPDIR=/tmp
 out=gpurun_out/final; mkdir -p $out
 what="${*:-tests bench prof pmc pmc_score}"
@@ -37,5 +37,8 @@ if has pmc_score; then
   pmc score_write --workload score256 -- WRITE_SIZE
   pmc score_sq --workload score256 -- SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY
   python tools/reduce_pmc.py /tmp/pmc_score_fetch_counter_collection.csv /tmp/pmc_score_write_counter_collection.csv $out/pmc_score_fetch.json $out/r03_pmc.json "field_kernel<128, 2, 2, false, false" field_kernel_scoring
+fi
+if has pmc_train; then
+  pmc train_atomic --workload train --train-dtypes f16 -- TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum
 fi
 ls $out
