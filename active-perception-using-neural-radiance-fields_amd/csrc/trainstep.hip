@@ -350,10 +350,15 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
                     g_head, g_sem, false, true, opts->deterministic != 0, s);
 }
 
-// view groups per member of a scoring call.  Two render jobs in flight is the measured optimum (profiles/r03_split_experiment.txt): with
-// two or more members each member is one job; a single member's pose list is cut into two halves, so that one half's marcher runs beside
-// the other half's field kernel.
-static inline int score_groups(int32_t n_views, int32_t n_members = 1) { return n_members >= 2 || n_views < 2 ? 1 : 2; }
+// view groups per member of a scoring call.  FOUR render jobs in flight (the caller's stream + the three shared side streams) is the measured optimum for
+// these small views (profiles/r03_hw_queues.txt: 256 views x 2 members 101.1 ms with 4 jobs, 107.0 with 2; 32 views 21.3 against 22.6; more jobs than
+// streams: worse): two members -> two halves of the pose list each, one member -> four quarters; one half's marcher runs beside another's field kernel.
+// (profiles/r03_split_experiment.txt had two as the optimum: measured when every job still had a stream of its own, see common.h shared_side_stream.)
+static inline int score_groups(int32_t n_views, int32_t n_members = 1) {
+    int g = 4 / (n_members > 0 ? n_members : 1);
+    if (g < 1) g = 1;
+    return g > n_views ? (n_views > 0 ? n_views : 1) : g;
+}
 static inline int32_t group_lo(int32_t n_views, int g, int G) { return (int32_t)((int64_t)n_views * g / G); }
 
 extern "C" int64_t mnf_score_poses_workspace_bytes(int32_t n_members, int32_t n_views, int32_t n_pix, int32_t n_classes) {

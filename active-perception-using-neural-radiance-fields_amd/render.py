@@ -656,12 +656,13 @@ def score_views(radiance_fields, estimators, poses, width, height, focal, near_p
     if hi > lo:
         o, d, h, w = _pose_rays(poses[lo:hi], width, height, focal, scale, device)
         n = hi - lo
-        # every ensemble member renders the same rays: the members advance side by side as render jobs of one call (two jobs in
-        # flight is the measured optimum: a single member is cut into two groups of views; rays stay in row-major march order —
-        # the 8x8-block order of full images buys nothing on 64x64 sub-sampled views: profiles/r03_split_experiment.txt)
+        # every ensemble member renders the same rays: the members advance side by side as render jobs of one call (four jobs in
+        # flight — the caller's stream + the library's three shared side streams — is the measured optimum for these small views,
+        # profiles/r03_hw_queues.txt: two members are cut into two groups of views each, one member into four; rays stay in row-major
+        # march order — the 8x8-block order of full images buys nothing on 64x64 sub-sampled views: profiles/r03_split_experiment.txt)
         M = len(radiance_fields)
         outs = _render_jobs([(rf, est, o, d) for rf, est in zip(radiance_fields, estimators)], h * w, 1024, near_plane, 1e10, render_step_size,
-                            torch.zeros(3), cone_angle, alpha_thre, 1e-4, True, 8, None, max(1, 2 // M))
+                            torch.zeros(3), cone_angle, alpha_thre, 1e-4, True, 8, None, max(1, 4 // M))
         totals = [r["total"] for r in outs]
         rv = [r["rgb_var"].reshape(n, h * w, 3) for r in outs]; dv = [r["depth_var"].reshape(n, h * w) for r in outs]
         ac = [r["acc"].reshape(n, h * w) for r in outs]; sm = [r["sem"].reshape(n, h * w, -1) for r in outs]

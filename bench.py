@@ -627,11 +627,11 @@ def main():
               "samples_per_ray_rank0": evaluated / max(1, (256 // world) * 4096 * 2),
               "samples_per_s_rank0": evaluated * ssteps / dt_s,
               "per_rank_compute_ms": [1e3 * float(p[0]) for p in per_rank], "per_rank_gather_ms": [1e3 * float(p[1]) for p in per_rank],
-              "render_jobs_in_flight": 2,
+              "render_jobs_in_flight": 4,
               "collective": "one all_gather_into_tensor of [V/N,4] float64 per pass" if world > 1 else "none (single rank)",
               "workload": "BASELINE config 4: scene 102344250 (two trained stand-ins: seeds 9 and 10), 256 candidate poses in free "
                           "space, 64x64 rays each (linspace sub-sample of 640x640), probabilistic render + predictive-information terms; the two "
-                          "ensemble members advance side by side as render jobs of one call"}
+                          "ensemble members advance side by side, each cut into two groups of views: four render jobs of one call (the caller's stream + three shared side streams)"}
         if world > 1:
             full, _ = score_call(poses256, False)
             same = bool(torch.equal(full, terms))
