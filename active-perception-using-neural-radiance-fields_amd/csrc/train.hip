@@ -537,10 +537,13 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
 // are DOUBLES: ds_add_f32 retires about one lane every 2.5 clocks per CU (4 x slower than the loads feed it), ds_add_f64 and the integer
 // adds run at the rate of the loads (tools/bin_bench.hip, profiles/r03_bin_bench.txt).  A list that
 // is full sends its items to the gradient with float atomics as before, so the bins only need to be sized for a uniform hash.
-constexpr int kBinEntriesLog2 = 12;
+#ifndef MNF_BIN_LOG2
+#define MNF_BIN_LOG2 12
+#endif
+constexpr int kBinEntriesLog2 = MNF_BIN_LOG2;
 constexpr uint32_t kBinEntries = 1u << kBinEntriesLog2;     // x 4 features x 8 bytes = 128 KB of LDS per workgroup of pass B
 constexpr int kMaxBins = 512;                                // per level: tables up to 2^21 entries
-constexpr int kBinThreadsB = 1024;
+constexpr int kBinThreadsB = MNF_BIN_LOG2 >= 12 ? 1024 : 512;
 
 struct BinArgs {
     const float *positions;   // normalised positions [N,3]
