@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(64) visibility_kernel(int32_t n_rays, const in
 __device__ __forceinline__ void smooth_l1(float x, float &val, float &grad) {      // beta = 1
     const float ax = fabsf(x);
     val = ax < 1.0f ? 0.5f * x * x : ax - 0.5f;
-    grad = ax < 1.0f ? x : (x > 0.0f ? 1.0f : -1.0f);
+    grad = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);      // torch's branch order: a NaN difference gives a NaN gradient (the guard of pipeline.py:520-529 then drops the step)
 }
 
 __global__ void __launch_bounds__(256) loss_kernel(int32_t n_rays, int32_t C, const float *__restrict__ rgb, const float *__restrict__ depth,

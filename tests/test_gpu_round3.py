@@ -542,3 +542,31 @@ def test_multi_level_fused_train_step_and_scoring():
     terms_py, score_py = RD.score_views(fields, ests, poses, 640, 640, 320.0, 0.1, 1e-3, 0.025, 0.004, 0.01, DEV)
     terms_c, score_c = RD.score_poses(fields, ests, poses, 640, 640, 320.0, 0.1, 1e-3, 0.025, 0.004, 0.01, DEV)
     assert torch.equal(terms_py, terms_c) and float(score_py) == float(score_c) and np.isfinite(float(score_c))
+
+
+def test_nan_targets_skip_the_step_through_the_binned_scatter():
+    """pipeline.py:520-529: a step whose gradients hold a NaN is dropped.  Here the NaN arrives through the whole fused chain at a batch large enough for the fine
+    levels to go through the binned scatter (items keep non-finite values non-finite, the LDS sums are doubles): one NaN target pixel -> the loss and the table
+    gradient are non-finite, the guard raises the skip flag on the device, `FusedAdam` leaves parameters, moments and step count untouched; the same batch without
+    the NaN then steps normally."""
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene(log2_hashmap_size=15, seed=6)
+    hip, est = H.hip_field(sc).train(), H.hip_estimator(sc).train()
+    o, d, pix, dep, lab = (t.to(DEV) for t in _train_batch(sc, 3, 48, 48, 0))
+    opt = FusedAdam(hip.parameters(), lr=1e-3, eps=1e-15).bind_field(hip)
+    before = [p.detach().clone() for p in hip.parameters()]
+    bad = pix.clone(); bad[17, 1] = float("nan")
+    bk = torch.tensor([0.3, 0.3, 0.3], device=DEV)
+    r = RD.train_step(hip, est, opt, RD.Rays(o, d), bad, dep, lab, bk, step=3, **H.RENDER_KW)
+    assert r["n_rendering_samples"] >= 8192                         # the product library uses the bins from 8192 samples
+    assert r["skipped"] and not np.isfinite(float(r["loss"]))
+    n_mlp = hip.mlp_base.params.numel() - 4 * hip._table_entries()
+    assert not bool(torch.isfinite(hip.mlp_base.params.grad[n_mlp:]).all())       # the NaN reached the table gradient (fine levels: through the bins)
+    for p, b in zip(hip.parameters(), before):
+        assert torch.equal(p.detach(), b)
+    assert all(float(opt.state[p]["step"]) == 0 for p in hip.parameters() if p.numel() and p in opt.state)
+    r = RD.train_step(hip, est, opt, RD.Rays(o, d), pix, dep, lab, bk, step=5, **H.RENDER_KW)
+    assert not r["skipped"] and np.isfinite(float(r["loss"]))
+    assert any(not torch.equal(p.detach(), b) for p, b in zip(hip.parameters(), before) if p.numel())
+    assert bool(torch.isfinite(hip.mlp_base.params.detach()).all())
