@@ -535,7 +535,25 @@ extern "C" int mnf_run_bounds(const int64_t *ray_indices, int64_t n_samples, int
 
 extern "C" int64_t mnf_scan_workspace_bytes(int64_t n) { return n < 0 ? -1 : (ceil_div(n > 0 ? n : 1, kScanTile) + 1) * (int64_t)sizeof(int64_t); }
 
+// short inputs (the per-ray counts of a train batch): one workgroup, one launch instead of three (each small launch is ~5 us of the stream's time)
+constexpr int kScanSmall = 256 * 64;
+__global__ void __launch_bounds__(256) scan_small_kernel(const int64_t *__restrict__ in, int64_t n, int64_t *__restrict__ out, int64_t *__restrict__ total_out) {
+    __shared__ int64_t s_wave[4];
+    const int per = (int)((n + 255) / 256);                      // consecutive values per thread (<= 64)
+    const int64_t base = (int64_t)threadIdx.x * per;
+    int64_t v = 0;
+    for (int k = 0; k < per; ++k) if (base + k < n) v += in[base + k];
+    int64_t total;
+    int64_t run = block_exclusive_scan_256(v, s_wave, total);
+    for (int k = 0; k < per; ++k) if (base + k < n) { const int64_t x = in[base + k]; out[base + k] = run; run += x; }
+    if (threadIdx.x == 0 && total_out) *total_out = total;
+}
+
 static int exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, int64_t *total, int64_t *tiles, hipStream_t s) {
+    if (n <= kScanSmall && in != out) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(256), 0, s, in, n, out, total);
+        return launch_status("scan_small_kernel");
+    }
     const int64_t n_tiles = ceil_div(n, kScanTile);
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, in, n, tiles);
     hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, s, tiles, n_tiles, total);

@@ -1278,6 +1278,47 @@ __global__ void __launch_bounds__(256) adam_guarded_kernel(float *__restrict__ p
     }
 }
 
+// The three parameter vectors of a field in ONE launch each (guard, step counts, update): mnf_field_optimizer_step issued 3 + 3 + 3 launches, most of them ~5 us of nothing.
+struct Adam3 {
+    float *p[3]; const float *g[3]; float *m[3], *v[3]; float *step[3];
+    int64_t n[3];
+};
+__global__ void __launch_bounds__(256) count_nan3_kernel(const Adam3 a, int32_t *__restrict__ count) {
+    int local = 0;
+    const int64_t n01 = a.n[0] + a.n[1], total = n01 + a.n[2];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)blockDim.x * gridDim.x) {
+        const float x = i < a.n[0] ? a.g[0][i] : (i < n01 ? a.g[1][i - a.n[0]] : a.g[2][i - n01]);
+        local += !(fabsf(x) <= 3.4028234664e38f);
+    }
+    if (__ballot(local != 0) != 0ull && local) atomicAdd(count, local);
+}
+__global__ void adam_prepare3_kernel(const Adam3 a, const int32_t *__restrict__ skip, float lr, float beta1, float beta2, float *__restrict__ hyper) {
+    const int k = threadIdx.x;
+    if (k >= 3) return;
+    const bool sk = skip && *skip != 0;
+    float st = *a.step[k];
+    if (!sk) { st += 1.0f; *a.step[k] = st; }
+    const double bc1 = 1.0 - pow((double)beta1, (double)st), bc2 = 1.0 - pow((double)beta2, (double)st);
+    hyper[4 * k] = (float)((double)lr / bc1); hyper[4 * k + 1] = (float)sqrt(bc2); hyper[4 * k + 2] = sk ? 1.0f : 0.0f;
+}
+__global__ void __launch_bounds__(256) adam_guarded3_kernel(const Adam3 a, float beta1, float beta2, float eps, const float *__restrict__ hyper,
+                                                            _Float16 *__restrict__ half_out, int64_t half_from) {
+    if (hyper[2] != 0.0f) return;
+    const int64_t n01 = a.n[0] + a.n[1], total = n01 + a.n[2];
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)blockDim.x * gridDim.x) {
+        const int k = j < a.n[0] ? 0 : (j < n01 ? 1 : 2);
+        const int64_t i = k == 0 ? j : (k == 1 ? j - a.n[0] : j - n01);
+        const float step_size = hyper[4 * k], bc2_sqrt = hyper[4 * k + 1];
+        const float gi = a.g[k][i];
+        const float mi = a.m[k][i] + (gi - a.m[k][i]) * (1.0f - beta1);
+        const float vi = a.v[k][i] * beta2 + (1.0f - beta2) * gi * gi;
+        a.m[k][i] = mi; a.v[k][i] = vi;
+        const float pn = a.p[k][i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        a.p[k][i] = pn;
+        if (k == 0 && half_out && i >= half_from) half_out[i - half_from] = (_Float16)pn;
+    }
+}
+
 __global__ void __launch_bounds__(256) count_nan_kernel(const float *__restrict__ g, int64_t n, int32_t *__restrict__ count) {
     int local = 0;
     // NaN as the reference's guard (pipeline.py:520-529), and +-Inf as well: an overflowed fp16 activation gradient shows up
@@ -1381,16 +1422,25 @@ extern "C" int mnf_field_optimizer_step(mnf_field_t f, float *const *params_host
     MNF_REQUIRE(f && params_host && grads_host && exp_avg_host && exp_avg_sq_host && step_dev_host && hyper_dev, "field_optimizer_step: null argument");
     MNF_REQUIRE(f->params_loaded, "field_optimizer_step: the handle holds no parameters yet (mnf_field_set_params)");
     const int64_t n[3] = {f->n_base, f->n_head, f->n_sem};
-    int rc;
+    Adam3 a;
+    for (int k = 0; k < 3; ++k) {
+        MNF_REQUIRE(n[k] == 0 || (params_host[k] && grads_host[k] && exp_avg_host[k] && exp_avg_sq_host[k] && step_dev_host[k]), "field_optimizer_step: null pointer");
+        a.p[k] = params_host[k]; a.g[k] = grads_host[k]; a.m[k] = exp_avg_host[k]; a.v[k] = exp_avg_sq_host[k]; a.step[k] = step_dev_host[k]; a.n[k] = n[k];
+    }
+    MNF_REQUIRE(n[0] > 0 && n[1] > 0 && n[2] > 0, "field_optimizer_step: empty parameter vector");
+    hipStream_t s = as_stream(stream);
+    const int64_t total = n[0] + n[1] + n[2];
     if (count_nonfinite) {
         MNF_REQUIRE(skip_dev, "field_optimizer_step: counting non-finite gradients needs the skip flag");
-        for (int k = 0; k < 3; ++k) { rc = mnf_count_nan(grads_host[k], n[k], skip_dev, stream); if (rc) return rc; }
+        const int64_t blocks = ceil_div(total, 256 * 8);
+        hipLaunchKernelGGL(count_nan3_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, a, skip_dev);
     }
-    for (int k = 0; k < 3; ++k) {
-        rc = mnf_adam_step_guarded(params_host[k], grads_host[k], exp_avg_host[k], exp_avg_sq_host[k], n[k], lr, beta1, beta2, eps, step_dev_host[k], skip_dev,
-                                   hyper_dev + 4 * k, k == 0 ? f->d_table : nullptr, k == 0 ? f->n_base_mlp : 0, stream);
-        if (rc) return rc;
-    }
+    hipLaunchKernelGGL(adam_prepare3_kernel, dim3(1), dim3(64), 0, s, a, (const int32_t *)skip_dev, lr, beta1, beta2, hyper_dev);
+    const int64_t blocks = ceil_div(total, 256 * 4);
+    hipLaunchKernelGGL(adam_guarded3_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, a, beta1, beta2, eps, (const float *)hyper_dev,
+                       reinterpret_cast<_Float16 *>(f->d_table), (int64_t)f->n_base_mlp);
+    int rc = launch_status("adam_guarded3_kernel");
+    if (rc) return rc;
     return mnf_field_refresh_weights(f, params_host[0], params_host[1], params_host[2], stream);
 }
 

@@ -40,9 +40,16 @@ __device__ __forceinline__ U4 philox4x32_10(U4 ctr, uint32_t k0, uint32_t k1) {
 }
 
 // occ_grid.py:181-189: near / far planes, stratified jitter near += U[0,1) * step (Philox counter (ray, 0, 7, 0), key = seed)
+// Also the step's small zero-fills (loss terms, counters, skip flag, the two small gradient vectors): five separate memsets were five launches of ~5 us.
 __global__ void __launch_bounds__(256) planes_kernel(int32_t n, float near_plane, float far_plane, float step, int32_t stratified, uint32_t s0,
-                                                     uint32_t s1, float *__restrict__ nearp, float *__restrict__ farp) {
+                                                     uint32_t s1, float *__restrict__ nearp, float *__restrict__ farp, float *__restrict__ losses,
+                                                     int64_t *__restrict__ counts, int32_t *__restrict__ skip, float *__restrict__ g_head, int64_t n_head,
+                                                     float *__restrict__ g_sem, int64_t n_sem) {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < 4) { losses[r] = 0.f; counts[r] = 0; }
+    if (r == 0) *skip = 0;
+    for (int64_t i = r; i < n_head; i += (int64_t)gridDim.x * blockDim.x) g_head[i] = 0.f;
+    for (int64_t i = r; i < n_sem; i += (int64_t)gridDim.x * blockDim.x) g_sem[i] = 0.f;
     if (r >= n) return;
     float v = near_plane;
     if (stratified) v += ((float)(philox4x32_10({(uint32_t)r, 0u, 7u, 0u}, s0, s1).x & 0xFFFFFFu) * 5.9604644775390625e-08f) * step;
@@ -282,16 +289,12 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     const int C = f->cfg.num_semantic_classes;
     const int64_t cells = (int64_t)res_x * res_y * res_z;
     const int rblocks = (n_rays + 255) / 256;
-    MNF_HIP(hipMemsetAsync(losses, 0, 4 * sizeof(float), s));
-    MNF_HIP(hipMemsetAsync(counts_dev, 0, 4 * sizeof(int64_t), s));
-    MNF_HIP(hipMemsetAsync(skip_dev, 0, sizeof(int32_t), s));
-    MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));
-    MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
-    MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
+    MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));           // (losses, counters, skip flag, g_head, g_sem: zeroed by planes_kernel)
     int64_t *eff = w.totals + 4;                                           // [0] marched, [1] kept samples the kernels behind the guards work on
     // ---- occupancy sampling (occ_grid.py:80-238): march, density pre-pass, visibility filter
     hipLaunchKernelGGL(planes_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
-                       opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp);
+                       opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp, losses, counts_dev, skip_dev, g_head,
+                       (int64_t)f->n_head, g_sem, (int64_t)f->n_sem);
     double *mean_part = reinterpret_cast<double *>(w.totals + 8);          // 128 doubles behind the counters
     const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
     MNF_REQUIRE(n_levels <= 4, "train_step: at most 4 occupancy levels");
