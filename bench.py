@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the second, hipEvent-instrumented passes")
     ap.add_argument("--no-views1", action="store_true", help="skip the one-view-per-call and random-weight passes (profiling runs)")
+    ap.add_argument("--render-jobs", type=int, default=2, choices=[1, 2, 4],
+                    help="render jobs in flight in the timed 800x800 pass (2 = the reported configuration; 1 = launches back to back on one stream, the form "
+                         "the roofline pass uses: a rocprofv3 --stats run with 1 gives per-launch durations that can be compared with roofline.avg_launch_ms)")
     ap.add_argument("--train-dtypes", default="f16,bf16", help="matrix-core operand types of the train leg")
     return ap.parse_args()
 
@@ -410,7 +413,7 @@ def main():
 
         V = args.views
         log("render800: timed pass")
-        dt, samples = render_pass(V, args.steps, args.warmup, False)                # the reported value: no instrumentation
+        dt, samples = render_pass(V, args.steps, args.warmup, False, n_split=args.render_jobs)      # the reported value: no instrumentation
         log(f"render800: {1e3 * dt / args.steps:.2f} ms/step, {samples / (n_per_view * V * args.steps):.1f} samples/ray")
         line["value"] = n_per_view * V * world * args.steps / dt
         line["ms_per_step"] = 1e3 * dt / args.steps
@@ -419,7 +422,7 @@ def main():
                                            "64x2 heads", "views_per_step": V, "rays_per_step_per_gpu": n_per_view * V,
                                "ms_per_view": 1e3 * dt / args.steps / V, "samples_per_ray": samples / (n_per_view * V * args.steps),
                                "samples_per_s": samples * world / dt,
-                               "render_jobs_in_flight": min(2, V),
+                               "render_jobs_in_flight": min(args.render_jobs, V),
                                "march_order": "8x8 pixel blocks inside every view (mnf_render_opts.view_order); per-ray results do not depend on it"})
         if not args.no_kernel_timing:
             # second pass of the same K steps, ONE job in flight, hipEvent pairs around every field-kernel launch (hipEventRecord

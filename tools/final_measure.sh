@@ -16,6 +16,7 @@ stats() {   # stats <tag> <bench args...>: rocprofv3 kernel stats of one workloa
 }
 if has prof; then
   stats render800 --workload render800 --no-views1
+  stats render800_serial --workload render800 --no-views1 --render-jobs 1        # one job in flight: per-launch durations comparable with roofline.avg_launch_ms
   stats train --workload train --steps 20 --warmup 5
   stats score --workload score256 --steps 3
 fi
