@@ -12,6 +12,7 @@ running on libmi355nerf.so.
 """
 import collections
 import ctypes
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -375,6 +376,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
     st = _TRAIN_STATE.get(key)
     if st is None:
         st = _TRAIN_STATE[key] = dict(cap_m=R * 384, cap_k=R * 192, pending=[])
+        weakref.finalize(radiance_field, _TRAIN_STATE.pop, key, None)      # (the key holds id(field): drop the entry with the field, or a later field could inherit it)
     # counts of earlier lazy steps (copied to pinned memory behind each step): adapt the bounds, surface their errors.  Everything that
     # has arrived is read; the step enqueued two calls ago is waited for (the host is at least a step ahead of the GPU: no stall), so a
     # bound that is too small is corrected at most two steps late.
