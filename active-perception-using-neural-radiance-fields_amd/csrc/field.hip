@@ -72,7 +72,8 @@ struct ColData {
     float ts, te;
 };
 
-__device__ __forceinline__ ColData load_cols(const KernelArgs &args, int64_t tile, int lane) {
+template <class A>
+__device__ __forceinline__ ColData load_cols(const A &args, int64_t tile, int lane) {
     const int64_t col = tile * kWaveSamples + lane;
     ColData c;
     typedef const int32_t __attribute__((address_space(4))) *HdrPtr;
@@ -83,8 +84,8 @@ __device__ __forceinline__ ColData load_cols(const KernelArgs &args, int64_t til
     return c;
 }
 
-template <int MODE, bool WANT_DIR>
-__device__ __forceinline__ void fetch_sample(const KernelArgs &args, const ColData &cd, int64_t col, int64_t n, float (&xn)[3],
+template <int MODE, bool WANT_DIR, class A>
+__device__ __forceinline__ void fetch_sample(const A &args, const ColData &cd, int64_t col, int64_t n, float (&xn)[3],
                                              float (&dir)[3], TileSample &tsm, bool &valid, bool &selector) {
     valid = col < n;
     float pos[3] = {0.f, 0.f, 0.f};
@@ -222,6 +223,29 @@ __global__ void __launch_bounds__(kEncodeThreads, 6) encode_kernel(const KernelA
 }
 
 // ------------------------------------------------------------------ the fused kernel
+// The compositing epilogue's arguments (eleven pointers and a few scalars) re-read from the kernel-argument segment where the epilogue runs, instead of living in
+// SGPRs for the whole launch: the kernel sits at the SGPR limit (106) and the compiler had moved these loop-invariant pointers to VGPRs and from there to SCRATCH
+// (72 bytes per lane, ~27 scratch loads per tile).  Scalar loads from the kernarg segment hit the scalar cache; the empty asm keeps them inside the tile loop.
+// (the same for a scalar the epilogue compares per-lane row indices with: hoisted out of the tile loop, the 32 `row < C` lane masks alone took 64 SGPRs)
+// by-value copy of a small struct that lives in the constant address space (the kernel-argument segment): scalar loads
+template <class T>
+__device__ __forceinline__ T from_constant(const T __attribute__((address_space(4))) *p) {
+    T out;
+    __builtin_memcpy(&out, (const void *)p, sizeof(T));
+    return out;
+}
+__device__ __forceinline__ int in_loop(int x) { asm volatile("" : "+s"(x)); return x; }
+// ... and for the lane index: the epilogue's lane-role predicates (first / last lane, DPP row, half) and row offsets are one v_cmp / v_or each; kept across the
+// loop they were ~15 SGPR pairs and a dozen VGPRs, spilled to VGPR lanes (v_readlane + wait states at every use) and to scratch
+__device__ __forceinline__ int in_loop_v(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ FusedRender fr_of_kernarg() {
+    typedef const FusedRender __attribute__((address_space(4))) *FrPtr;
+    typedef const char __attribute__((address_space(4))) *BytePtr;
+    FrPtr p = (FrPtr)((BytePtr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernelArgs, io) + offsetof(FieldIO, fr));
+    asm volatile("" : "+s"(p));
+    return from_constant(p);
+}
+
 template <int W, int NH, int MODE, bool DENSITY_ONLY, bool SAVE = false, bool ENC = false>
 __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs args) {
     using L = Layout<W, NH>;
@@ -279,6 +303,8 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     if (wave >= 4) __builtin_amdgcn_s_sleep(64);    // stagger the two waves of a SIMD
 #endif
 
+    typedef const KernelArgs __attribute__((address_space(4))) KArgs;
+    KArgs *const kp = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     WaveCounters wc;
     ColData cd_next = {-1, 64, 0, 0.f, 0.f};
     // MODE 3 (ray-major density pass, `mnf_field_density_rays`): a wave takes whole rays (dynamically, one atomic per ray)
@@ -288,14 +314,19 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     int64_t ray_start = 0, ray_cnt = 0, ray_base = 0;
     float ray_sdt = 0.0f;
     for (int64_t grp = g_first; MODE == 3 || grp < g_end; grp += g_step) {
+        // Everything the tile reads from the kernel arguments is re-read from the kernel-argument segment (scalar loads, scalar cache) where it is used: kept in SGPRs for
+        // the whole launch these ~60 dwords pushed the kernel over the 102 SGPRs (spills to VGPR lanes: ~220 v_readlane with their wait states per tile, and to scratch).
+        KArgs *lp = kp;
+        asm volatile("" : "+s"(lp));
+        KArgs &la = *lp;
         int64_t tile = tile0 + grp * wpb + wave, col, n_eff = n;
         if (MODE == 3) {
-            if (ray_base >= ray_cnt || ray_sdt > args.io.sdt_stop) {
+            if (ray_base >= ray_cnt || ray_sdt > la.io.sdt_stop) {
                 int r = 0;
-                if (lane == 0) r = atomicAdd(args.io.ray_counter, 1);
+                if (lane == 0) r = atomicAdd(la.io.ray_counter, 1);
                 r = __builtin_amdgcn_readfirstlane(r);
-                if (r >= args.io.n_rays) break;
-                ray_start = args.io.chunk_starts[r]; ray_cnt = args.io.chunk_cnts[r]; ray_base = 0; ray_sdt = 0.0f;
+                if (r >= la.io.n_rays) break;
+                ray_start = la.io.chunk_starts[r]; ray_cnt = la.io.chunk_cnts[r]; ray_base = 0; ray_sdt = 0.0f;
                 if (ray_cnt == 0) continue;
             }
             col = ray_start + ray_base + lane; n_eff = ray_start + ray_cnt; ray_base += kWaveSamples;
@@ -318,7 +349,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         TileSample tsm;
         bool valid, selector;
         fetch_sample<MODE, !DENSITY_ONLY>(args, cd, col, n_eff, xn, dir, tsm, valid, selector);
-        const LevelsPtr lv = levels_here(args.levels);
+        const LevelsPtr lv = levels_here(la.levels);
         const bool in_box = __ballot(valid && !selector) == 0ull;   // wave-uniform: the cheap dense-level wrap applies
 
         // ---- hash encode: all 16 levels of this lane's sample (one k-step = 4 levels = 32 gathers in flight),
@@ -326,7 +357,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         half8 bfeat[CT][4];
         if (ENC) {
             // features were produced by encode_kernel, already in fragment order
-            const half8 *src = reinterpret_cast<const half8 *>(args.io.enc) + tile * 512 + lane;
+            const half8 *src = reinterpret_cast<const half8 *>(la.io.enc) + tile * 512 + lane;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -361,7 +392,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 hash_prep(level_meta(lv, 4 * MNF_KB(0) + q), xn, prep[0][q], in_box);
-                hash_load(args.table, prep[0][q], v[0][q], 4 * MNF_KB(0) + q >= MNF_NT_FROM);
+                hash_load(la.table, prep[0][q], v[0][q], 4 * MNF_KB(0) + q >= MNF_NT_FROM);
             }
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
@@ -370,7 +401,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         hash_prep(level_meta(lv, 4 * MNF_KB(kb + 1) + q), xn, prep[nxt][q], in_box);
-                        hash_load(args.table, prep[nxt][q], v[nxt][q], 4 * MNF_KB(kb + 1) + q >= MNF_NT_FROM);
+                        hash_load(la.table, prep[nxt][q], v[nxt][q], 4 * MNF_KB(kb + 1) + q >= MNF_NT_FROM);
                     }
                 }
 #if MNF_EXP == 10
@@ -403,10 +434,10 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #endif
 
         // the mask-dump base of this tile
-        uint8_t *mdump = SAVE ? args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
+        uint8_t *mdump = SAVE ? la.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
         if (SAVE) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) save_pair<false>(args.train, tile, T::rX + 16 * ks, lane, stage, bfeat[0][ks], bfeat[1][ks]);
+            for (int ks = 0; ks < 4; ++ks) save_pair<false>(from_constant(&la.train), tile, T::rX + 16 * ks, lane, stage, bfeat[0][ks], bfeat[1][ks]);
         }
 
 #if MNF_EXP_LOCK
@@ -425,7 +456,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         if (SAVE) {
 #pragma unroll
             for (int k = 0; k < L::KSW; ++k) {
-                save_pair<true>(args.train, tile, T::rH0 + 16 * k, lane, stage, hb[0][k], hb[1][k]);
+                save_pair<true>(from_constant(&la.train), tile, T::rH0 + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) if (MNF_EXP_SAVE != 3) mdump[((T::mH0 + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
             }
@@ -441,7 +472,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             if (SAVE) {
 #pragma unroll
                 for (int k = 0; k < L::KSW; ++k) {
-                    save_pair<true>(args.train, tile, T::rH0 + (l + 1) * W + 16 * k, lane, stage, hb[0][k], hb[1][k]);
+                    save_pair<true>(from_constant(&la.train), tile, T::rH0 + (l + 1) * W + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) if (MNF_EXP_SAVE != 3) mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
                 }
@@ -449,7 +480,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         }
         f32x16 bo[CT];
         dense_out<L::KSW>(s_w + L::o_b_out * 64, lane, hb, bo);
-        if (args.out_fp16) round_outputs_fp16(bo);     // tcnn hands its network outputs over in fp16 (ngp.py:181-200 casts them back)
+        if (la.out_fp16) round_outputs_fp16(bo);     // tcnn hands its network outputs over in fp16 (ngp.py:181-200 casts them back)
 
         // Results come back in MFMA layout: lane (c, h) holds rows {8g + 4h + i} of column c of tile ct.
         // The density logit (row 0) of this lane's OWN sample sits in lane (lane&31) register 0 of tile h.
@@ -458,7 +489,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         const float sigma = selector ? expf((h ? logit_t1 : logit_t0) - 1.0f) : 0.0f;   // ngp.py:79, :193-195
 
         if (DENSITY_ONLY) {
-            if (col < n_eff && args.io.density) args.io.density[col] = sigma;
+            if (col < n_eff && la.io.density) la.io.density[col] = sigma;
             if (MODE == 3) {
                 float sdt = valid ? sigma * (tsm.te - tsm.ts) : 0.0f;
 #pragma unroll
@@ -470,7 +501,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 
 #if MNF_KNOCK & 2
         if (MODE == 2 && !SAVE) {   // diagnostic build: density only, no head networks, no compositing
-            if (sigma == 1.2345e30f) args.io.fr.acc[0] = sigma;
+            if (sigma == 1.2345e30f) la.io.fr.acc[0] = sigma;
             continue;
         }
 #endif
@@ -481,7 +512,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         if (MODE == 2 && !SAVE) {
             const float sdt0 = valid ? sigma * (tsm.te - tsm.ts) : 0.0f;
             const float alpha0 = 1.0f - expf(-sdt0);
-            const bool keep0 = valid && !(args.io.fr.alpha_thre > 0.f && !(alpha0 >= args.io.fr.alpha_thre));
+            const bool keep0 = valid && !(la.io.fr.alpha_thre > 0.f && !(alpha0 >= la.io.fr.alpha_thre));
             if (__ballot(keep0) == 0ull) {
                 const float zrgb[3] = {0.f, 0.f, 0.f};
                 f32x16 zsem[CT];
@@ -489,7 +520,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) zsem[ct][i] = 0.0f;
-                fused_composite(args.io.fr, args.C, lane, tsm, sigma, zrgb, zsem, wc);
+                fused_composite(fr_of_kernarg(), in_loop(la.C), in_loop_v(lane), tsm, sigma, zrgb, zsem, wc);
                 continue;
             }
         }
@@ -511,15 +542,15 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             hin[0][1] = bgeo[0][0]; hin[1][1] = bgeo[1][0];
         }
         if (SAVE) {
-            save_pair<false>(args.train, tile, T::rS, lane, stage, hin[0][0], hin[1][0]);
-            save_pair<true>(args.train, tile, T::rG, lane, stage, hin[0][1], hin[1][1]);
+            save_pair<false>(from_constant(&la.train), tile, T::rS, lane, stage, hin[0][0], hin[1][0]);
+            save_pair<true>(from_constant(&la.train), tile, T::rG, lane, stage, hin[0][1], hin[1][1]);
         }
         half8 h1[CT][L::KSh], h2[CT][L::KSh];
         f32x16 out_rgb[CT], out_sem[CT];
         auto save_hidden = [&](const half8 (&a)[CT][L::KSh], int row0, int mblk) {
 #pragma unroll
             for (int k = 0; k < L::KSh; ++k) {
-                save_pair<true>(args.train, tile, row0 + 16 * k, lane, stage, a[0][k], a[1][k]);
+                save_pair<true>(from_constant(&la.train), tile, row0 + 16 * k, lane, stage, a[0][k], a[1][k]);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) if (MNF_EXP_SAVE != 3) mdump[((mblk + k) * CT + ct) * 64] = frag_mask(a[ct][k]);
             }
@@ -530,14 +561,14 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         dense_relu<L::RTh, L::KSh>(s_w + L::o_h_hid * 64, lane, h1, h2);
         if (SAVE) save_hidden(h2, T::rHH2, T::mHH2);
         dense_out<L::KSh>(s_w + L::o_h_out * 64, lane, h2, out_rgb);
-        if (args.out_fp16) round_outputs_fp16(out_rgb);
+        if (la.out_fp16) round_outputs_fp16(out_rgb);
         // semantic head (ngp.py:158-169, :215-220)
         dense_relu<L::RTh, 1>(s_w + L::o_s_in * 64, lane, bgeo, h1);
         if (SAVE) save_hidden(h1, T::rHS1, T::mHS1);
         dense_relu<L::RTh, L::KSh>(s_w + L::o_s_hid * 64, lane, h1, h2);
         if (SAVE) save_hidden(h2, T::rHS2, T::mHS2);
         dense_out<L::KSh>(s_w + L::o_s_out * 64, lane, h2, out_sem);
-        if (args.out_fp16) round_outputs_fp16(out_sem);
+        if (la.out_fp16) round_outputs_fp16(out_sem);
 
 #if MNF_EXP_LOCK
         if (MODE == 2 && !SAVE && !DENSITY_ONLY) {
@@ -567,32 +598,32 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sink += out_sem[ct][i];
-            if (sink == 1.2345e30f) args.io.fr.acc[0] = sink;
+            if (sink == 1.2345e30f) la.io.fr.acc[0] = sink;
 #else
-            fused_composite(args.io.fr, args.C, lane, tsm, sigma, rgb, out_sem, wc);
+            fused_composite(fr_of_kernarg(), in_loop(la.C), in_loop_v(lane), tsm, sigma, rgb, out_sem, wc);
 #endif
             continue;
         }
         if (col < n) {
-            if (args.io.density) args.io.density[col] = sigma;
-            if (args.io.rgb) { args.io.rgb[3 * col] = rgb[0]; args.io.rgb[3 * col + 1] = rgb[1]; args.io.rgb[3 * col + 2] = rgb[2]; }
+            if (la.io.density) la.io.density[col] = sigma;
+            if (la.io.rgb) { la.io.rgb[3 * col] = rgb[0]; la.io.rgb[3 * col + 1] = rgb[1]; la.io.rgb[3 * col + 2] = rgb[2]; }
         }
         // semantic logits: lane (c, h) writes rows 8g + 4h + i of column c for both tiles
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int64_t scol = tile * kWaveSamples + ct * 32 + (lane & 31);
-            if (args.io.sem && scol < n) {
+            if (la.io.sem && scol < n) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int row = 8 * g + 4 * h + i;
-                        if (row < args.C) args.io.sem[scol * args.C + row] = out_sem[ct][4 * g + i];
+                        if (row < la.C) la.io.sem[scol * la.C + row] = out_sem[ct][4 * g + i];
                     }
             }
         }
     }
-    if (MODE == 2) flush_counters(args.io.fr, wc, lane);
+    if (MODE == 2) flush_counters(fr_of_kernarg(), wc, lane);
 }
 
 // ------------------------------------------------------------------ parameter preparation kernels
