@@ -38,6 +38,7 @@ struct mnf_field_s {
     bool params_loaded;
     std::vector<int32_t> frag_src_host;   // host copy of the gather table (train.hip inverts it: parameter -> fragment slot)
     void *train_state;        // lazily built by train.hip (transposed fragments, weight-gradient job table)
+    int bwd_mode = 0;         // mnf_field_set_backward_mode: 0 auto (fused backward where supported), 1 split kernels (dgrad + wgrad), 2 fused required
 };
 
 namespace mnf {
@@ -97,13 +98,16 @@ struct TrainBuf {
     uint8_t *masks;   // [tiles][mask_blocks][CT][64]
     int64_t Np;
     int32_t rows;
+    void *xenc;       // fused backward (csrc/fused_bwd.h): instead of `act` / `masks`, [tiles][kEncBlocks][64] x 16 B — the tile's hash features
+                      // (blocks ks * 2 + ct, ks < 4) and its SH fragment (blocks 8 + ct) in B-fragment order; NULL selects the full dump
 };
+constexpr int kEncBlocks = 10;
 
 // dispatchers on the handle's operand type (defined once, in the fp16 translation units)
 void free_train_state(mnf_field_t f);
 int launch_field(mnf_field_t f, const FieldIO &io, bool density_only, hipStream_t stream, const TrainBuf *train = nullptr);
 // training forward / backward with the sample count optionally on the device (io.n_dev64 / n_dev; n = upper bound)
-int forward_train(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream);
+int forward_train(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream, bool deterministic = false);
 int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb, const float *d_density,
              const float *d_sem, const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale,
              float *g_base, float *g_head, float *g_sem, bool zero_grads, bool positions_normalized, bool deterministic, hipStream_t stream);
@@ -115,7 +119,8 @@ int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_
                         hipStream_t stream);                                                                                         \
     void free_train_state_impl(mnf_field_t f);                                                                                       \
     int64_t train_workspace_bytes_impl(mnf_field_t f, int64_t n);                                                                    \
-    int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream);         \
+    int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream,          \
+                           bool deterministic);                                                                                      \
     int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb,                  \
                       const float *d_density, const float *d_sem, const float *rgb, const float *density, void *workspace,          \
                       int64_t workspace_bytes, float loss_scale, float *g_base, float *g_head, float *g_sem, bool zero_grads,       \

@@ -246,10 +246,14 @@ __device__ __forceinline__ FusedRender fr_of_kernarg() {
     return from_constant(p);
 }
 
-template <int W, int NH, int MODE, bool DENSITY_ONLY, bool SAVE = false, bool ENC = false>
+template <int W, int NH, int MODE, bool DENSITY_ONLY, int SAVEK = 0, bool ENC = false>
 __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs args) {
     using L = Layout<W, NH>;
     using T = TrainLayout<W, NH>;
+    // SAVEK: 0 inference; 1 training with the full activation dump (split backward: dgrad + wgrad kernels); 2 training for the fused backward
+    // (csrc/fused_bwd.h): only the encoded inputs leave the kernel — the hash features and the SH fragment, in B-fragment order, 160 B per sample
+    constexpr bool SAVE = SAVEK == 1;
+    constexpr bool SAVE_X = SAVEK == 2;
     constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
     __shared__ half8 s_w[kBlocks * 64];
     __shared__ half_t s_stage[SAVE ? kWavesPerBlock * kStageHalves : 1];   // training: per-wave transpose tile of the activation dump
@@ -439,6 +443,13 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) save_pair<false>(from_constant(&la.train), tile, T::rX + 16 * ks, lane, stage, bfeat[0][ks], bfeat[1][ks]);
         }
+        half8 *xdump = SAVE_X ? reinterpret_cast<half8 *>(la.train.xenc) + tile * (kEncBlocks * 64) + lane : nullptr;
+        if (SAVE_X) {      // lane-linear 16-byte stores, no transpose: block (ks * 2 + ct) of the tile
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) xdump[(ks * 2 + ct) * 64] = bfeat[ct][ks];
+        }
 
 #if MNF_EXP_LOCK
         if (MODE == 2 && !SAVE && !DENSITY_ONLY) {
@@ -545,6 +556,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             save_pair<false>(from_constant(&la.train), tile, T::rS, lane, stage, hin[0][0], hin[1][0]);
             save_pair<true>(from_constant(&la.train), tile, T::rG, lane, stage, hin[0][1], hin[1][1]);
         }
+        if (SAVE_X) { xdump[8 * 64] = hin[0][0]; xdump[9 * 64] = hin[1][0]; }     // the SH fragment (blocks 8, 9)
         half8 h1[CT][L::KSh], h2[CT][L::KSh];
         f32x16 out_rgb[CT], out_sem[CT];
         auto save_hidden = [&](const half8 (&a)[CT][L::KSh], int row0, int mblk) {
@@ -742,7 +754,7 @@ static std::vector<int32_t> build_frag_table(const mnf_field_config &cfg) {
 template <int W, int NH>
 static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, int grid, hipStream_t stream, const TrainBuf *train) {
     KernelArgs a;
-    a.train = train ? *train : TrainBuf{nullptr, nullptr, 0, 0};
+    a.train = train ? *train : TrainBuf{nullptr, nullptr, 0, 0, nullptr};
     a.table = reinterpret_cast<const tab4 *>(f->d_table);
     a.frags = reinterpret_cast<const half8 *>(f->d_frags);
     std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));
@@ -753,9 +765,12 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     a.levels = reinterpret_cast<const LevelMeta *>(reinterpret_cast<const char *>(f->d_frags) + (size_t)f->shape.blocks_total * 1024);
     a.io = io;
 #define MNF_LAUNCH(MODE, DO) hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO>), dim3(grid), dim3(kThreads), 0, stream, a)
-    if (train) {
-        if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else hipLaunchKernelGGL((field_kernel<W, NH, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    if (train && train->xenc) {
+        if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else hipLaunchKernelGGL((field_kernel<W, NH, 0, false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+    } else if (train) {
+        if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else hipLaunchKernelGGL((field_kernel<W, NH, 0, false, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
     } else if (io.enc) {
         // two launches: gather at high occupancy, then the register-heavy MLP chain on ready-made fragments
         half8 *enc = reinterpret_cast<half8 *>(const_cast<void *>(io.enc));
@@ -768,13 +783,13 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
         if (io.mlp_waves > 0 && io.mlp_waves <= kWavesPerBlock) a.active_waves = io.mlp_waves;
         if (io.phase == 1) {
         } else if (density_only) {
-            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, true, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, true, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-            else hipLaunchKernelGGL((field_kernel<W, NH, 2, true, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, true, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, true, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else hipLaunchKernelGGL((field_kernel<W, NH, 2, true, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
         } else {
-            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, false, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-            else hipLaunchKernelGGL((field_kernel<W, NH, 2, false, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, false, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else hipLaunchKernelGGL((field_kernel<W, NH, 2, false, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
         }
     } else if (density_only) {
         if (io.mode == 0) MNF_LAUNCH(0, true); else if (io.mode == 1) MNF_LAUNCH(1, true); else if (io.mode == 3) MNF_LAUNCH(3, true); else MNF_LAUNCH(2, true);

@@ -427,7 +427,7 @@ extern "C" int64_t mnf_render_workspace_bytes(int64_t n_rays, int32_t rays_per_v
 namespace mnf {
 namespace {
 
-struct JobRes {          // per-thread pool: pinned flag words, events, side streams
+struct JobRes {          // per-(thread, device) pool: pinned flag words, events, side streams
     int32_t *flags = nullptr;
     hipEvent_t ev_flags = nullptr, ev_join = nullptr;
     hipStream_t side = nullptr;
@@ -449,7 +449,15 @@ struct JobPool {
         return MNF_OK;
     }
 };
-JobPool &job_pool() { static thread_local JobPool p; return p; }
+// One pool per host thread AND device: events and the shared side streams belong to the device that was current when they
+// were created, so a later call for a field on another GPU must not record device-0 events on device-1 streams.
+JobPool *job_pool() {
+    static thread_local std::vector<JobPool> pools;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) { set_error("render: no current device"); return nullptr; }
+    if ((int)pools.size() <= dev) pools.resize(dev + 1);
+    return &pools[dev];
+}
 
 struct RenderJob {
     mnf_field_t f;
@@ -668,7 +676,9 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
                                int64_t *total_samples, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
     MNF_REQUIRE(n_rays >= 0, "render_test: negative n_rays");
     if (n_rays == 0) return MNF_OK;
-    JobPool &pool = job_pool();
+    JobPool *pp = job_pool();
+    if (!pp) return MNF_ERR_HIP;
+    JobPool &pool = *pp;
     int rc = pool.ensure(1);
     if (rc) return rc;
     std::vector<RenderJob> jobs(1);
@@ -681,7 +691,9 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
 extern "C" int mnf_render_jobs(const mnf_render_job *jobs_host, int32_t n_jobs, int32_t res_x, int32_t res_y, int32_t res_z,
                                const float *aabb_host, const mnf_render_opts *opts, mnf_stream_t stream) {
     MNF_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= 64 && opts, "render_jobs: bad arguments");
-    JobPool &pool = job_pool();
+    JobPool *pp = job_pool();
+    if (!pp) return MNF_ERR_HIP;
+    JobPool &pool = *pp;
     int rc = pool.ensure((size_t)n_jobs);
     if (rc) return rc;
     hipStream_t s0 = as_stream(stream);

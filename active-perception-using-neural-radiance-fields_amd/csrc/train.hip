@@ -329,6 +329,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradJob *__res
     g[jb.param_off + (int64_t)(jb.n0 + row) * jb.stride + col] = sum * inv_scale;   // every weight belongs to exactly one tile
 }
 
+#include "fused_bwd.h"
+
 // ------------------------------------------------------------------ hash-grid gradient scatter
 // Deterministic mode (mnf_train_opts.deterministic): the table gradient is accumulated in 64-bit fixed point (value * 2^56, integer
 // atomics: associative, so the result does not depend on the order in which the adds arrive), then converted to fp32 once.  The
@@ -466,8 +468,10 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
 #endif
 #if MNF_EXP_SCATTER != 1      /* timing experiment: 1 = the walk without its atomics */
             if (DET) {
-                if (fabsf(acc) <= 3.0e38f) atomicAdd(q_dst + ((size_t)(m.offset + idx) << 2) + feat, to_fixed(acc));
-                else atomicAdd(args.q_bad, 1ull);          // NaN / Inf: reported through the converted gradient (fixed_to_float_kernel)
+                // a contribution outside the fixed-point range would saturate silently into a wrong finite gradient: it poisons the
+                // step like a non-finite one (one contribution of +-64 already means the step is beyond repair; the sum of an entry has 2x headroom)
+                if (fabsf(acc) < 64.0f) atomicAdd(q_dst + ((size_t)(m.offset + idx) << 2) + feat, to_fixed(acc));
+                else atomicAdd(args.q_bad, 1ull);          // too large / NaN / Inf: reported through the converted gradient (fixed_to_float_kernel)
             }
             else atomicAdd(g_dst + ((size_t)(m.offset + idx) << 2) + feat, acc);
 #else
@@ -870,9 +874,13 @@ static bool tables_for(int W, int NH, int C, TrainTables &tt) {
 // Transposed fragments are a re-ordering of the forward fragments the handle already holds in fp16 (every weight sits in
 // exactly one forward slot): `src_slot[i]` = forward slot of transposed element i, -1 = structural zero.  No pointer into
 // the caller's fp32 vectors is kept between calls.
+// Also clears the list cursors of the binned scatter: as a memset at the head of the bins' stream (round 3) the 2.5 KB fill was dispatched
+// at the fork, beside the first workgroups of wgrad and the walk, and took 335 us to get through (profiles/r03_train_timeline.txt) — on the
+// critical path of the step's tail.  Here it rides on a launch that runs before the fork.
 __global__ void __launch_bounds__(256) gather_fragsT_kernel(const int32_t *__restrict__ src_slot, const half_t *__restrict__ frags,
-                                                            half_t *__restrict__ dst, int64_t n) {
+                                                            half_t *__restrict__ dst, int64_t n, uint32_t *__restrict__ cursors, int n_cursors) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cursors) cursors[i] = 0u;
     if (i >= n) return;
     const int32_t s = src_slot[i];
     dst[i] = s >= 0 ? frags[s] : (half_t)0.0f;
@@ -926,6 +934,7 @@ static int ensure_train_state(mnf_field_t f) {
     if (e == hipSuccess) e = hipMemcpy(ts->d_groups, ts->tt.groups.data(), ts->tt.groups.size() * sizeof(WgradGroup), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_fragT_src, ts->tt.fragT.data(), ts->tt.fragT.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ts->d_jobs, ts->tt.jobs.data(), ts->tt.jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&ts->d_bin_cursors, (size_t)16 * kMaxBins * sizeof(uint32_t));
     // side streams: the process-wide ones (common.h shared_side_stream), not a pair per train state
     ts->side = shared_side_stream(0);
     ts->side2 = shared_side_stream(1);
@@ -964,8 +973,15 @@ void free_train_state_impl(mnf_field_t f) {
 
 struct WsView {
     half_t *act; uint8_t *masks; float *dX, *xn, *repl;
+    half8 *enc;            // fused backward: the forward's encoded inputs ([tiles][kEncBlocks][64] x 16 B) instead of act / masks
     int64_t Np, bytes;
 };
+
+// The fused backward (fused_bwd.h) serves neurons = 128 with one or two hidden layers (the reference's yaml: 128 x 2) in the float-atomic mode;
+// deterministic accumulation and the other shapes keep the split kernels (dgrad + wgrad with the activation dump).
+static bool use_fused_backward(mnf_field_t f, bool deterministic) {
+    return !deterministic && f->cfg.neurons == 128 && f->cfg.layers <= 2 && f->bwd_mode != 1;
+}
 
 static WsView carve_train(const TrainTables &tt, void *base, int64_t n) {
     WsView v;
@@ -977,6 +993,7 @@ static WsView carve_train(const TrainTables &tt, void *base, int64_t n) {
     v.dX = (float *)take((size_t)v.Np * 64 * 4);
     v.xn = (float *)take((size_t)v.Np * 3 * 4);
     v.repl = (float *)take((size_t)kReplicas * kReplMaxEntries * 4 * sizeof(float));   // private copies of the coarsest levels' gradient (scatter)
+    v.enc = (half8 *)take((size_t)(v.Np / 64) * kEncBlocks * 64 * sizeof(half8));
     v.bytes = (int64_t)off;
     return v;
 }
@@ -993,7 +1010,7 @@ int64_t train_workspace_bytes_impl(mnf_field_t f, int64_t n) {
     return carve_train(tt, nullptr, n).bytes;
 }
 
-int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream) {
+int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream, bool deterministic) {
     MNF_REQUIRE(f && f->params_loaded, "field_forward_train: parameters not loaded");
     MNF_REQUIRE(io.n >= 0, "field_forward_train: negative n");
     if (io.n == 0) return MNF_OK;
@@ -1005,7 +1022,7 @@ int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_
         set_error("field_forward_train: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)v.bytes);
         return MNF_ERR_WORKSPACE;
     }
-    TrainBuf tb = {v.act, v.masks, v.Np, ts->tt.rows};
+    TrainBuf tb = {v.act, v.masks, v.Np, ts->tt.rows, use_fused_backward(f, deterministic) ? v.enc : nullptr};
     return launch_field_impl(f, io, false, stream, &tb);
 }
 
@@ -1044,8 +1061,10 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     if (repl_levels && !deterministic) MNF_HIP(hipMemsetAsync(v.repl, 0, (size_t)kReplicas * repl_entries * 4 * sizeof(float), ts->side));
     // transposed fp16 weight fragments from the handle's forward fragments (the parameters of the last set_params)
     const int64_t n_frag = (int64_t)ts->tt.fragT.size();
-    hipLaunchKernelGGL(gather_fragsT_kernel, dim3((unsigned)ceil_div(n_frag, 256)), dim3(256), 0, s, ts->d_fragT_src,
-                       reinterpret_cast<const half_t *>(f->d_frags), ts->d_fragT, n_frag);
+    hipLaunchKernelGGL(gather_fragsT_kernel, dim3((unsigned)ceil_div(n_frag > 16 * kMaxBins ? n_frag : (int64_t)16 * kMaxBins, 256)), dim3(256), 0, s, ts->d_fragT_src,
+                       reinterpret_cast<const half_t *>(f->d_frags), ts->d_fragT, n_frag, ts->d_bin_cursors, 16 * kMaxBins);
+    const bool fused = use_fused_backward(f, deterministic);
+    if (f->bwd_mode == 2 && !fused) { set_error("field_backward: the fused backward serves neurons = 128, layers <= 2, non-deterministic mode only"); return MNF_ERR_UNSUPPORTED; }
     BwdArgs a;
     a.fragsT = reinterpret_cast<const half8 *>(ts->d_fragT);
     a.d_rgb = d_rgb; a.d_sigma = d_density; a.d_sem = d_sem; a.rgb = rgb; a.sigma = density;
@@ -1056,8 +1075,21 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     if (wgs < grid) grid = (int)wgs;
     const int W = f->cfg.neurons, NH = f->cfg.layers;
     bool ok = false;
-    const int prof_dgrad = prof_start("dgrad", s);
-#define MNF_CASE(w, nh) if (W == w && NH == nh) { launch_dgrad<w, nh>(a, grid, s); ok = true; }
+    if (fused) {      // forward recompute + backward-data + weight gradients in one launch (fused_bwd.h); the scatter below is unchanged
+        FusedBwdArgs fa;
+        fa.frags = reinterpret_cast<const half8 *>(f->d_frags); fa.fragsT = a.fragsT; fa.enc = v.enc; fa.jobs = ts->d_jobs;
+        fa.d_rgb = d_rgb; fa.d_sigma = d_density; fa.d_sem = d_sem; fa.rgb = rgb; fa.sigma = density; fa.dX = v.dX;
+        fa.g0 = g_base; fa.g1 = g_head; fa.g2 = g_sem; fa.n = n; fa.Np = v.Np; fa.n_dev = n_dev; fa.C = f->cfg.num_semantic_classes;
+        fa.out_fp16 = f->cfg.output_fp16 ? 1 : 0; fa.loss_scale = loss_scale;
+        const int64_t tiles = ceil_div(n, kWaveSamples);
+        const int fgrid = (int)(tiles < 256 ? tiles : 256);
+        ProfScope ps("fused_backward", s);
+        if (NH == 1) hipLaunchKernelGGL((fused_bwd_kernel<1>), dim3(fgrid), dim3(kFusedThreads), 0, s, fa);
+        else hipLaunchKernelGGL((fused_bwd_kernel<2>), dim3(fgrid), dim3(kFusedThreads), 0, s, fa);
+        ok = true;
+    }
+    const int prof_dgrad = fused ? -1 : prof_start("dgrad", s);
+#define MNF_CASE(w, nh) if (!fused && W == w && NH == nh) { launch_dgrad<w, nh>(a, grid, s); ok = true; }
 #ifdef MNF_DEV_ONLY_128x2
     MNF_CASE(128, 2)
 #else
@@ -1099,7 +1131,7 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         partials = ts->d_partials;
     }
     static const bool no_wgrad = diag_env("MNF_NO_WGRAD") != nullptr;    // timing experiments: the scatter alone on the chip
-    if (!no_wgrad) {
+    if (!no_wgrad && !fused) {
         ProfScope ps("wgrad", s);
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * split, 4)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
                            split, v.act, n, n_dev, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem, partials);
@@ -1165,7 +1197,6 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
             MNF_HIP(hipMalloc((void **)&ts->d_bin_items, need * sizeof(float4)));
             ts->bin_items = need;
         }
-        if (!ts->d_bin_cursors) MNF_HIP(hipMalloc((void **)&ts->d_bin_cursors, (size_t)16 * kMaxBins * sizeof(uint32_t)));
         ba.positions = hb.positions; ba.dX = hb.dX; ba.Np = hb.Np; ba.n = n; ba.n_dev = n_dev; ba.level0 = first_binned; ba.n_levels = n_binned;
         ba.items = ts->d_bin_items; ba.cursors = ts->d_bin_cursors; ba.cap = cap; ba.g_table = hb.g_table;
         std::memcpy(ba.levels, f->levels, sizeof(ba.levels));
@@ -1194,7 +1225,7 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
             hipStream_t s2 = same_stream ? ss : ts->side2;
             MNF_HIP(hipStreamWaitEvent(s2, ts->ev_fork, 0));
             const int prof_bins = prof_start("hash_scatter_bins", s2);
-            MNF_HIP(hipMemsetAsync(ba.cursors, 0, (size_t)n_binned * kMaxBins * sizeof(uint32_t), s2));
+            // (list cursors: cleared by gather_fragsT_kernel, in front of the fork)
             // (Measured and dropped, tools/r03_walk_wgs.sh: pass B level by level or half by half on a fourth stream under the next pass A — 5.8 and 5.6 ms
             // per step against 5.55-5.6 for one launch each: walk, bins and wgrad together are bound by HBM, the order inside does not matter.)
             hipLaunchKernelGGL(bin_items_kernel, dim3((unsigned)(ceil_div(n, kBinChunk * 256) * n_binned)), dim3(256), 0, s2, ba);
@@ -1331,9 +1362,10 @@ __global__ void __launch_bounds__(256) count_nan_kernel(const float *__restrict_
 void free_train_state(mnf_field_t f) {
     if (f->cfg.mfma_bf16) bf16::free_train_state_impl(f); else f16::free_train_state_impl(f);
 }
-int forward_train(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream) {
+int forward_train(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream, bool deterministic) {
     MNF_REQUIRE(f, "field_forward_train: null handle");
-    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, io, workspace, workspace_bytes, stream) : f16::forward_train_impl(f, io, workspace, workspace_bytes, stream);
+    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, io, workspace, workspace_bytes, stream, deterministic)
+                            : f16::forward_train_impl(f, io, workspace, workspace_bytes, stream, deterministic);
 }
 int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb, const float *d_density, const float *d_sem,
              const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale, float *g_base, float *g_head,
@@ -1348,6 +1380,13 @@ int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_
 
 using namespace mnf;
 
+extern "C" int mnf_field_set_backward_mode(mnf_field_t f, int32_t mode) {
+    MNF_REQUIRE(f && mode >= 0 && mode <= 2, "field_set_backward_mode: mode must be 0 (auto), 1 (split kernels) or 2 (fused)");
+    MNF_REQUIRE(mode != 2 || (f->cfg.neurons == 128 && f->cfg.layers <= 2), "field_set_backward_mode: the fused backward serves neurons = 128, layers <= 2");
+    f->bwd_mode = mode;
+    return MNF_OK;
+}
+
 extern "C" int64_t mnf_field_train_workspace_bytes(mnf_field_t f, int64_t n) {
     if (!f) return -1;
     return f->cfg.mfma_bf16 ? bf16::train_workspace_bytes_impl(f, n) : f16::train_workspace_bytes_impl(f, n);
@@ -1361,8 +1400,8 @@ extern "C" int mnf_field_forward_train(mnf_field_t f, const float *positions, co
     FieldIO io = {};
     io.mode = 0; io.positions = positions; io.directions = directions; io.n = n;
     io.rgb = rgb; io.density = density; io.sem = sem;
-    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream))
-                            : f16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream));
+    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream), false)
+                            : f16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream), false);
 }
 
 extern "C" int mnf_field_forward_train_samples(mnf_field_t f, const float *rays_o, const float *rays_d, const int64_t *ray_indices,
@@ -1375,8 +1414,8 @@ extern "C" int mnf_field_forward_train_samples(mnf_field_t f, const float *rays_
     FieldIO io = {};
     io.mode = 1; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = ray_indices; io.t_starts = t_starts; io.t_ends = t_ends; io.n = n;
     io.rgb = rgb; io.density = density; io.sem = sem; io.positions_out = positions_out;
-    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream))
-                            : f16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream));
+    return f->cfg.mfma_bf16 ? bf16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream), false)
+                            : f16::forward_train_impl(f, io, workspace, workspace_bytes, as_stream(stream), false);
 }
 
 extern "C" int mnf_field_backward(mnf_field_t f, const float *positions, int64_t n,

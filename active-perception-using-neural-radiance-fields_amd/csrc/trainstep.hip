@@ -329,7 +329,7 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
         io.mode = 1; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = w.k_ray; io.t_starts = w.k_ts; io.t_ends = w.k_te;
         io.n = max_kept; io.n_dev64 = eff + 1;
         io.rgb = w.k_rgb; io.density = w.k_sigma; io.sem = w.k_sem; io.xn_out = w.k_pos;        // aabb-normalised: what the backward's scatter reads
-        rc = forward_train(f, io, w.field_ws, w.field_ws_bytes, s);
+        rc = forward_train(f, io, w.field_ws, w.field_ws_bytes, s, opts->deterministic != 0);
         if (rc) return rc;
     }
     const float *bk = opts->render_bkgd_dev;                               // the caller's device colour, or the by-value one

@@ -314,9 +314,22 @@ _TRAIN_STATE = {}
 _ST_MARCHED, _ST_ROW, _ST_KEPT, _ST_LABEL, _ST_EMPTY = 1, 2, 4, 8, 16
 
 
-def _grow_caps(st, marched, kept):
-    st["cap_m"] = max(st["cap_m"], int(marched * 1.3) + 1024)
-    st["cap_k"] = max(st["cap_k"], int(max(kept, marched // 2) * 1.3) + 1024)
+def _grow_caps(st, marched, kept, R):
+    """Raise the sample bounds of a field's train state after a step that overflowed them.  The state is per FIELD, not per ray
+    count (the reference changes `num_rays` after every iteration, scripts/pipeline.py:494-504, to hold the sample count near
+    `target_sample_batch_size`): it keeps an absolute bound (what the schedule holds constant) and a per-ray bound (what a
+    fixed-size batch holds constant); a call uses the larger of the two for its ray count (`_caps_for`)."""
+    st["abs_m"] = max(st["abs_m"], int(marched * 1.3) + 1024)
+    st["abs_k"] = max(st["abs_k"], int(max(kept, marched // 2) * 1.3) + 1024)
+    st["per_m"] = max(st["per_m"], marched * 1.3 / max(R, 1))
+    st["per_k"] = max(st["per_k"], max(kept, marched // 2) * 1.3 / max(R, 1))
+
+
+def _caps_for(st, R):
+    """Sample bounds of a call with R rays: generous per-ray defaults, raised by whatever earlier steps of this field overflowed.  (The bounds of a
+    fixed-size batch never shrink: the deterministic mode's partial-sum grouping depends on them, and with it the bitwise reproducibility of the
+    stand-in scenes.)"""
+    return max(R * 384, st["abs_m"], int(st["per_m"] * R)), max(R * 192, st["abs_k"], int(st["per_k"] * R))
 
 
 def _check_status(status):
@@ -372,17 +385,17 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         if p_.grad is None or p_.grad.shape != p_.shape or not p_.grad.is_contiguous():
             p_.grad = torch.empty_like(p_)
     tp, td, tl = L.contig(pixels, torch.float32), L.contig(dep, torch.float32), L.contig(sem, torch.int64)
-    key = (id(radiance_field), R)
+    key = id(radiance_field)           # one state per field whatever the ray count of the call (under the reference's schedule R changes every step)
     st = _TRAIN_STATE.get(key)
     if st is None:
-        st = _TRAIN_STATE[key] = dict(cap_m=R * 384, cap_k=R * 192, pending=[])
+        st = _TRAIN_STATE[key] = dict(abs_m=0, abs_k=0, per_m=0.0, per_k=0.0, pending=[])
         weakref.finalize(radiance_field, _TRAIN_STATE.pop, key, None)      # (the key holds id(field): drop the entry with the field, or a later field could inherit it)
     # counts of earlier lazy steps (copied to pinned memory behind each step): adapt the bounds, surface their errors.  Everything that
     # has arrived is read; the step enqueued two calls ago is waited for (the host is at least a step ahead of the GPU: no stall), so a
     # bound that is too small is corrected at most two steps late.
     pending = st["pending"]
     while pending and (sync or len(pending) > 1 or pending[0][1].query()):
-        host, ev = pending.pop(0)
+        host, ev, r_then = pending.pop(0)                       # (whatever ray count that step had: the bounds are the field's)
         ev.synchronize()
         c = host.tolist()
         st.setdefault("pinned", []).append((host, ev))
@@ -390,17 +403,19 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         if c[3] & _ST_ROW:
             raise L.MnfError("train_step: a ray has more samples than a scratch row holds (use the autograd path: fused=False)")
         if c[3] & (_ST_MARCHED | _ST_KEPT):
-            _grow_caps(st, c[0], c[1])
+            st["overflowed_steps"] = st.get("overflowed_steps", 0) + 1
+            _grow_caps(st, c[0], c[1], r_then)
     for _attempt in range(4):
         losses = torch.empty(4, device=dev)
         counts = torch.empty(4, dtype=torch.int64, device=dev)
         skip = torch.empty((), dtype=torch.int32, device=dev)
-        nbytes = int(lib.mnf_train_step_workspace_bytes(handle, R, st["cap_m"], st["cap_k"]))
+        cap_m, cap_k = _caps_for(st, R)
+        nbytes = int(lib.mnf_train_step_workspace_bytes(handle, R, cap_m, cap_k))
         ws = _workspace(dev, nbytes)
         L.launch(lib.mnf_train_step, handle, L.ptr(binaries), L.ptr(bits[0]), L.ptr(estimator.occs), res[0], res[1], res[2],
                  (ctypes.c_float * len(aabb))(*aabb), L.ptr(o), L.ptr(d), R, L.ptr(tp), L.ptr(td), L.ptr(tl), ctypes.byref(opts),
                  L.ptr(params[0].grad), L.ptr(params[1].grad), L.ptr(params[2].grad), L.ptr(losses), L.ptr(counts), L.ptr(skip),
-                 st["cap_m"], st["cap_k"], L.ptr(ws), nbytes)
+                 cap_m, cap_k, L.ptr(ws), nbytes)
         if not sync:
             break
         c = counts.tolist()                                         # the step's one host round trip, after everything is enqueued
@@ -408,7 +423,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         if c[3] & _ST_ROW:
             return None
         if c[3] & (_ST_MARCHED | _ST_KEPT):                         # a sample bound was too small: grow and redo
-            _grow_caps(st, c[0], c[1])
+            _grow_caps(st, c[0], c[1], R)
             continue
         break
     else:
@@ -424,7 +439,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         host, ev = pool.pop() if pool else (torch.empty(4, dtype=torch.int64).pin_memory(), torch.cuda.Event())
         host.copy_(counts, non_blocking=True)
         ev.record(torch.cuda.current_stream(dev))
-        st["pending"].append((host, ev))
+        st["pending"].append((host, ev, R))
         estimator.last_sampling = {"n_marched": counts[0]}
         out.update(n_rendering_samples=counts[1], n_marched=counts[0])
     return out

@@ -48,7 +48,7 @@ def leg(tag):
     for _ in range(500):
         x.add_(1.0)
     b.record(); b.synchronize()
-    print("   tiny torch kernels: %.2f us each |" % (a.elapsed_time(b) / 500 * 1e3), smi, "| caps", {k[1]: (v["cap_m"], v["cap_k"]) for k, v in RD._TRAIN_STATE.items()}, flush=True)
+    print("   tiny torch kernels: %.2f us each |" % (a.elapsed_time(b) / 500 * 1e3), smi, "| caps", {k: (v["abs_m"], v["abs_k"]) for k, v in RD._TRAIN_STATE.items()}, flush=True)
     print(f"[{variant}: {tag}] {(time.perf_counter() - t0) / 40 * 1e3:.3f} ms/step | workspaces MB {[v.numel() >> 20 for v in RD._WORKSPACES.values()]} | torch reserved MB {torch.cuda.memory_reserved() >> 20} | train states {len(RD._TRAIN_STATE)}", flush=True)
 
 
