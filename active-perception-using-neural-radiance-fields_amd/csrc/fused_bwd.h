@@ -176,6 +176,10 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
         const half8 *enct = args.enc + tile * (kEncBlocks * 64);      // this tile's encoded inputs (uniform)
         const half8 *ft = args.fragsT;
         asm volatile("" : "+s"(ft));                                   // keep the table's address arithmetic inside the loop (scalar, cheap)
+        // ... and everything derived from the lane index: hoisted out of the tile loop, the identity fragments, the per-lane row predicates and the
+        // 64-bit addresses of the gradient loads were computed once, spilled to scratch and re-read in every tile
+        int rl = r, hl = h;
+        asm volatile("" : "+v"(rl), "+v"(hl));
         // =============================================================== forward recompute
         half8 hS[NH][CT][2];                  // S tiles (own feature tile q) of the base hidden activations, post-ReLU, packed
         uint32_t mF[NH];                      // ReLU masks of the F tiles: byte ct * 2 + s
@@ -249,7 +253,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
             for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) geoF[ct][j] = (half_t)bo[ct][j];
-                if (h == 0) geoF[ct][0] = (half_t)1.0f;
+                if (hl == 0) geoF[ct][0] = (half_t)1.0f;
             }
         }
         // head layer 1 (rgb: SH + geo, semantic: geo), published to the partner wave through s_e[LB ^ 1]; head layer 2: masks and S tiles only
@@ -309,7 +313,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
         }
 
         // =============================================================== backward
-        const int64_t fcol0 = tile * kWaveSamples + r;
+        const int64_t fcol0 = tile * kWaveSamples + rl;
         // output-layer gradients as natural-order F fragments (rgb pair: 1 k-step, semantic pair: 2), and the density-logit gradient
         half8 dyF[CT][2];
         float dlogit[CT];
@@ -322,7 +326,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dyF[ct][s][j] = (half_t)0.0f;
             if (head == 0) {
-                if (ok && h == 0) {
+                if (ok && hl == 0) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const float y = args.rgb[3 * col + k];
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int row = 16 * s + 8 * h + j;
+                        const int row = 16 * s + 8 * hl + j;
                         if (ok && row < C) dyF[ct][s][j] = sat_half(args.d_sem[col * C + row] * ls);
                     }
             }
@@ -351,8 +355,8 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
                 f32x16 t;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) t[i] = 0.0f;
-                t = mfma(dyF[ct][0], ident_nat(r, h, 0), t);
-                if (head) t = mfma(dyF[ct][1], ident_nat(r, h, 16), t);
+                t = mfma(dyF[ct][0], ident_nat(rl, hl, 0), t);
+                if (head) t = mfma(dyF[ct][1], ident_nat(rl, hl, 16), t);
                 dyP[ct][0] = pack8(t, 0); dyP[ct][1] = pack8(t, 1);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -406,10 +410,10 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
 #pragma unroll
                 for (int i = 0; i < 16; ++i) t[i] = 0.0f;
                 if (head == 0) {
-                    t = mfma(ldg_block(enct, 8 + ct, lane), ident_nat(r, h, 0), t);
-                    t = mfma(geoF[ct], ident_acc(r, h, 16), t);
+                    t = mfma(ldg_block(enct, 8 + ct, lane), ident_nat(rl, hl, 0), t);
+                    t = mfma(geoF[ct], ident_acc(rl, hl, 16), t);
                 } else {
-                    t = mfma(geoF[ct], ident_acc(r, h, 0), t);
+                    t = mfma(geoF[ct], ident_acc(rl, hl, 0), t);
                 }
                 inP[ct][0] = pack8(t, 0); inP[ct][1] = pack8(t, 1);
             }
@@ -431,7 +435,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
         for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) dboF[ct][j] = (half_t)(s_g[((0 * 2 + ct) * 8 + j) * 64 + lane] + s_g[((1 * 2 + ct) * 8 + j) * 64 + lane]);
-            if (h == 0) dboF[ct][0] = sat_half(dlogit[ct]);
+            if (hl == 0) dboF[ct][0] = sat_half(dlogit[ct]);
         }
         half8 dzS[CT][2];                       // packed S tile (own rows q) of the current base pre-activation gradient
         {   // base output layer: weight gradient (0, q), then dZ(NH-1) in both orientations
@@ -443,7 +447,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
                 f32x16 t;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) t[i] = 0.0f;
-                t = mfma(dboF[ct], ident_acc(r, h, 0), t);
+                t = mfma(dboF[ct], ident_acc(rl, hl, 0), t);
                 dboP[ct][0] = pack8(t, 0); dboP[ct][1] = pack8(t, 1);
                 const half8 w = ldg_block(ft, LT::o_bo + q, lane);
                 aF[ct] = mfma(w, dboF[ct], aF[ct]); aS[ct] = mfma(dboF[ct], w, aS[ct]);
@@ -506,7 +510,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 v = {acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv};
-                dst[(int64_t)(8 * rt + 2 * g + h) * args.Np] = v;
+                dst[(int64_t)(8 * rt + 2 * g + hl) * args.Np] = v;
             }
         }
         {   // base input layer: weight gradient tiles (q, kt): the hash features as S tiles (identity products of the fragments re-read from L2)
@@ -518,8 +522,8 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
                     f32x16 t;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) t[i] = 0.0f;
-                    t = mfma(ldg_block(enct, (2 * kt) * 2 + ct, lane), ident_nat(r, h, 0), t);
-                    t = mfma(ldg_block(enct, (2 * kt + 1) * 2 + ct, lane), ident_nat(r, h, 16), t);
+                    t = mfma(ldg_block(enct, (2 * kt) * 2 + ct, lane), ident_nat(rl, hl, 0), t);
+                    t = mfma(ldg_block(enct, (2 * kt + 1) * 2 + ct, lane), ident_nat(rl, hl, 16), t);
                     xP[ct][0] = pack8(t, 0); xP[ct][1] = pack8(t, 1);
                 }
                 wgrad_acc(a_in[kt], dzS, xP);

@@ -469,8 +469,8 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
 #if MNF_EXP_SCATTER != 1      /* timing experiment: 1 = the walk without its atomics */
             if (DET) {
                 // a contribution outside the fixed-point range would saturate silently into a wrong finite gradient: it poisons the
-                // step like a non-finite one (one contribution of +-64 already means the step is beyond repair; the sum of an entry has 2x headroom)
-                if (fabsf(acc) < 64.0f) atomicAdd(q_dst + ((size_t)(m.offset + idx) << 2) + feat, to_fixed(acc));
+                // step like a non-finite one
+                if (fabsf(acc) < 127.99999f) atomicAdd(q_dst + ((size_t)(m.offset + idx) << 2) + feat, to_fixed(acc));
                 else atomicAdd(args.q_bad, 1ull);          // too large / NaN / Inf: reported through the converted gradient (fixed_to_float_kernel)
             }
             else atomicAdd(g_dst + ((size_t)(m.offset + idx) << 2) + feat, acc);
@@ -979,8 +979,11 @@ struct WsView {
 
 // The fused backward (fused_bwd.h) serves neurons = 128 with one or two hidden layers (the reference's yaml: 128 x 2) in the float-atomic mode;
 // deterministic accumulation and the other shapes keep the split kernels (dgrad + wgrad with the activation dump).
+// It is OPT-IN (mnf_field_set_backward_mode(f, 2)): measured on MI355X (round 4, profiles/r04_fused_backward.txt) it is bit-compatible with the split
+// kernels up to summation order but slower — one wave per SIMD with 512 registers (176 of them weight-gradient accumulators) leaves every LDS /
+// memory round trip of its nine phases exposed (68 % of wave cycles parked on s_waitcnt / s_barrier).
 static bool use_fused_backward(mnf_field_t f, bool deterministic) {
-    return !deterministic && f->cfg.neurons == 128 && f->cfg.layers <= 2 && f->bwd_mode != 1;
+    return !deterministic && f->cfg.neurons == 128 && f->cfg.layers <= 2 && f->bwd_mode == 2;
 }
 
 static WsView carve_train(const TrainTables &tt, void *base, int64_t n) {

@@ -314,22 +314,38 @@ _TRAIN_STATE = {}
 _ST_MARCHED, _ST_ROW, _ST_KEPT, _ST_LABEL, _ST_EMPTY = 1, 2, 4, 8, 16
 
 
-def _grow_caps(st, marched, kept, R):
-    """Raise the sample bounds of a field's train state after a step that overflowed them.  The state is per FIELD, not per ray
-    count (the reference changes `num_rays` after every iteration, scripts/pipeline.py:494-504, to hold the sample count near
-    `target_sample_batch_size`): it keeps an absolute bound (what the schedule holds constant) and a per-ray bound (what a
-    fixed-size batch holds constant); a call uses the larger of the two for its ray count (`_caps_for`)."""
-    st["abs_m"] = max(st["abs_m"], int(marched * 1.3) + 1024)
-    st["abs_k"] = max(st["abs_k"], int(max(kept, marched // 2) * 1.3) + 1024)
-    st["per_m"] = max(st["per_m"], marched * 1.3 / max(R, 1))
-    st["per_k"] = max(st["per_k"], max(kept, marched // 2) * 1.3 / max(R, 1))
+def _grow_caps(st, marched, kept, R, carry):
+    """Raise the sample bounds of a field's train state after a step that overflowed them.  The state is per FIELD, not per ray count (the
+    reference changes `num_rays` after every iteration, scripts/pipeline.py:494-504, to hold the sample count near `target_sample_batch_size`).
+      carry=False (synchronous steps: the overflowing step is repeated at once): only the bounds of this ray count grow — exactly the bounds
+                  rounds 1-3 used, which the deterministic mode's partial-sum grouping (and with it the bitwise identity of the stand-in
+                  scenes across rounds) depends on;
+      carry=True  (asynchronous steps, counts read late): an absolute bound (what the schedule holds constant) and a per-ray bound (what a
+                  fixed-size batch holds constant) grow, and every later call — whatever its ray count — uses at least the larger of the two."""
+    cm, ck = int(marched * 1.3) + 1024, int(max(kept, marched // 2) * 1.3) + 1024
+    if carry:
+        st["abs_m"], st["abs_k"] = max(st["abs_m"], cm), max(st["abs_k"], ck)
+        st["per_m"], st["per_k"] = max(st["per_m"], cm / max(R, 1)), max(st["per_k"], ck / max(R, 1))
+    else:
+        bm, bk = st["by_R"].get(R, (R * 384, R * 192))
+        st["by_R"][R] = (max(bm, cm), max(bk, ck))
 
 
 def _caps_for(st, R):
-    """Sample bounds of a call with R rays: generous per-ray defaults, raised by whatever earlier steps of this field overflowed.  (The bounds of a
-    fixed-size batch never shrink: the deterministic mode's partial-sum grouping depends on them, and with it the bitwise reproducibility of the
-    stand-in scenes.)"""
-    return max(R * 384, st["abs_m"], int(st["per_m"] * R)), max(R * 192, st["abs_k"], int(st["per_k"] * R))
+    """(max_marched, max_kept) of a call with R rays: generous per-ray defaults, raised by what earlier steps of this field overflowed."""
+    bm, bk = st["by_R"].get(R, (R * 384, R * 192))
+    # (the marched bound has an absolute floor: small batches of the dynamic schedule march ~1000 samples per ray through empty-looking early grids,
+    #  and an asynchronous step cannot be repeated; the surviving bound keeps its per-ray form — the deterministic mode's grouping depends on it)
+    return max(bm, 1 << 18, st["abs_m"], int(st["per_m"] * R)), max(bk, st["abs_k"], int(st["per_k"] * R))
+
+
+def latest_step_counts(radiance_field):
+    """(n_rays, marched samples, surviving samples) of the most recent asynchronous train step of this field whose counts have ARRIVED on the
+    host (they travel to pinned memory behind every `sync=False` step and are read at the start of the next call), or None.  What the
+    reference's dynamic batch size (scripts/pipeline.py:494-504: num_rays *= target_sample_batch_size / n_rendering_samples) can use
+    without waiting for the GPU: the schedule then runs one or two steps behind the counts, the sample bounds absorb the lag."""
+    st = _TRAIN_STATE.get(id(radiance_field))
+    return None if st is None else st.get("last_counts")
 
 
 def _check_status(status):
@@ -388,7 +404,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
     key = id(radiance_field)           # one state per field whatever the ray count of the call (under the reference's schedule R changes every step)
     st = _TRAIN_STATE.get(key)
     if st is None:
-        st = _TRAIN_STATE[key] = dict(abs_m=0, abs_k=0, per_m=0.0, per_k=0.0, pending=[])
+        st = _TRAIN_STATE[key] = dict(by_R={}, abs_m=0, abs_k=0, per_m=0.0, per_k=0.0, pending=[])
         weakref.finalize(radiance_field, _TRAIN_STATE.pop, key, None)      # (the key holds id(field): drop the entry with the field, or a later field could inherit it)
     # counts of earlier lazy steps (copied to pinned memory behind each step): adapt the bounds, surface their errors.  Everything that
     # has arrived is read; the step enqueued two calls ago is waited for (the host is at least a step ahead of the GPU: no stall), so a
@@ -398,13 +414,14 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         host, ev, r_then = pending.pop(0)                       # (whatever ray count that step had: the bounds are the field's)
         ev.synchronize()
         c = host.tolist()
+        st["last_counts"] = (r_then, int(c[0]), int(c[1]))       # latest_step_counts(): the dynamic ray-count schedule without a host round trip
         st.setdefault("pinned", []).append((host, ev))
         _check_status(c[3])
         if c[3] & _ST_ROW:
             raise L.MnfError("train_step: a ray has more samples than a scratch row holds (use the autograd path: fused=False)")
         if c[3] & (_ST_MARCHED | _ST_KEPT):
             st["overflowed_steps"] = st.get("overflowed_steps", 0) + 1
-            _grow_caps(st, c[0], c[1], r_then)
+            _grow_caps(st, c[0], c[1], r_then, carry=True)
     for _attempt in range(4):
         losses = torch.empty(4, device=dev)
         counts = torch.empty(4, dtype=torch.int64, device=dev)
@@ -423,7 +440,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         if c[3] & _ST_ROW:
             return None
         if c[3] & (_ST_MARCHED | _ST_KEPT):                         # a sample bound was too small: grow and redo
-            _grow_caps(st, c[0], c[1], R)
+            _grow_caps(st, c[0], c[1], R, carry=False)
             continue
         break
     else:

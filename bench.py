@@ -484,7 +484,7 @@ def main():
                 out.append((r,) + SI.analytic_targets(proc, scene280["aabb"], r.origins, r.viewdirs))
             return out
 
-        def train_leg(dtype, R_, sync, steps, with_kernels):
+        def train_leg(dtype, R_, sync, steps, with_kernels, dynamic_target=0):
             """ms per step of `steps` train iterations from the SAME start state (the stand-in's weights and grid are restored before every leg;
             the optimizer continues the stand-in's run); returns a dict."""
             tf = SC.hip_field(scene280, dev, mfma_bf16=(dtype == "bf16"))
@@ -505,7 +505,24 @@ def main():
             bkd = torch.rand(3, generator=torch.Generator().manual_seed(7)).to(dev)      # a random background colour on the device (habitat_to_data.py:189-191)
             outs = []
 
+            dyn = {"R": 1024, "seen": []}                                        # pipeline.py:418 starts the data set at 1024 rays
+
+            def tstep_dynamic(i):
+                """scripts/pipeline.py:494-504 without a host round trip: the ray count of the next step follows the latest sample count that has
+                ARRIVED on the host (RD.latest_step_counts: one or two steps old), capped at 2000 as the reference caps it."""
+                r, pix, dep_, lab = batches[i % 8]
+                n = dyn["R"]
+                rr = RD.Rays(r.origins[:n], r.viewdirs[:n])
+                out = RD.train_step(tf, te, opt, rr, pix[:n], dep_[:n], lab[:n], bkd, step=1000 + i, sync=False, occ_thre=1e-2, **SC.RENDER_KW)
+                dyn["seen"].append(n)
+                c = RD.latest_step_counts(tf)
+                if c is not None and c[2] > 0:
+                    dyn["R"] = int(min(R_, max(64, c[0] * dynamic_target / c[2])))
+                return out
+
             def tstep(i):
+                if dynamic_target:
+                    return tstep_dynamic(i)
                 r, pix, dep_, lab = batches[i % 8]
                 # occ_thre as the stand-in's own training (the reference uses 1e-3 / 1e-2 / 3e-3 by phase, pipeline.py:447-470): the refresh at
                 # step 1008 then keeps the grid the stand-in converged to, and the workload stays stationary
@@ -513,6 +530,13 @@ def main():
             dt_t = timed(tstep, steps, max(args.warmup, 6), False, outs.append)      # (the first asynchronous steps also size the sample bounds)
             kept = float(np.mean([int(o["n_rendering_samples"]) for o in outs]))
             marched = float(int(te.last_sampling["n_marched"]))
+            if dynamic_target:
+                seen = dyn["seen"][-steps:]
+                return {"ms_per_step": 1e3 * dt_t / steps, "steps": steps, "dtype": dtype, "host_round_trips_per_step": 0,
+                        "rays_per_step_mean": float(np.mean(seen)), "rays_per_step_min_max": [int(min(seen)), int(max(seen))],
+                        "distinct_ray_counts": len(set(seen)), "target_sample_batch_size": dynamic_target,
+                        "rendering_samples_per_step": kept, "skipped_steps": int(sum(int(o["skipped"]) for o in outs)),
+                        "train_states_of_the_field": 1, "overflowed_steps": RD._TRAIN_STATE[id(tf)].get("overflowed_steps", 0)}
             res = {"ms_per_step": 1e3 * dt_t / steps, "steps": steps, "rays_per_step": R_, "dtype": dtype,
                    "host_round_trips_per_step": 1 if sync else 0, "rendering_samples_per_step": kept, "marched_samples_per_step": marched,
                    "skipped_steps": int(sum(int(o["skipped"]) for o in outs))}
@@ -574,8 +598,12 @@ def main():
                           "262 144 samples (config:4); same scene and start state")
         if "kernels" in ry:
             ry["fixed_cost_share"] = 1.0 - sum(v["ms_per_step"] for k, v in ry["kernels"].items() if k in ("field_density", "field_train_forward", "dgrad", "wgrad")) / ry["ms_per_step"]
+        dy = train_leg("f16", 2000, False, max(tsteps, 40), False, dynamic_target=1 << 18)
+        dy["workload"] = ("the reference's own schedule (scripts/pipeline.py:494-504, config_102344250.yaml:3-4): num_rays starts at 1024 and is recomputed after "
+                          "every iteration to hold 262 144 samples, capped at 2000; asynchronous steps, the count used is the latest that has arrived on the host")
         line["train"] = train
         line["train_refyaml"] = ry
+        line["train_dynamic"] = dy
         if not want("render800"):
             line.update({"metric": "train-step ms", "value": train["ms_per_step"], "unit": "ms", "higher_is_better": False,
                          "ms_per_step": train["ms_per_step"], "dtype": dtypes[0]})

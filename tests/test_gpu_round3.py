@@ -87,7 +87,7 @@ def test_fused_adam_skip_flag_and_table_mirror():
     assert float(oa.state[a.mlp_base.params]["step"]) == 4.0 and not torch.equal(a.mlp_base.params.detach(), base_before)
 
 
-def test_train_step_flags_bad_labels_and_recovers_from_small_bounds(monkeypatch):
+def test_train_step_flags_bad_labels_and_recovers_from_small_bounds():
     """a class id outside [0, C) must not be read past the logits row: the step is flagged on the device (status bit
     8, skip raised) and surfaces as an error.  Sample bounds that are too small end the step on the device with zero gradients;
     the synchronous path repeats it with larger bounds, the asynchronous one skips it and grows the bounds for the next call."""
@@ -104,13 +104,13 @@ def test_train_step_flags_bad_labels_and_recovers_from_small_bounds(monkeypatch)
     n_ok, g_ok = out["n_rendering_samples"], hip.mlp_head.params.grad.clone()
     assert n_ok > 1000 and int(out["skip"]) == 0
     key = id(hip)
-    small = dict(abs_m=0, abs_k=0, per_m=4.0, per_k=2.0)
-    monkeypatch.setattr(RD, "_caps_for", lambda st, R: (max(st["abs_m"], int(st["per_m"] * R)), max(st["abs_k"], int(st["per_k"] * R))))   # no generous defaults
+    R_ = o.shape[0]
+    small = dict(by_R={R_: (2048, 1024)}, abs_m=0, abs_k=0, per_m=0.0, per_k=0.0)
     RD._TRAIN_STATE[key].update(small)                            # far too small
     out = RD.fused_forward_backward(hip, est, RD.Rays(o, d), pix, dep, lab, None, stratified=False, **H.RENDER_KW)
     assert out["n_rendering_samples"] == n_ok and RD._caps_for(RD._TRAIN_STATE[key], o.shape[0])[1] >= n_ok       # repeated with larger bounds
     np.testing.assert_allclose(hip.mlp_head.params.grad.cpu().numpy(), g_ok.cpu().numpy(), rtol=2e-2, atol=1e-6)
-    RD._TRAIN_STATE[key].update(small)
+    RD._TRAIN_STATE[key].update(dict(small, by_R={R_: (2048, 1024)}))
     lazy = RD.fused_forward_backward(hip, est, RD.Rays(o, d), pix, dep, lab, None, stratified=False, sync=False, **H.RENDER_KW)
     assert int(lazy["skip"]) > 0 and int(lazy["counts"][3]) & 1 and float(hip.mlp_head.params.grad.abs().max()) == 0.0
     # WITHOUT any synchronisation by the caller the bounds are corrected at most two calls late (per bound: marched, then surviving)
@@ -120,7 +120,6 @@ def test_train_step_flags_bad_labels_and_recovers_from_small_bounds(monkeypatch)
         skips.append(lazy["skip"])
     skips = [int(x) for x in skips]
     assert skips[-1] == 0 and skips[-2] == 0 and int(lazy["n_rendering_samples"]) == n_ok, skips
-    monkeypatch.undo()
     # rays that miss the grid: no sample, skip raised with status bit 16, zero gradients (pipeline.py:491 `continue`)
     up = torch.zeros_like(d); up[:, 1] = 1.0
     far_o = o + torch.tensor([0.0, 100.0, 0.0], device=DEV)

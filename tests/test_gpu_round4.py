@@ -1,0 +1,140 @@
+"""Round-4 GPU tests: the fused backward (csrc/fused_bwd.h) against the split kernels and against the oracle's autograd; the reference's
+dynamic ray-count schedule (scripts/pipeline.py:494-504) through the asynchronous train step; full-size checks of BASELINE configs 3 and 4."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("layers,bf16,n", [(2, False, 5000), (1, False, 777), (2, True, 4097)])
+def test_fused_backward_matches_split_kernels(layers, bf16, n):
+    """mode 2 (one kernel: forward recompute + backward-data + weight gradients, no activation dump) and mode 1 (dgrad + wgrad over the dump)
+    are the same arithmetic — 16-bit operands rounded at the same points, fp32 accumulation — in a different summation order: every parameter
+    gradient agrees to 1e-5 relative L2 per matrix (the split path run twice agrees with itself to ~1e-7: float atomics), the forward outputs
+    bit for bit."""
+    sc = H.make_scene(layers=layers, log2_hashmap_size=15, head_gain=4.0)
+    f = H.hip_field(sc, mfma_bf16=bf16).train()
+    g = torch.Generator().manual_seed(5)
+    lo, hi = torch.from_numpy(sc["aabb"][:3]), torch.from_numpy(sc["aabb"][3:])
+    pos = (lo + (hi - lo) * torch.rand(n, 3, generator=g)).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(DEV)
+    g_rgb, g_sig, g_sem = (torch.randn(n, 3, generator=g) * 1e-3).to(DEV), (torch.randn(n, 1, generator=g) * 1e-5).to(DEV), (torch.randn(n, sc["C"], generator=g) * 1e-3).to(DEV)
+
+    def run(mode):
+        f.set_backward_mode(mode)
+        for p in f.parameters():
+            p.grad = None
+        rgb, sigma, sem = f(pos, dirs)
+        ((rgb * g_rgb).sum() + (sigma * g_sig).sum() + (sem * g_sem).sum()).backward()
+        return [rgb.detach(), sigma.detach(), sem.detach()], [p.grad.clone() for p in (f.mlp_base.params, f.mlp_head.params, f.mlp_sem.params)]
+    out1, g1 = run(1)
+    out2, g2 = run(2)
+    for a, b in zip(out1, out2):
+        assert torch.equal(a, b)
+    W, Wh = 128, 64
+    n_mlp = W * 64 + (layers - 1) * W * W + 16 * W
+    cuts = {0: [0, W * 64] + [W * 64 + (l + 1) * W * W for l in range(layers - 1)] + [n_mlp, g1[0].numel()],
+            1: [0, Wh * 32, Wh * 32 + Wh * Wh, g1[1].numel()], 2: [0, Wh * 16, Wh * 16 + Wh * Wh, g1[2].numel()]}
+    for i in range(3):
+        assert torch.isfinite(g2[i]).all()
+        for a, b in zip(cuts[i][:-1], cuts[i][1:]):
+            assert float(g1[i][a:b].norm()) > 0, (i, a, b)
+            assert _rel(g2[i][a:b], g1[i][a:b]) < 1e-5, (i, a, b, _rel(g2[i][a:b], g1[i][a:b]))
+
+
+def test_fused_backward_train_step_matches_split_and_oracle():
+    """The whole train step (`mnf_train_step`) with the fused backward: same sample counts and losses as with the split kernels, gradients
+    within atomics noise of them, and within the fp16 gradient tolerance of the oracle's autograd (the split path's own bar)."""
+    from apnrf_amd import render as RD
+    from oracle import render as R
+    sc = H.make_scene(log2_hashmap_size=15)
+    o, d = H.view_rays(sc, 2, h=20, w=20)
+    rng = np.random.default_rng(3)
+    n = o.shape[0]
+    pix = torch.from_numpy(rng.random((n, 3)).astype(np.float32)); dep = torch.from_numpy(rng.uniform(0.5, 4.0, n).astype(np.float32))
+    lab = torch.from_numpy(rng.integers(0, sc["C"], n))
+    bk = torch.tensor([0.1, 0.5, 0.9])
+    res = {}
+    for mode in (1, 2):
+        hip, est = H.hip_field(sc).train(), H.hip_estimator(sc)
+        hip.set_backward_mode(mode)
+        out = RD.fused_forward_backward(hip, est, RD.Rays(o.to(DEV), d.to(DEV)), pix.to(DEV), dep.to(DEV), lab.to(DEV), bk.to(DEV), stratified=False, **H.RENDER_KW)
+        res[mode] = (out["n_rendering_samples"], float(out["loss"]), [p.grad.clone() for p in (hip.mlp_base.params, hip.mlp_head.params, hip.mlp_sem.params)])
+    assert res[1][0] == res[2][0] and res[1][0] > 2000
+    assert abs(res[1][1] - res[2][1]) <= 1e-6 * abs(res[1][1])
+    for a, b in zip(res[2][2], res[1][2]):
+        assert _rel(a, b) < 1e-5
+    # oracle autograd on the same batch
+    import torch.nn.functional as F
+    orc = H.oracle_field(sc, "f16", requires_grad=True)
+    est = H.hip_estimator(sc)
+    ref = R.render_train(orc, sc["occ"], sc["aabb"][None], float(est.occs.mean().item()), o, d, torch.full((n,), 0.1), render_bkgd=bk,
+                         render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01)
+    loss = F.smooth_l1_loss(ref[0], pix) * 10 + F.smooth_l1_loss(ref[2], dep.unsqueeze(1)) / 5 + F.cross_entropy(ref[3], lab) / 2
+    loss.backward()
+    assert ref[4] == res[2][0]
+    assert abs(float(loss) - res[2][1]) < 5e-4 * max(1.0, abs(float(loss)))
+    for got, want in zip(res[2][2], (orc.p_base.grad, orc.p_head.grad, orc.p_sem.grad)):
+        w = want.to(DEV)
+        assert _rel(got, w) < 5e-2 and torch.nn.functional.cosine_similarity(got, w, dim=0) > 0.998, (_rel(got, w),)
+
+
+def test_dynamic_ray_count_schedule_async_matches_sync():
+    """scripts/pipeline.py:494-504: `num_rays` is recomputed after EVERY iteration (capped at 2000) to hold the sample count near the target.
+    The asynchronous train step keeps ONE state per field whatever the ray count: replaying the synchronous run's ray
+    counts without any host round trip gives the same trajectory (float-atomics noise), one train state, a bounded pool of pinned buffers,
+    and a flagged step (bad class id) still surfaces although every step has a different ray count."""
+    from apnrf_amd import _lib as L
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene(log2_hashmap_size=15)
+    o_all, d_all = H.view_rays(sc, 1, h=64, w=64)
+    rng = np.random.default_rng(11)
+    pix_all = torch.from_numpy(rng.random((4096, 3)).astype(np.float32)); dep_all = torch.from_numpy(rng.uniform(0.5, 4.0, 4096).astype(np.float32))
+    lab_all = torch.from_numpy(rng.integers(0, sc["C"], 4096))
+    perms = [torch.from_numpy(np.random.default_rng(100 + k).permutation(4096)) for k in range(40)]
+    target, bk = 1 << 15, torch.tensor([0.2, 0.2, 0.2], device=DEV)
+
+    def run(sync, schedule=None):
+        torch.manual_seed(77)                                          # the occupancy refresh draws its device seeds from torch's generator
+        hip, est = H.hip_field(sc).train(), H.hip_estimator(sc)
+        opt = FusedAdam(hip.parameters(), lr=1e-3, eps=1e-15).bind_field(hip)
+        R_, rs, losses, skipped = 1024, [], [], 0
+        for k in range(40):
+            R_ = schedule[k] if schedule is not None else R_
+            sel = perms[k][:R_]
+            out = RD.train_step(hip, est, opt, RD.Rays(o_all[sel].to(DEV), d_all[sel].to(DEV)), pix_all[sel].to(DEV), dep_all[sel].to(DEV),
+                                lab_all[sel].to(DEV), bk, step=k + 1, sync=sync, stratified=False, **H.RENDER_KW)
+            rs.append(R_); losses.append(out["loss"]); skipped += int(out["skipped"]) if sync else 0
+            if schedule is None:
+                n = out["n_rendering_samples"]
+                R_ = min(2000, max(16, int(R_ * target / n)))           # pipeline.py:494-504 (update_num_rays(min(2000, num_rays)))
+        return hip, rs, [float(x) for x in losses], skipped
+    _, rs, loss_sync, skipped = run(True)
+    assert skipped == 0 and len(set(rs)) > 10, rs                       # the ray count really changes from step to step
+    n_states = len(RD._TRAIN_STATE)
+    hip, rs2, loss_async, _ = run(False, rs)
+    assert len(RD._TRAIN_STATE) <= n_states + 1                          # one more field, ONE state for its 40 different ray counts
+    st = RD._TRAIN_STATE[id(hip)]
+    assert len(st["pending"]) + len(st.get("pinned", [])) <= 4 and st.get("overflowed_steps", 0) == 0
+    assert RD.latest_step_counts(hip) is not None and RD.latest_step_counts(hip)[0] in rs
+    np.testing.assert_allclose(loss_async, loss_sync, rtol=5e-3)
+    # a flagged step among changing ray counts is not lost: the error surfaces within the next two calls
+    bad = lab_all.clone(); bad[:] = sc["C"] + 3
+    opt = FusedAdam(hip.parameters(), lr=1e-3, eps=1e-15).bind_field(hip)
+    with pytest.raises(L.MnfError, match="class id"):
+        for k, R_ in enumerate((300, 411, 522, 633)):
+            sel = perms[k][:R_]
+            RD.train_step(hip, H.hip_estimator(sc), opt, RD.Rays(o_all[sel].to(DEV), d_all[sel].to(DEV)), pix_all[sel].to(DEV), dep_all[sel].to(DEV),
+                          (bad if k == 0 else lab_all)[sel].to(DEV), bk, step=100 + k, sync=False, stratified=False, **H.RENDER_KW)
+        torch.cuda.synchronize()
+        RD.train_step(hip, H.hip_estimator(sc), opt, RD.Rays(o_all[:64].to(DEV), d_all[:64].to(DEV)), pix_all[:64].to(DEV), dep_all[:64].to(DEV), lab_all[:64].to(DEV), bk,
+                      step=200, sync=False, stratified=False, **H.RENDER_KW)

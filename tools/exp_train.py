@@ -21,14 +21,18 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 lr = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0          # 0: the parameters (hence the sample counts) stay put across the timed steps
 shapes = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [8192, 2000]
 modes = [bool(int(x)) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [True, False]
+bwd_mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0        # mnf_field_set_backward_mode: 0 auto (fused where supported), 1 split kernels, 2 fused
 dev = "cuda:0"
 scene = SC.make_scene("102344280", n_poses=40)
 field, est, info = SI.train_standin(scene, dev, seed=11)
+print("[exp_train] stand-in:", {k: v for k, v in info.items() if k != "optimizer_state"}, flush=True)
 if dtype == "bf16":
     f2 = SC.hip_field(scene, dev, mfma_bf16=True)
     f2.load_state_dict(field.state_dict())
     field = f2
 field.train(); est.train()
+from apnrf_amd import _lib as L
+L.check(L.load_library().mnf_field_set_backward_mode(field._ensure_handle(), bwd_mode))
 proc = SI._procedural_estimator(scene, dev)
 c2w = np.stack([RD.pose_to_c2w(p) for p in scene["poses"][:8]]).astype(np.float32)
 K6 = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
@@ -64,4 +68,4 @@ for R in shapes:
         dt = (time.perf_counter() - t0) / steps
         kept = np.mean([int(o["n_rendering_samples"]) for o in outs])
         skipped = sum(int(o["skipped"]) for o in outs)
-        print(f"[exp_train] {dtype} rays {R} sync={sync}: {1e3 * dt:.3f} ms/step, kept {kept:.0f}, skipped {skipped}", flush=True)
+        print(f"[exp_train] {dtype} rays {R} sync={sync} bwd_mode={bwd_mode}: {1e3 * dt:.3f} ms/step, kept {kept:.0f}, skipped {skipped}", flush=True)
