@@ -116,26 +116,43 @@ __global__ void __launch_bounds__(256) traverse_kernel(int32_t n_rays, const flo
 // workgroup (a dependent global load per visited cell otherwise).  Same t values as traverse_kernel, bit for bit.
 constexpr int kSamplerGridWords = 16384;   // 64 KB of LDS = 524 288 cells
 
+#ifndef MNF_SAMPLER_THREADS
+#define MNF_SAMPLER_THREADS 64       /* threads per workgroup of sample_rays_kernel.  The kernel is one dependent chain per ray (its time does not depend on the ray
+                                        count: 197 us for 8192 and for 2000 rays with 256 threads, 184 / 187 us with 64, tools/exp_sampler.py, profiles/r04_exp_sampler.txt):
+                                        one wave per workgroup spreads the waves over 4x more compute units */
+#endif
+#ifndef MNF_SAMPLER_EXP
+#define MNF_SAMPLER_EXP 0            /* timing experiments only: 1 = no sample stores (results invalid) */
+#endif
 struct ScratchSink {
     float *ts, *te;
     int32_t cap;
     __device__ __forceinline__ void sample(float t_last, float t_next, bool, int32_t k) {
+#if MNF_SAMPLER_EXP == 1
+        if (k == 0x7fffffff) { ts[0] = t_last; te[0] = t_next; }
+#else
         if (k < cap) { ts[k] = t_last; te[k] = t_next; }
+#endif
     }
 };
 
 template <bool LDS_GRID, bool MULTI>
-__global__ void __launch_bounds__(256) sample_rays_kernel(int32_t n_rays, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+__global__ void __launch_bounds__(MNF_SAMPLER_THREADS) sample_rays_kernel(int32_t n_rays, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                           I3 res, const uint8_t *__restrict__ binaries, const LevelBoxes boxes, const float *__restrict__ near_planes,
                                                           const float *__restrict__ far_planes, float step_size, float cone_angle,
                                                           int32_t cap, float *__restrict__ scratch_ts, float *__restrict__ scratch_te,
                                                           int64_t *__restrict__ counts, const uint32_t *__restrict__ bitgrid) {
-    __shared__ uint32_t s_bits[LDS_GRID ? kSamplerGridWords : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[LDS_GRID ? kSamplerGridWords : 1];
     const int64_t cells = (int64_t)res.x * res.y * res.z;
     if (LDS_GRID) {   // every level's bits: level l at word l * words_per_level (the layout of mnf_pack_bitgrid)
         const int wpl = boxes.words_per_level, n_words = wpl * boxes.n;
         if (bitgrid) {   // the estimator's bit-packed grid (kept current by mnf_occ_binarize): 1/8 of the bytes, no packing here
-            for (int w = threadIdx.x; w < n_words; w += blockDim.x) s_bits[w] = bitgrid[w];
+            // 16-byte loads, all of a thread's requests in flight before its first LDS write (the tail by single words)
+            const int n4 = (reinterpret_cast<uintptr_t>(bitgrid) & 15) == 0 ? n_words >> 2 : 0;
+            const uint4 *src4 = reinterpret_cast<const uint4 *>(bitgrid);
+            uint4 *dst4 = reinterpret_cast<uint4 *>(s_bits);
+            for (int w = threadIdx.x; w < n4; w += blockDim.x) dst4[w] = src4[w];
+            for (int w = 4 * n4 + threadIdx.x; w < n_words; w += blockDim.x) s_bits[w] = bitgrid[w];
         } else {
             for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
                 const int lvl = w / wpl, wl = w - lvl * wpl;
@@ -478,8 +495,8 @@ extern "C" int mnf_sample_rays_levels(const float *rays_o, const float *rays_d, 
         for (int k = 0; k < 6; ++k) boxes.ab[l][k] = aabb_host[6 * l + k];
     ProfScope ps("sample_rays", as_stream(stream));
     const bool lds = (int64_t)boxes.words_per_level * n_levels <= (int64_t)kSamplerGridWords;
-    const int grid = grid_for(n_rays, 256);
-#define MNF_SAMPLE(LDS, ML) hipLaunchKernelGGL((sample_rays_kernel<LDS, ML>), dim3(grid), dim3(256), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, boxes, \
+    const int grid = grid_for(n_rays, MNF_SAMPLER_THREADS);
+#define MNF_SAMPLE(LDS, ML) hipLaunchKernelGGL((sample_rays_kernel<LDS, ML>), dim3(grid), dim3(MNF_SAMPLER_THREADS), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, boxes, \
                                                near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts, bitgrid)
     if (n_levels > 1) { if (lds) MNF_SAMPLE(true, true); else MNF_SAMPLE(false, true); }
     else { if (lds) MNF_SAMPLE(true, false); else MNF_SAMPLE(false, false); }

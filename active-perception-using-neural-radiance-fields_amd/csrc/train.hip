@@ -46,6 +46,15 @@ __device__ __forceinline__ int64_t count_here(int64_t n_cap, const int64_t *n_de
     return nd < n_cap ? nd : n_cap;
 }
 
+// The backward's kernels can be issued for one of `n_chunks` contiguous ranges of 64-sample tiles (whole tiles: dgrad's unit), so that the
+// hash-table scatter of a range starts behind the backward-data launch of THAT range while the next range is still in dgrad.  The ranges are
+// fractions of the actual (device-side) count.
+__device__ __forceinline__ void chunk_tiles(int64_t n, int chunk, int n_chunks, int64_t &t0, int64_t &t1) {
+    const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
+    t0 = n_chunks > 1 ? n_tiles * chunk / n_chunks : 0;
+    t1 = n_chunks > 1 ? n_tiles * (chunk + 1) / n_chunks : n_tiles;
+}
+
 struct BwdArgs {
     const half8 *fragsT;
     const float *d_rgb, *d_sigma, *d_sem;   // [N,3], [N], [N,C]
@@ -55,6 +64,7 @@ struct BwdArgs {
     const int64_t *n_dev;
     int C;
     float loss_scale;
+    int chunk, n_chunks;
     TrainBuf train;
 };
 
@@ -123,13 +133,14 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
     half_t *stage = s_stage + wave * kStageHalves;
     const int64_t n = count_here(args.n, args.n_dev);
-    const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
-    if ((int64_t)blockIdx.x * kWavesPerBlock >= n_tiles) return;
+    int64_t tile0, n_tiles;
+    chunk_tiles(n, args.chunk, args.n_chunks, tile0, n_tiles);
+    if (tile0 + (int64_t)blockIdx.x * kWavesPerBlock >= n_tiles) return;
     for (int i = threadIdx.x; i < L::blocks * 64; i += kThreads) s_w[i] = args.fragsT[i];
     __syncthreads();
     const float ls = args.loss_scale;
 
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWavesPerBlock) {
+    for (int64_t tile = tile0 + (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWavesPerBlock) {
         const int64_t fcol0 = tile * kWaveSamples + c;
         const uint8_t *mdump = args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane;
         // ---- output-layer gradients, built directly as natural-order B fragments ----
@@ -348,6 +359,7 @@ struct HashBwdArgs {
                               // three divisions are done once per sample, not once per sample, level and lane
     const float *dX;      // [16][Np][4]
     int64_t Np;
+    int chunk, n_chunks;  // this launch covers tile range `chunk` of `n_chunks` (chunk_tiles)
     int level0;           // first level of this launch (experiments; 0 in production)
     int n_walk_levels;    // levels level0 .. level0 + n_walk_levels - 1
     float *repl;          // [kReplicas][repl_floats]: private copies of the coarsest levels' gradient (see below)
@@ -431,16 +443,19 @@ __global__ void __launch_bounds__(256) hash_bwd_walk_kernel(const HashBwdArgs ar
     const int sub = threadIdx.x & 31;                 // lane inside the half-wave
     const int corner = sub >> 2, feat = sub & 3;
     const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
-    const int64_t n_all = count_here(args.n, args.n_dev);
+    const int64_t n_cnt = count_here(args.n, args.n_dev);
+    int64_t rt0, rt1;
+    chunk_tiles(n_cnt, args.chunk, args.n_chunks, rt0, rt1);
+    const int64_t s_lo = rt0 * kWaveSamples, n_all = rt1 * kWaveSamples < n_cnt ? rt1 * kWaveSamples : n_cnt;       // samples [s_lo, n_all) of this launch
     // A bounded number of workgroups walks all (level, chunk) pairs (level by level, so that the workgroups of the moment add into the same few
     // megabytes): the kernel is bound by the atomic unit, not by waves in flight, and the wave slots it leaves are what lets the binned passes
     // and the weight gradients run beside it instead of behind it.
-    const int64_t chunks = (n_all + kWalkChunk - 1) / kWalkChunk;
+    const int64_t chunks = n_all > s_lo ? (n_all - s_lo + kWalkChunk - 1) / kWalkChunk : 0;
     const int64_t items = chunks * args.n_walk_levels;
     for (int64_t item = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5; item < items; item += ((int64_t)gridDim.x * blockDim.x) >> 5) {
     const int64_t chunk = item % chunks;
     const int l = (int)(item / chunks) + args.level0;
-    const int64_t i0 = chunk * kWalkChunk;
+    const int64_t i0 = s_lo + chunk * kWalkChunk;
     const int64_t i1 = i0 + kWalkChunk < n_all ? i0 + kWalkChunk : n_all;
     const LevelMeta m = args.levels[l];
     const uint32_t replica = (uint32_t)((chunk >> 3) % kReplicas);
@@ -554,6 +569,7 @@ struct BinArgs {
     const float *dX;          // [16][Np][4]
     int64_t Np, n;
     const int64_t *n_dev;
+    int chunk, n_chunks;      // pass A of this launch covers tile range `chunk` of `n_chunks` (chunk_tiles); pass B runs once, behind the last pass A
     int level0, n_levels;     // levels level0 .. level0 + n_levels - 1, all hashed with size a multiple of kBinEntries
     float4 *items;            // [n_levels][bins of that level][cap]: level k's lists start at item_base[k]
     uint32_t *cursors;        // [n_levels][kMaxBins] items handed out per list (may exceed cap: the excess went to the atomics)
@@ -592,8 +608,11 @@ __global__ void __launch_bounds__(256) bin_items_kernel(const BinArgs args) {
     const int64_t chunk = blockIdx.x / (unsigned)args.n_levels;
     const LevelMeta m = args.levels[l];
     const uint32_t nb = m.size >> kBinEntriesLog2;
-    const int64_t n_all = count_here(args.n, args.n_dev);
-    const int64_t first = chunk * (kBinChunk * 256);
+    const int64_t n_cnt = count_here(args.n, args.n_dev);
+    int64_t rt0, rt1;
+    chunk_tiles(n_cnt, args.chunk, args.n_chunks, rt0, rt1);
+    const int64_t n_all = rt1 * kWaveSamples < n_cnt ? rt1 * kWaveSamples : n_cnt;
+    const int64_t first = rt0 * kWaveSamples + chunk * (kBinChunk * 256);
     if (first >= n_all) return;
     for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
     __syncthreads();
@@ -896,6 +915,7 @@ struct TrainState {
     // on a second stream of the handle: both only depend on the backward-data kernel
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_entry = nullptr;
+    hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr};      // behind each backward-data launch of the chunked pipeline
     // ... and the binned part of the scatter (streams through HBM and LDS) beside the walk (memory-side atomics) on a third
     hipStream_t side2 = nullptr;
     hipEvent_t ev_join2 = nullptr;
@@ -941,6 +961,7 @@ static int ensure_train_state(mnf_field_t f) {
     if (!ts->side || !ts->side2) { delete ts; return MNF_ERR_HIP; }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming);
+    for (int c = 0; c < 4 && e == hipSuccess; ++c) e = hipEventCreateWithFlags(&ts->ev_chunk[c], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_entry, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ts->ev_join2, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -965,6 +986,7 @@ void free_train_state_impl(mnf_field_t f) {
     if (ts->d_bin_cursors) (void)hipFree(ts->d_bin_cursors);
     if (ts->ev_fork) (void)hipEventDestroy(ts->ev_fork);
     if (ts->ev_join) (void)hipEventDestroy(ts->ev_join);
+    for (int c = 0; c < 4; ++c) if (ts->ev_chunk[c]) (void)hipEventDestroy(ts->ev_chunk[c]);
     if (ts->ev_entry) (void)hipEventDestroy(ts->ev_entry);
     if (ts->ev_join2) (void)hipEventDestroy(ts->ev_join2);
     delete ts;
@@ -1073,8 +1095,24 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     a.d_rgb = d_rgb; a.d_sigma = d_density; a.d_sem = d_sem; a.rgb = rgb; a.sigma = density;
     a.dX = v.dX; a.n = n; a.n_dev = n_dev; a.C = f->cfg.num_semantic_classes; a.loss_scale = loss_scale;
     a.train = {v.act, v.masks, v.Np, ts->tt.rows};
+    // Chunked pipeline (float-atomic mode, large batches): the backward-data kernel is launched for four contiguous ranges of tiles and the scatter of a
+    // range (walk on the side stream, pass A of the bins on the third) starts behind ITS launch, beside the next range's dgrad: dgrad writes activations
+    // through the matrix cores and HBM stores, the scatter is bound by the memory-side atomic unit — the two overlap, and only the last range's scatter
+    // (and the weight gradients, which read every range) is left behind the last dgrad.  One range = the old schedule (deterministic mode: its grouping
+    // of partial sums must not change).
+    static const int chunks_env = diag_env("MNF_BWD_CHUNKS") ? atoi(diag_env("MNF_BWD_CHUNKS")) : 0;
+    const bool fused_ = use_fused_backward(f, deterministic);
+    int n_chunks = (!deterministic && !fused_ && n >= ((int64_t)1 << 18)) ? 2 : 1;      // measured (profiles/r04_bwd_chunks.txt): 5.77 / 5.52 / 5.60 ms per step with 1 / 2 / 4 ranges
+    if (chunks_env >= 1 && chunks_env <= 4 && !deterministic && !fused_) n_chunks = chunks_env;
+    if (!positions_normalized) {   // (the train step's forward hands over normalised positions already: FieldIO::xn_out)
+        const float *ab = f->cfg.aabb;
+        const int64_t blocks = ceil_div(3 * n, 256);
+        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, positions, n, n_dev, ab[0], ab[1], ab[2],
+                           ab[3], ab[4], ab[5], v.xn);
+    }
     int grid = 256;
-    const int64_t wgs = ceil_div(ceil_div(n, kWaveSamples), kWavesPerBlock);
+    const int64_t chunk_tiles_max = ceil_div(ceil_div(n, kWaveSamples), n_chunks) + 1;      // tiles of one range, at most
+    const int64_t wgs = ceil_div(chunk_tiles_max, kWavesPerBlock);
     if (wgs < grid) grid = (int)wgs;
     const int W = f->cfg.neurons, NH = f->cfg.layers;
     bool ok = false;
@@ -1092,28 +1130,23 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         ok = true;
     }
     const int prof_dgrad = fused ? -1 : prof_start("dgrad", s);
+    for (int c = 0; c < n_chunks; ++c) {
+        a.chunk = c; a.n_chunks = n_chunks;
 #define MNF_CASE(w, nh) if (!fused && W == w && NH == nh) { launch_dgrad<w, nh>(a, grid, s); ok = true; }
 #ifdef MNF_DEV_ONLY_128x2
-    MNF_CASE(128, 2)
+        MNF_CASE(128, 2)
 #else
-    MNF_CASE(128, 1) MNF_CASE(128, 2) MNF_CASE(128, 3) MNF_CASE(128, 4)
-    MNF_CASE(64, 1) MNF_CASE(64, 2) MNF_CASE(64, 3) MNF_CASE(64, 4)
+        MNF_CASE(128, 1) MNF_CASE(128, 2) MNF_CASE(128, 3) MNF_CASE(128, 4)
+        MNF_CASE(64, 1) MNF_CASE(64, 2) MNF_CASE(64, 3) MNF_CASE(64, 4)
 #endif
 #undef MNF_CASE
+        MNF_HIP(hipEventRecord(ts->ev_chunk[c], s));      // ---- fork point of range c: its scatter may start (the weight gradients stay on the caller's stream)
+    }
     prof_stop(prof_dgrad, s);
     MNF_REQUIRE(ok, "field_backward: unsupported shape");
     rc = launch_status("dgrad_kernel");
     if (rc) return rc;
-    if (!positions_normalized) {   // (the train step's forward hands over normalised positions already: FieldIO::xn_out)
-        const float *ab = f->cfg.aabb;
-        const int64_t blocks = ceil_div(3 * n, 256);
-        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, positions, n, n_dev, ab[0], ab[1], ab[2],
-                           ab[3], ab[4], ab[5], v.xn);
-    }
-    // ---- fork: the hash-table scatter goes to the handle's side stream, the weight gradients stay on the caller's
     hipStream_t ss = ts->side;
-    MNF_HIP(hipEventRecord(ts->ev_fork, s));
-    MNF_HIP(hipStreamWaitEvent(ss, ts->ev_fork, 0));
     // weight gradients
     const int n_groups = (int)ts->tt.groups.size();
     // enough sample chunks to fill the chip with waves (the loop is load-latency bound; 2 x 2 blocking leaves room for
@@ -1150,7 +1183,7 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     std::memcpy(hb.aabb, f->cfg.aabb, sizeof(hb.aabb));
     std::memcpy(hb.levels, f->levels, sizeof(hb.levels));
     int n_levels = 16;
-    hb.level0 = 0;
+    hb.level0 = 0; hb.chunk = 0; hb.n_chunks = 1;
     if (const char *e = diag_env("MNF_HASH_BWD_LEVELS")) { int lo = 0, hi = 16; if (sscanf(e, "%d,%d", &lo, &hi) == 2) { hb.level0 = lo; n_levels = hi - lo; } }
     // replicated coarse levels (their own region of the workspace, zeroed above)
     hb.repl_levels = repl_levels;
@@ -1200,18 +1233,22 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
             MNF_HIP(hipMalloc((void **)&ts->d_bin_items, need * sizeof(float4)));
             ts->bin_items = need;
         }
+        ba.chunk = 0; ba.n_chunks = 1;
         ba.positions = hb.positions; ba.dX = hb.dX; ba.Np = hb.Np; ba.n = n; ba.n_dev = n_dev; ba.level0 = first_binned; ba.n_levels = n_binned;
         ba.items = ts->d_bin_items; ba.cursors = ts->d_bin_cursors; ba.cap = cap; ba.g_table = hb.g_table;
         std::memcpy(ba.levels, f->levels, sizeof(ba.levels));
         n_levels = first_binned;
     }
+    MNF_HIP(hipStreamWaitEvent(ss, ts->ev_chunk[0], 0));
     const int prof_scatter = prof_start("hash_scatter", ss);
     hb.n_walk_levels = n_levels;
     int walk_wgs = 8;                                                                   // workgroups per CU of the 256 (gfx950 only: as the field kernel)
     if (const char *e = diag_env("MNF_WALK_WGS")) walk_wgs = atoi(e);
-    const int64_t walk_full = ceil_div(ceil_div(n, kWalkChunk) * 32, 256) * (n_levels > 0 ? n_levels : 1);
+    const int64_t range_samples = chunk_tiles_max * kWaveSamples;                        // samples of one range, at most
+    const int64_t walk_full = ceil_div(ceil_div(range_samples, kWalkChunk) * 32, 256) * (n_levels > 0 ? n_levels : 1);
     const dim3 walk_grid((unsigned)(walk_wgs > 0 && walk_full > (int64_t)256 * walk_wgs ? (int64_t)256 * walk_wgs : (walk_full > 0 ? walk_full : 1)));
     if (deterministic) {
+        MNF_HIP(hipStreamWaitEvent(ss, ts->ev_chunk[0], 0));
         MNF_HIP(hipMemsetAsync(hb.q_table, 0, q_table_words * sizeof(unsigned long long), ss));
         if (hb.repl_levels) MNF_HIP(hipMemsetAsync(hb.q_repl, 0, (size_t)kReplicas * hb.repl_floats * sizeof(unsigned long long), ss));
         MNF_HIP(hipMemsetAsync(hb.q_bad, 0, sizeof(unsigned long long), ss));
@@ -1226,19 +1263,31 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
             const uint32_t nb = f->levels[15].size >> kBinEntriesLog2;
             static const bool same_stream = diag_env("MNF_BIN_SAME_STREAM") != nullptr;     // timing experiments: bins in front of the walk on one stream
             hipStream_t s2 = same_stream ? ss : ts->side2;
-            MNF_HIP(hipStreamWaitEvent(s2, ts->ev_fork, 0));
+            MNF_HIP(hipStreamWaitEvent(s2, ts->ev_chunk[0], 0));
             const int prof_bins = prof_start("hash_scatter_bins", s2);
             // (list cursors: cleared by gather_fragsT_kernel, in front of the fork)
             // (Measured and dropped, tools/r03_walk_wgs.sh: pass B level by level or half by half on a fourth stream under the next pass A — 5.8 and 5.6 ms
             // per step against 5.55-5.6 for one launch each: walk, bins and wgrad together are bound by HBM, the order inside does not matter.)
-            hipLaunchKernelGGL(bin_items_kernel, dim3((unsigned)(ceil_div(n, kBinChunk * 256) * n_binned)), dim3(256), 0, s2, ba);
+            for (int c = 0; c < n_chunks; ++c) {          // pass A range by range, each behind its dgrad; pass B once, behind the last
+                if (c) MNF_HIP(hipStreamWaitEvent(s2, ts->ev_chunk[c], 0));
+                ba.chunk = c; ba.n_chunks = n_chunks;
+                hipLaunchKernelGGL(bin_items_kernel, dim3((unsigned)(ceil_div(range_samples, kBinChunk * 256) * n_binned)), dim3(256), 0, s2, ba);
+            }
             hipLaunchKernelGGL(bin_accumulate_kernel, dim3(nb, n_binned), dim3(kBinThreadsB), 0, s2, ba);
             prof_stop(prof_bins, s2);
             MNF_HIP(hipEventRecord(ts->ev_join2, s2));
             MNF_HIP(hipStreamWaitEvent(s, ts->ev_join2, 0));
         }
-        if (simple) hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, ss, hb);
-        else if (n_levels > 0) hipLaunchKernelGGL(hash_bwd_walk_kernel<false>, walk_grid, dim3(256), 0, ss, hb);
+        if (simple) {
+            MNF_HIP(hipStreamWaitEvent(ss, ts->ev_chunk[n_chunks - 1], 0));
+            hipLaunchKernelGGL(hash_bwd_simple_kernel, dim3((unsigned)ceil_div(n, 256), n_levels), dim3(256), 0, ss, hb);
+        } else {
+            for (int c = 0; c < n_chunks; ++c) {
+                MNF_HIP(hipStreamWaitEvent(ss, ts->ev_chunk[c], 0));
+                hb.chunk = c; hb.n_chunks = n_chunks;
+                if (n_levels > 0) hipLaunchKernelGGL(hash_bwd_walk_kernel<false>, walk_grid, dim3(256), 0, ss, hb);
+            }
+        }
         if (hb.repl_levels)
             hipLaunchKernelGGL(fold_replicas_kernel, dim3((hb.repl_floats + 255) / 256), dim3(256), 0, ss, hb.repl, hb.repl_floats, hb.g_table);
     }

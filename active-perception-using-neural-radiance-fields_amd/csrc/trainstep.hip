@@ -312,7 +312,15 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
                        (int64_t)cap, eff, counts_dev, skip_dev);
     rc = mnf_compact_samples(w.scratch_ts, w.scratch_te, cap, w.starts, w.counts, n_rays, w.ts, w.te, w.ray, stream);
     if (rc) return rc;
-    rc = mnf_field_density_rays(f, rays_o, rays_d, w.ray, w.ts, w.te, w.starts, w.counts, n_rays, max_marched, opts->early_stop_eps, w.sigma, stream);
+    static const bool prepass_flat = diag_env("MNF_PREPASS_FLAT") != nullptr;    // experiment: every marched sample, full lanes, no early termination
+    if (prepass_flat) {
+        FieldIO io = {};
+        io.mode = 1; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = w.ray; io.t_starts = w.ts; io.t_ends = w.te;
+        io.n = max_marched; io.n_dev64 = eff; io.density = w.sigma;
+        rc = launch_field(f, io, true, s);
+    } else {
+        rc = mnf_field_density_rays(f, rays_o, rays_d, w.ray, w.ts, w.te, w.starts, w.counts, n_rays, max_marched, opts->early_stop_eps, w.sigma, stream);
+    }
     if (rc) return rc;
     const int vgrid = n_rays < 65535 ? n_rays : 65535;
     hipLaunchKernelGGL(visibility_kernel<false>, dim3(vgrid), dim3(64), 0, s, n_rays, w.starts, w.counts, w.ts, w.te, w.sigma, opts->early_stop_eps,
