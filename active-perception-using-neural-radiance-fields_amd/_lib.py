@@ -19,7 +19,7 @@ class FieldConfig(ctypes.Structure):
     _fields_ = [("aabb", c_float * 6), ("neurons", c_int32), ("layers", c_int32),
                 ("num_semantic_classes", c_int32), ("n_levels", c_int32), ("n_features", c_int32),
                 ("log2_hashmap_size", c_int32), ("base_resolution", c_int32), ("max_resolution", c_int32),
-                ("output_fp16", c_int32), ("mfma_bf16", c_int32)]
+                ("output_fp16", c_int32), ("mfma_bf16", c_int32), ("blend_fp16", c_int32)]
 
 
 class TrainOpts(ctypes.Structure):

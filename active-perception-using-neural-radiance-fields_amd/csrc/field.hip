@@ -27,37 +27,7 @@
 #include <cmath>
 #include <cstring>
 
-#ifndef MNF_EXP
-#define MNF_EXP 2           /* wave priority: 0 while a tile's hash gathers are issued and awaited, 1 through its MLP + compositing
-                               (the two waves of a SIMD then finish their matrix phases sooner and go back to issuing loads):
-                               -4.6 % field-kernel time; 0 = uniform priority, 1 = the opposite assignment (-2.4 %), 3 = static
-                               priority for waves 4-7, 4 = start-up stagger (both 0 %), 5 = finest levels first (+4.7 %) */
-#endif
-#ifndef MNF_EXP_LOCK
-#define MNF_EXP_LOCK 0      /* experiment: a per-SIMD lock around the matrix phase (anti-phase schedule of the two waves of a SIMD) */
-#endif
-#ifndef MNF_COL_AHEAD
-#define MNF_COL_AHEAD 0    /* 1: request the next tile's columns before the compositing of the current one (measured: +1.5 % time, 6 spilled registers) */
-#endif
-#ifndef MNF_KNOCK
-#define MNF_KNOCK 0
-#endif
-#ifndef MNF_SKIP_HEADS
-#define MNF_SKIP_HEADS 0    /* experiment (measured: no gain, 0.570 -> 0.569): skip the head networks of renderer tiles in which no sample
-                               passes the alpha threshold */
-#endif
-#ifndef MNF_NT_FROM
-#define MNF_NT_FROM 99      /* experiment: hash levels >= this are fetched with non-temporal loads */
-#endif
 
-#if (MNF_PK == 4 || MNF_PK == 5) && !defined(MNF_BF16)
-#include "field_dev.h"
-extern "C" int mnf_debug_pk_read(unsigned int *host, int clear) {      // root-cause builds only (tools/debug_pk.py)
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(mnf::f16::g_pk_dbg), sizeof(unsigned int) * (8 * 512 + 8)) != hipSuccess) return -1;
-    if (clear) { static unsigned int zero[8 * 512 + 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(mnf::f16::g_pk_dbg), zero, sizeof(zero)); }
-    return 0;
-}
-#endif
 
 MNF_DT_BEGIN
 
@@ -65,8 +35,7 @@ MNF_DT_BEGIN
 // Position / direction of column `col`: mode 0 explicit arrays, mode 1 packed samples with int64 ray ids, mode 2 renderer
 // columns.  xn = position normalised to the aabb (ngp.py:177-178), selector = inside the open unit box (ngp.py:179).
 // Renderer columns of one tile (mode 2).  The tile header (budget | view << 8, written by the marcher of the same round) is
-// wave-uniform and read with a scalar load.  MNF_COL_AHEAD: the columns of the wave's NEXT tile are requested before the
-// compositing epilogue of the current one, so that a tile does not start with a memory round trip and nothing else in flight.
+// wave-uniform and read with a scalar load.
 struct ColData {
     int ray, stride, view;
     float ts, te;
@@ -257,10 +226,6 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
     __shared__ half8 s_w[kBlocks * 64];
     __shared__ half_t s_stage[SAVE ? kWavesPerBlock * kStageHalves : 1];   // training: per-wave transpose tile of the activation dump
-#if MNF_EXP_LOCK
-    __shared__ int s_lock[4];          // experiment: at most one of the two waves of a SIMD (waves w, w + 4) inside the matrix phase
-    if (threadIdx.x < 4) s_lock[threadIdx.x] = 0;
-#endif
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -301,11 +266,6 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     }
     __syncthreads();
     if (wave >= wpb) return;
-#if MNF_EXP == 3
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // static priority for the second-dispatched half (MI355X guide, two waves per SIMD, item 4)
-#elif MNF_EXP == 4
-    if (wave >= 4) __builtin_amdgcn_s_sleep(64);    // stagger the two waves of a SIMD
-#endif
 
     typedef const KernelArgs __attribute__((address_space(4))) KArgs;
     KArgs *const kp = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -342,12 +302,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         // ---- this lane's sample ----
         ColData cd = {-1, 64, 0, 0.f, 0.f};
         if (MODE == 2) {
-#if MNF_COL_AHEAD
-            if (!DENSITY_ONLY && !SAVE && !ENC) { if (grp == g_first) cd_next = load_cols(args, tile, lane); cd = cd_next; }
-            else cd = load_cols(args, tile, lane);
-#else
             cd = load_cols(args, tile, lane);
-#endif
         }
         float xn[3], dir[3];
         TileSample tsm;
@@ -367,36 +322,15 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) bfeat[ct][ks] = src[(ks * 2 + ct) * 64];
         }
-#if MNF_KNOCK & 4
-        else {   // diagnostic build: no hash gather, features made up from the position
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bfeat[ct][ks][j] = (half_t)(xn[j % 3] * 0.01f * (float)(j + ks + ct));
-        }
-#else
         else {
             // double-buffered: the loads of batch kb+1 are issued before batch kb is blended
             LevelPrep prep[2][4];
             tab4 v[2][4][8];
-#if MNF_EXP == 1
-            __builtin_amdgcn_s_setprio(1);
-#elif MNF_EXP == 2 || MNF_EXP == 6 || MNF_EXP == 7
             __builtin_amdgcn_s_setprio(0);
-#elif MNF_EXP == 10
-            __builtin_amdgcn_s_setprio(2);
-#endif
-#if MNF_EXP == 5
-#define MNF_KB(i) (3 - (i))      /* finest levels first: their misses have the longest way to go */
-#else
-#define MNF_KB(i) (i)
-#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                hash_prep(level_meta(lv, 4 * MNF_KB(0) + q), xn, prep[0][q], in_box);
-                hash_load(la.table, prep[0][q], v[0][q], 4 * MNF_KB(0) + q >= MNF_NT_FROM);
+                hash_prep(level_meta(lv, q), xn, prep[0][q], in_box);
+                hash_load(la.table, prep[0][q], v[0][q]);
             }
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
@@ -404,38 +338,41 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 if (kb < 3) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        hash_prep(level_meta(lv, 4 * MNF_KB(kb + 1) + q), xn, prep[nxt][q], in_box);
-                        hash_load(la.table, prep[nxt][q], v[nxt][q], 4 * MNF_KB(kb + 1) + q >= MNF_NT_FROM);
+                        hash_prep(level_meta(lv, 4 * (kb + 1) + q), xn, prep[nxt][q], in_box);
+                        hash_load(la.table, prep[nxt][q], v[nxt][q]);
                     }
                 }
-#if MNF_EXP == 10
-                __builtin_amdgcn_s_setprio(0);      // waiting for / blending the current batch: low; issuing the next one: high
-#endif
-                float f[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hash_blend(prep[cur][q], v[cur][q], f + 4 * q);
                 half8 lo, hi;
+                if (la.blend16) {       // (wave-uniform) tcnn's fp16 blend: the sums come out as the packed 16-bit features themselves
+                    u32x2 r[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
+                    for (int q = 0; q < 4; ++q) r[q] = hash_blend16(prep[cur][q], v[cur][q]);
+#ifdef MNF_BF16
+                    float f[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const h16x2 p0 = __builtin_bit_cast(h16x2, (uint32_t)r[q].x), p1 = __builtin_bit_cast(h16x2, (uint32_t)r[q].y);
+                        f[4 * q] = (float)p0.x; f[4 * q + 1] = (float)p0.y; f[4 * q + 2] = (float)p1.x; f[4 * q + 3] = (float)p1.y;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
+#else
+                    lo = __builtin_bit_cast(half8, u32x4{r[0].x, r[0].y, r[1].x, r[1].y});
+                    hi = __builtin_bit_cast(half8, u32x4{r[2].x, r[2].y, r[3].x, r[3].y});
+#endif
+                } else {
+                    float f[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hash_blend(prep[cur][q], v[cur][q], f + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
+                }
                 exchange_halves(lo, hi);
-                bfeat[0][MNF_KB(kb)] = lo; bfeat[1][MNF_KB(kb)] = hi;
+                bfeat[0][kb] = lo; bfeat[1][kb] = hi;
                 __builtin_amdgcn_sched_barrier(0);
-#if MNF_EXP == 10
-                if (kb < 2) __builtin_amdgcn_s_setprio(2);
-#endif
             }
-#undef MNF_KB
-#if MNF_EXP == 1
-            __builtin_amdgcn_s_setprio(0);
-#elif MNF_EXP == 2 || MNF_EXP == 10
             __builtin_amdgcn_s_setprio(1);
-#elif MNF_EXP == 6
-            __builtin_amdgcn_s_setprio(3);
-#elif MNF_EXP == 7
-            __builtin_amdgcn_s_setprio(2);
-#endif
         }
-#endif
 
         // the mask-dump base of this tile
         uint8_t *mdump = SAVE ? la.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
@@ -451,16 +388,6 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 for (int ct = 0; ct < CT; ++ct) xdump[(ks * 2 + ct) * 64] = bfeat[ct][ks];
         }
 
-#if MNF_EXP_LOCK
-        if (MODE == 2 && !SAVE && !DENSITY_ONLY) {
-            int got = 0;
-            do {
-                if (lane == 0) got = atomicCAS(&s_lock[wave & 3], 0, 1) == 0;
-                got = __builtin_amdgcn_readfirstlane(got);
-                if (!got) __builtin_amdgcn_s_sleep(4);
-            } while (!got);
-        }
-#endif
         // ---- base MLP ----
         half8 hb[CT][L::KSW];
         dense_relu<L::RT, 4>(s_w + L::o_b_in * 64, lane, bfeat, hb);
@@ -469,7 +396,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int k = 0; k < L::KSW; ++k) {
                 save_pair<true>(from_constant(&la.train), tile, T::rH0 + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) if (MNF_EXP_SAVE != 3) mdump[((T::mH0 + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
+                for (int ct = 0; ct < CT; ++ct) mdump[((T::mH0 + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
             }
         }
 #pragma unroll
@@ -485,7 +412,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 for (int k = 0; k < L::KSW; ++k) {
                     save_pair<true>(from_constant(&la.train), tile, T::rH0 + (l + 1) * W + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) if (MNF_EXP_SAVE != 3) mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
+                    for (int ct = 0; ct < CT; ++ct) mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
                 }
             }
         }
@@ -510,32 +437,6 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             continue;
         }
 
-#if MNF_KNOCK & 2
-        if (MODE == 2 && !SAVE) {   // diagnostic build: density only, no head networks, no compositing
-            if (sigma == 1.2345e30f) la.io.fr.acc[0] = sigma;
-            continue;
-        }
-#endif
-#if MNF_SKIP_HEADS
-        // Renderer tiles in which no sample passes the alpha threshold (utils.py:714-725 drops them after the query): their rgb
-        // and semantic outputs are multiplied by a zero weight in the compositing, so the two head networks are not evaluated.
-        // The density still goes through the compositing (transmittance, sample counters, ray retirement): results unchanged.
-        if (MODE == 2 && !SAVE) {
-            const float sdt0 = valid ? sigma * (tsm.te - tsm.ts) : 0.0f;
-            const float alpha0 = 1.0f - expf(-sdt0);
-            const bool keep0 = valid && !(la.io.fr.alpha_thre > 0.f && !(alpha0 >= la.io.fr.alpha_thre));
-            if (__ballot(keep0) == 0ull) {
-                const float zrgb[3] = {0.f, 0.f, 0.f};
-                f32x16 zsem[CT];
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) zsem[ct][i] = 0.0f;
-                fused_composite(fr_of_kernarg(), in_loop(la.C), in_loop_v(lane), tsm, sigma, zrgb, zsem, wc);
-                continue;
-            }
-        }
-#endif
         // ---- heads ----
         half8 bgeo[CT][1];
 #pragma unroll
@@ -564,7 +465,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int k = 0; k < L::KSh; ++k) {
                 save_pair<true>(from_constant(&la.train), tile, row0 + 16 * k, lane, stage, a[0][k], a[1][k]);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) if (MNF_EXP_SAVE != 3) mdump[((mblk + k) * CT + ct) * 64] = frag_mask(a[ct][k]);
+                for (int ct = 0; ct < CT; ++ct) mdump[((mblk + k) * CT + ct) * 64] = frag_mask(a[ct][k]);
             }
         };
         // rgb head (ngp.py:143-156, :202-213)
@@ -582,11 +483,6 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         dense_out<L::KSh>(s_w + L::o_s_out * 64, lane, h2, out_sem);
         if (la.out_fp16) round_outputs_fp16(out_sem);
 
-#if MNF_EXP_LOCK
-        if (MODE == 2 && !SAVE && !DENSITY_ONLY) {
-            if (lane == 0) s_lock[wave & 3] = 0;
-        }
-#endif
         // ---- write out ----
         // rgb rows 0..2 of this lane's own sample: lane (lane&31), registers 0..2 of tile h
         float rgb[3];
@@ -597,23 +493,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             rgb[k] = 1.0f / (1.0f + expf(-(h ? t1 : t0)));   // ngp.py:211-212
         }
         if (MODE == 2) {
-#if MNF_COL_AHEAD
-            if (!DENSITY_ONLY && !SAVE && !ENC) {
-                const int64_t tile_next = tile0 + (grp + g_step) * wpb + wave;
-                if (grp + g_step < g_end && tile_next < n_tiles) cd_next = load_cols(args, tile_next, lane);
-            }
-#endif
-#if MNF_KNOCK & 1
-            // diagnostic build: the compositing epilogue is skipped (outputs kept alive by a store that never happens)
-            float sink = sigma + rgb[0] + rgb[1] + rgb[2];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sink += out_sem[ct][i];
-            if (sink == 1.2345e30f) la.io.fr.acc[0] = sink;
-#else
             fused_composite(fr_of_kernarg(), in_loop(la.C), in_loop_v(lane), tsm, sigma, rgb, out_sem, wc);
-#endif
             continue;
         }
         if (col < n) {
@@ -760,6 +640,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));
     a.C = f->cfg.num_semantic_classes;
     a.out_fp16 = f->cfg.output_fp16 ? 1 : 0;
+    a.blend16 = f->cfg.blend_fp16 ? 1 : 0;
     static const int active_waves = diag_env("MNF_FIELD_ACTIVE_WAVES") ? atoi(diag_env("MNF_FIELD_ACTIVE_WAVES")) : kWavesPerBlock;
     a.active_waves = active_waves >= 1 && active_waves <= kWavesPerBlock ? active_waves : kWavesPerBlock;
     a.levels = reinterpret_cast<const LevelMeta *>(reinterpret_cast<const char *>(f->d_frags) + (size_t)f->shape.blocks_total * 1024);

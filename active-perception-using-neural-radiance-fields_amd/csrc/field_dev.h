@@ -99,6 +99,7 @@ struct KernelArgs {
     int C;
     int out_fp16;           // mnf_field_config.output_fp16: round every network output to fp16 (tcnn's hand-over precision)
     int active_waves;       // experiment knob (MNF_FIELD_ACTIVE_WAVES): waves per workgroup that take tiles, default 8
+    int blend16;            // mnf_field_config.blend_fp16: the hash levels' 8-corner blend as fp16 fused multiply-adds (tcnn's T = __half arithmetic)
     const LevelMeta *levels;   // [16] in device memory, wave-uniform: read with scalar loads where a batch needs them
                                // (as a by-value kernarg array the 112 dwords were all loaded up front and lived in
                                // spilled SGPRs: ~1000 v_readlane per tile)
@@ -118,17 +119,11 @@ __device__ __forceinline__ int feat_acc(int h, int j) { return 8 * (j >> 2) + 4 
 // one byte permute), so that each lane owns a (row, 2 adjacent samples) dword; those go into this wave's 2 KB LDS tile
 // [16 rows][64 samples], which is read back as 16-byte pieces and leaves as two `global_store_dwordx4` per lane (2 KB
 // contiguous per group).  Before: 16 `global_store_short` per group — the stores, not the bytes, cost 0.6 ms of the 1.3 ms
-// training forward and 0.5 ms of the backward-data kernel (MNF_EXP_SAVE experiments).
+// training forward and 0.5 ms of the backward-data kernel (round-2 experiments; tools/experiments/field_variants.patch).
 constexpr int kStageHalves = 8 * 64;     // per-wave staging tile: 8 rows x 64 samples (the 16-row group goes out in two passes)
 
-#ifndef MNF_EXP_SAVE
-#define MNF_EXP_SAVE 0      /* timing experiment only (results invalid): 1 = no activation stores */
-#endif
 template <bool ACC_ORDER>
 __device__ __forceinline__ void save_pair(const TrainBuf &tb, int64_t tile, int row0, int lane, half_t *stage, const half8 &f0, const half8 &f1) {
-#if MNF_EXP_SAVE == 1
-    return;
-#endif
     const int c = lane & 31, h = lane >> 5, odd = c & 1;
     uint32_t *st32 = reinterpret_cast<uint32_t *>(stage);
     const uint32_t sel = odd ? 0x03020706u : 0x05040100u;   // even lane: {own.lo, partner.lo}; odd lane: {partner.hi, own.hi}
@@ -152,9 +147,6 @@ __device__ __forceinline__ void save_pair(const TrainBuf &tb, int64_t tile, int 
             }
         }
         __builtin_amdgcn_wave_barrier();
-#if MNF_EXP_SAVE == 2
-        if (src[lane][0] == 0x12345678u)      /* timing experiment: transposes and LDS traffic kept, (almost) no global store */
-#endif
         *reinterpret_cast<u32x4 *>(gbase + (q * 64 + lane) * 16) = src[lane];
         __builtin_amdgcn_wave_barrier();
     }
@@ -271,28 +263,8 @@ __device__ __forceinline__ LevelMeta level_meta(LevelsPtr lv, int l) {
 // levels can be in flight together: hash_prep computes the 8 byte offsets and the separable trilinear weights,
 // hash_blend consumes the 8 loaded entries.  The blend weight of corner (bx,by,bz) is ((wx*wy)*wz), the same
 // association as the oracle's running product.
-#ifndef MNF_MIX_ASM
-#define MNF_MIX_ASM 0
-#endif
-#ifndef MNF_PK
-#define MNF_PK 0            /* 1: x/y grid position, fraction and 1 - fraction as v_pk_fma_f32 / v_pk_add_f32 with the level scale read
-                               from an SGPR pair.  Measured on MI355X: wrong features in lanes 48..63 of occasional tiles (13-35 samples
-                               of 5037 per launch, different tiles from run to run; tools/debug_pk.py) -- kept off.  The packed
-                               multiplies of the blend weights (VGPR operands only) are not affected and stay on. */
-#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // arithmetic on it is v_pk_{mul,add,fma}_f32: two fp32 results per issue slot
-#if MNF_PK == 4 || MNF_PK == 5
-// root-cause instrumentation (tools/r03_pk.sh): [0] = number of records, then records of 8 words:
-// lane, level scale bits, x bits, y bits, packed result lo, packed result hi, scalar result hi, workgroup
-static __device__ unsigned int g_pk_dbg[8 * 512 + 8];      // (one copy per translation unit: the reader lives in field.hip's fp16 unit)
-#endif
 
-#ifndef MNF_PAIR_DENSE
-#define MNF_PAIR_DENSE 0     /* 1: dense levels fetch the two x-neighbour corners of a cell (adjacent table entries) with ONE 16-byte gather per pair: 4 instead of 8
-                               lane-loads per dense level, 108 instead of 128 per sample.  Measured on MI355X (round 3, tools/r03_ab.sh): no change -- 800x800 render
-                               37.86 vs 37.63 M rays/s, random-weight leg 148.95 vs 149.4, field kernel 0.7139 vs 0.7117 ms per launch; results bit-identical.  The L1's
-                               divergent-lane rate is not what limits the kernel.  Kept off (8 % more code). */
-#endif
 typedef _Float16 tab8 __attribute__((ext_vector_type(8), aligned(8)));      // two adjacent entries: a 16-byte load that is only 8-byte aligned
 
 struct LevelPrep {
@@ -305,39 +277,6 @@ struct LevelPrep {
 
 __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], LevelPrep &o, bool all_in_box = false) {
     // x and y as one packed pair (same operations, same rounding as the scalar form), z alone
-#if MNF_PK
-    f32x2 sc2 = {m.scale, m.scale};
-#if MNF_PK == 2
-    asm volatile("" : "+v"(sc2));       // root-cause variant: the scale pair lives in VGPRs (no scalar operand on the packed op)
-#elif MNF_PK == 3
-    asm volatile("" : "+s"(sc2));       // root-cause variant: an SGPR pair with BOTH halves written (no op_sel broadcast of the low half)
-#endif
-#if MNF_PK == 5
-    asm volatile("s_nop 7\n\ts_nop 7");    // variant: 16 wait states between the scalar load of the scale and the packed instruction
-#endif
-    const f32x2 pxy = __builtin_elementwise_fma(sc2, f32x2{xn[0], xn[1]}, f32x2{0.5f, 0.5f});
-#if MNF_PK == 4 || MNF_PK == 5
-    {   // the same two products with scalar-operand v_fma_f32: any difference is recorded
-        float sx = m.scale, rx, ry;
-        asm volatile("v_fma_f32 %0, %2, %3, 0.5\n\tv_fma_f32 %1, %2, %4, 0.5" : "=&v"(rx), "=&v"(ry) : "s"(sx), "v"(xn[0]), "v"(xn[1]));
-        if (rx != pxy.x || ry != pxy.y) {
-            const unsigned k = atomicAdd(&g_pk_dbg[0], 1u);
-            if (k < 512) {
-                unsigned *r = g_pk_dbg + 8 + 8 * k;
-                r[0] = threadIdx.x & 63; r[1] = __builtin_bit_cast(unsigned, m.scale); r[2] = __builtin_bit_cast(unsigned, xn[0]); r[3] = __builtin_bit_cast(unsigned, xn[1]);
-                r[4] = __builtin_bit_cast(unsigned, pxy.x); r[5] = __builtin_bit_cast(unsigned, pxy.y); r[6] = __builtin_bit_cast(unsigned, ry); r[7] = blockIdx.x;
-            }
-        }
-    }
-#endif
-    const float pz = __builtin_fmaf(m.scale, xn[2], 0.5f);
-    const f32x2 fxy = {floorf(pxy.x), floorf(pxy.y)};
-    const float fz = floorf(pz);
-    const f32x2 frxy = pxy - fxy;
-    const float frz = pz - fz;
-    const uint32_t cell[3] = {(uint32_t)(int32_t)fxy.x, (uint32_t)(int32_t)fxy.y, (uint32_t)(int32_t)fz};
-    const f32x2 one_m = f32x2{1.0f, 1.0f} - frxy;          // {1 - fx, 1 - fy}
-#else
     const float px = __builtin_fmaf(m.scale, xn[0], 0.5f), py = __builtin_fmaf(m.scale, xn[1], 0.5f), pz = __builtin_fmaf(m.scale, xn[2], 0.5f);
     const f32x2 fxy = {floorf(px), floorf(py)};
     const float fz = floorf(pz);
@@ -345,7 +284,6 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
     const float frz = pz - fz;
     const uint32_t cell[3] = {(uint32_t)(int32_t)fxy.x, (uint32_t)(int32_t)fxy.y, (uint32_t)(int32_t)fz};
     const f32x2 one_m = {1.0f - frxy.x, 1.0f - frxy.y};
-#endif
     o.wz[0] = 1.0f - frz; o.wz[1] = frz;
     const f32x2 wx = {one_m.x, frxy.x};                    // {wx0, wx1}
     o.wxy[0] = wx * f32x2{one_m.y, one_m.y};
@@ -378,12 +316,6 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
                 const uint32_t idx = cell[0] + (uint32_t)(corner & 1) + ((corner >> 1) & 1 ? ty1 : ty0) + ((corner >> 2) ? tz1 : tz0);
                 o.off[corner] = min(idx, idx - m.size) * 8u;
             }
-#if MNF_PAIR_DENSE
-            // corners (x, y, z) and (x+1, y, z) are entries idx and idx+1 unless the index wraps between them (only at the far corner of the level):
-            // when no lane of the wave has such a pair the level is fetched as four 16-byte gathers
-            const bool split = (o.off[1] != o.off[0] + 8u) | (o.off[3] != o.off[2] + 8u) | (o.off[5] != o.off[4] + 8u) | (o.off[7] != o.off[6] + 8u);
-            o.paired = __ballot(split) == 0ull ? 1u : 0u;
-#endif
         } else {
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
@@ -397,25 +329,8 @@ __device__ __forceinline__ void hash_prep(const LevelMeta m, const float xn[3], 
     }
 }
 
-__device__ __forceinline__ void hash_load(const tab4 *__restrict__ table, const LevelPrep &p, tab4 (&v)[8], bool stream = false) {
+__device__ __forceinline__ void hash_load(const tab4 *__restrict__ table, const LevelPrep &p, tab4 (&v)[8]) {
     const char *level = reinterpret_cast<const char *>(table + p.base);      // uniform: scalar address arithmetic
-#if MNF_PAIR_DENSE
-    if (p.paired) {   // wave-uniform
-#pragma unroll
-        for (int pair = 0; pair < 4; ++pair) {
-            const tab8 two = *reinterpret_cast<const tab8 *>(level + p.off[2 * pair]);
-            v[2 * pair] = {two[0], two[1], two[2], two[3]};
-            v[2 * pair + 1] = {two[4], two[5], two[6], two[7]};
-        }
-        return;
-    }
-#endif
-    if (stream) {   // wave-uniform: a level whose lines are not worth keeping in L2 (experiment: MNF_NT_FROM)
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner)
-            v[corner] = __builtin_nontemporal_load(reinterpret_cast<const tab4 *>(level + p.off[corner]));
-        return;
-    }
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner)
         v[corner] = *reinterpret_cast<const tab4 *>(level + p.off[corner]);
@@ -439,20 +354,34 @@ __device__ __forceinline__ void hash_blend(const LevelPrep &p, const tab4 (&v)[8
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
         const float w = (corner & 1) ? w4[corner >> 1].y : w4[corner >> 1].x;
-#if MNF_MIX_ASM
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 d = __builtin_bit_cast(u32x2, v[corner]);
-        a0 = fma_mix_half<0>(d[0], w, a0); a1 = fma_mix_half<1>(d[0], w, a1);
-        a2 = fma_mix_half<0>(d[1], w, a2); a3 = fma_mix_half<1>(d[1], w, a3);
-#else
         // fma(fpext(half), w, acc): selected as v_fma_mix_f32 (one instruction per feature; no SLP pairing in this file).
         // Left to the compiler rather than inline asm so that its hazard recogniser sees producer and consumer: the asm form
         // right behind a v_pk_mul_f32 gave wrong values in lanes 48..63 of occasional tiles.
         a0 = __builtin_fmaf((float)v[corner][0], w, a0); a1 = __builtin_fmaf((float)v[corner][1], w, a1);
         a2 = __builtin_fmaf((float)v[corner][2], w, a2); a3 = __builtin_fmaf((float)v[corner][3], w, a3);
-#endif
     }
     f[0] = a0; f[1] = a1; f[2] = a2; f[3] = a3;
+}
+
+// The same blend in tiny-cuda-nn's half-precision arithmetic (mnf_field_config.blend_fp16): `result = fma((T)weight, entry, result)` with T = __half,
+// corners in index order (x fastest) — the weight rounded to fp16, the running sum an fp16 fused multiply-add per corner.  The two feature pairs of an
+// entry are the two dwords it was loaded as, so a corner is one conversion and two v_pk_fma_f16; the result is already the 16-bit MLP input.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 hash_blend16(const LevelPrep &p, const tab4 (&v)[8]) {
+    h16x2 a01 = {(_Float16)0.0f, (_Float16)0.0f}, a23 = a01;
+    const f32x2 w4[4] = {p.wxy[0] * f32x2{p.wz[0], p.wz[0]}, p.wxy[1] * f32x2{p.wz[0], p.wz[0]},
+                         p.wxy[0] * f32x2{p.wz[1], p.wz[1]}, p.wxy[1] * f32x2{p.wz[1], p.wz[1]}};
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const _Float16 wh = (_Float16)((corner & 1) ? w4[corner >> 1].y : w4[corner >> 1].x);
+        const h16x2 w2 = {wh, wh};
+        const u32x2 d = __builtin_bit_cast(u32x2, v[corner]);
+        const uint32_t d0 = d.x, d1 = d.y;
+        a01 = __builtin_elementwise_fma(w2, __builtin_bit_cast(h16x2, d0), a01);
+        a23 = __builtin_elementwise_fma(w2, __builtin_bit_cast(h16x2, d1), a23);
+    }
+    return u32x2{__builtin_bit_cast(uint32_t, a01), __builtin_bit_cast(uint32_t, a23)};
 }
 
 // tcnn SphericalHarmonics degree 4 on 2u-1, u = (d+1)/2 (ngp.py:205): all 16 values of the lane's sample

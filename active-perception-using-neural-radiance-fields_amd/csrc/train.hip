@@ -924,8 +924,6 @@ struct TrainState {
     float *d_partials = nullptr;
     size_t partials_floats = 0;
     // binned scatter of the large hashed levels (allocated on first use, grows with the sample bound): item lists + list cursors
-    float4 *d_bin_items = nullptr;
-    size_t bin_items = 0;
     uint32_t *d_bin_cursors = nullptr;
 };
 
@@ -982,7 +980,6 @@ void free_train_state_impl(mnf_field_t f) {
     if (ts->d_groups) (void)hipFree(ts->d_groups);
     if (ts->d_qtable) (void)hipFree(ts->d_qtable);
     if (ts->d_partials) (void)hipFree(ts->d_partials);
-    if (ts->d_bin_items) (void)hipFree(ts->d_bin_items);
     if (ts->d_bin_cursors) (void)hipFree(ts->d_bin_cursors);
     if (ts->ev_fork) (void)hipEventDestroy(ts->ev_fork);
     if (ts->ev_join) (void)hipEventDestroy(ts->ev_join);
@@ -995,6 +992,8 @@ void free_train_state_impl(mnf_field_t f) {
 
 struct WsView {
     half_t *act; uint8_t *masks; float *dX, *xn, *repl;
+    float4 *bin_items;     // item lists of the binned scatter (levels kBinLevel0Default .. 15): part of the caller's workspace since round 4 (ADVICE r03:
+    size_t bin_items_n;    // they were ~720 B per sample of raw hipMalloc per train state, invisible to the caller's allocator and grown mid-step)
     half8 *enc;            // fused backward: the forward's encoded inputs ([tiles][kEncBlocks][64] x 16 B) instead of act / masks
     int64_t Np, bytes;
 };
@@ -1008,7 +1007,23 @@ static bool use_fused_backward(mnf_field_t f, bool deterministic) {
     return !deterministic && f->cfg.neurons == 128 && f->cfg.layers <= 2 && f->bwd_mode == 2;
 }
 
-static WsView carve_train(const TrainTables &tt, void *base, int64_t n) {
+// the binned scatter's plan for an upper bound of n samples: levels [first, 16) (all hashed, one size, whole bins), lists per level, items per list
+constexpr int kBinLevel0Default = 11;      // measured (tools/r03_bins_step.sh, profiles/r03_bins_step_*.txt): step time flat from 10 to 12, worse below and above
+static void bin_plan(const mnf_field_s *f, int64_t n, int want, int &first_binned, uint32_t &nb, uint32_t &cap) {
+    first_binned = 16; nb = 0; cap = 0;
+    if (n < 8192) return;                    // small batches: the walk alone (pass B costs ~20 us whatever it is given)
+    for (int l = 15; l >= want && l >= 0; --l) {
+        const LevelMeta &lm = f->levels[l];
+        if (!lm.hashed || lm.size < kBinEntries || (lm.size & (lm.size - 1u)) || lm.size != f->levels[15].size || (lm.size >> kBinEntriesLog2) > (uint32_t)kMaxBins) break;
+        first_binned = l;
+    }
+    if (first_binned == 16) return;
+    nb = f->levels[15].size >> kBinEntriesLog2;
+    const uint64_t per_list = (uint64_t)n * 8 / nb;
+    cap = (uint32_t)(per_list + per_list / 8 + 2048);      // a uniform hash fills the lists evenly; the excess of a full one goes to the atomics
+}
+
+static WsView carve_train(const TrainTables &tt, const mnf_field_s *f, void *base, int64_t n) {
     WsView v;
     v.Np = ceil_div(n, 64) * 64;
     size_t off = 0;
@@ -1019,6 +1034,12 @@ static WsView carve_train(const TrainTables &tt, void *base, int64_t n) {
     v.xn = (float *)take((size_t)v.Np * 3 * 4);
     v.repl = (float *)take((size_t)kReplicas * kReplMaxEntries * 4 * sizeof(float));   // private copies of the coarsest levels' gradient (scatter)
     v.enc = (half8 *)take((size_t)(v.Np / 64) * kEncBlocks * 64 * sizeof(half8));
+    {
+        int first; uint32_t nb, cap;
+        bin_plan(f, n, kBinLevel0Default, first, nb, cap);
+        v.bin_items_n = (size_t)(16 - first) * nb * cap;
+        v.bin_items = (float4 *)take(v.bin_items_n * sizeof(float4));
+    }
     v.bytes = (int64_t)off;
     return v;
 }
@@ -1032,7 +1053,7 @@ int64_t train_workspace_bytes_impl(mnf_field_t f, int64_t n) {
     if (!f || n < 0) return -1;
     TrainTables tt;
     if (!tables_for(f->cfg.neurons, f->cfg.layers, f->cfg.num_semantic_classes, tt)) return -1;
-    return carve_train(tt, nullptr, n).bytes;
+    return carve_train(tt, f, nullptr, n).bytes;
 }
 
 int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_t workspace_bytes, hipStream_t stream, bool deterministic) {
@@ -1042,7 +1063,7 @@ int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_
     int rc = ensure_train_state(f);
     if (rc) return rc;
     TrainState *ts = reinterpret_cast<TrainState *>(f->train_state);
-    WsView v = carve_train(ts->tt, workspace, io.n);
+    WsView v = carve_train(ts->tt, f, workspace, io.n);
     if (!workspace || workspace_bytes < v.bytes) {
         set_error("field_forward_train: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)v.bytes);
         return MNF_ERR_WORKSPACE;
@@ -1067,7 +1088,7 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     int rc = ensure_train_state(f);
     if (rc) return rc;
     TrainState *ts = reinterpret_cast<TrainState *>(f->train_state);
-    WsView v = carve_train(ts->tt, workspace, n);
+    WsView v = carve_train(ts->tt, f, workspace, n);
     if (!workspace || workspace_bytes < v.bytes) {
         set_error("field_backward: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)v.bytes);
         return MNF_ERR_WORKSPACE;
@@ -1208,34 +1229,20 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     static const bool simple = diag_env("MNF_HASH_BWD_SIMPLE") != nullptr;   // debugging aid: one atomic per lane, corner and feature
     // levels [first_binned, 16): through the bins (all of them hashed tables of one size that whole bins tile); the rest: the walk
     int first_binned = 16;
-    if (!deterministic && !simple && n_levels == 16 && n >= 8192) {     // (small batches: the walk alone; pass B costs ~20 us whatever it is given)
-        int want = 11;       // measured on MI355X (tools/r03_bins_step.sh, profiles/r03_bins_step.txt): step time is flat from 10 to 12, worse below (runs of samples share
-                             // cells on the coarser levels: the walk merges them, the bins cannot) and above
+    uint32_t nb_plan = 0, cap = 0;
+    if (!deterministic && !simple && n_levels == 16) {
+        int want = kBinLevel0Default;
         if (const char *e = diag_env("MNF_BIN_LEVEL0")) want = atoi(e);
-        first_binned = 16;
-        for (int l = 15; l >= want && l >= 0; --l) {
-            const LevelMeta &lm = f->levels[l];
-            if (!lm.hashed || lm.size < kBinEntries || (lm.size & (lm.size - 1u)) || lm.size != f->levels[15].size || (lm.size >> kBinEntriesLog2) > (uint32_t)kMaxBins) break;
-            first_binned = l;
-        }
+        bin_plan(f, n, want, first_binned, nb_plan, cap);
+        if (const char *e = diag_env("MNF_BIN_CAP")) cap = (uint32_t)atoi(e);     // tests: force the full-list path
+        while (first_binned < 16 && (size_t)(16 - first_binned) * nb_plan * cap > v.bin_items_n) ++first_binned;      // (a diagnostic plan larger than the workspace's)
     }
     BinArgs ba;
     const int n_binned = 16 - first_binned;
     if (n_binned > 0) {
-        const uint32_t nb = f->levels[15].size >> kBinEntriesLog2;
-        const uint64_t per_list = (uint64_t)n * 8 / nb;
-        uint32_t cap = (uint32_t)(per_list + per_list / 8 + 2048);                // a uniform hash fills the lists evenly; the excess of a full one goes to the atomics
-        if (const char *e = diag_env("MNF_BIN_CAP")) cap = (uint32_t)atoi(e);     // tests: force the full-list path
-        const size_t need = (size_t)n_binned * nb * cap;
-        if (ts->bin_items < need) {
-            if (ts->d_bin_items) { MNF_HIP(hipStreamSynchronize(ts->side2)); (void)hipFree(ts->d_bin_items); }
-            ts->d_bin_items = nullptr; ts->bin_items = 0;
-            MNF_HIP(hipMalloc((void **)&ts->d_bin_items, need * sizeof(float4)));
-            ts->bin_items = need;
-        }
         ba.chunk = 0; ba.n_chunks = 1;
         ba.positions = hb.positions; ba.dX = hb.dX; ba.Np = hb.Np; ba.n = n; ba.n_dev = n_dev; ba.level0 = first_binned; ba.n_levels = n_binned;
-        ba.items = ts->d_bin_items; ba.cursors = ts->d_bin_cursors; ba.cap = cap; ba.g_table = hb.g_table;
+        ba.items = v.bin_items; ba.cursors = ts->d_bin_cursors; ba.cap = cap; ba.g_table = hb.g_table;
         std::memcpy(ba.levels, f->levels, sizeof(ba.levels));
         n_levels = first_binned;
     }

@@ -109,7 +109,7 @@ class NGPRadianceField(torch.nn.Module):
                  neurons: int = 128, layers: int = 4, density_activation=None, unbounded: bool = False,
                  base_resolution: int = 16, max_resolution: int = 4096, geo_feat_dim: int = 15, n_levels: int = 16,
                  log2_hashmap_size: int = 19, num_semantic_classes: int = 0, seed: int = 0,
-                 tcnn_output_rounding: bool = False, mfma_bf16: bool = False) -> None:
+                 tcnn_output_rounding: bool = False, mfma_bf16: bool = False, tcnn_blend_fp16: bool = False) -> None:
         super().__init__()
         if not isinstance(aabb, torch.Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
@@ -138,6 +138,8 @@ class NGPRadianceField(torch.nn.Module):
         cfg.output_fp16 = 1 if tcnn_output_rounding else 0
         # matrix-core operand type: fp16 (the reference's tcnn arithmetic) or bf16 (BASELINE config 5); the hash table stays fp16
         cfg.mfma_bf16 = 1 if mfma_bf16 else 0
+        # precision of the 8-corner hash blend: fp32 with one rounding (default) or tcnn's fp16 fused multiply-adds (include/mi355nerf.h: blend_fp16)
+        cfg.blend_fp16 = 1 if tcnn_blend_fp16 else 0
         self._cfg = cfg
         self._handle = ctypes.c_void_p()
         self._handle_device = None

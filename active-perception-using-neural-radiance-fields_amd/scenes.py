@@ -21,11 +21,11 @@ def make_scene(scene="102344250", neurons=128, layers=2, C=29, seed=0, log2_hash
                 neurons=neurons, layers=layers, C=C, log2_hashmap_size=log2_hashmap_size)
 
 
-def hip_field(scene, device="cuda:0", tcnn_output_rounding=False, mfma_bf16=False):
+def hip_field(scene, device="cuda:0", tcnn_output_rounding=False, mfma_bf16=False, tcnn_blend_fp16=False):
     from .ngp import NGPRadianceField
     f = NGPRadianceField(aabb=torch.from_numpy(scene["aabb"]), neurons=scene["neurons"], layers=scene["layers"],
                          num_semantic_classes=scene["C"], log2_hashmap_size=scene["log2_hashmap_size"],
-                         tcnn_output_rounding=tcnn_output_rounding, mfma_bf16=mfma_bf16)
+                         tcnn_output_rounding=tcnn_output_rounding, mfma_bf16=mfma_bf16, tcnn_blend_fp16=tcnn_blend_fp16)
     with torch.no_grad():
         f.mlp_base.params.copy_(torch.from_numpy(scene["params"]["mlp_base"]))
         f.mlp_head.params.copy_(torch.from_numpy(scene["params"]["mlp_head"]))

@@ -142,8 +142,14 @@ def _thread_sweep(fn, unit_count, set_threads, budget_s=25.0):
         sweep[th] = unit_count / t
         notes.append(f"{th} threads: {warm} warm-up(s) + {iters} iterations" if iters else f"{th} threads: 1 pass")
         best_t = t if best_t is None else min(best_t, t)
-    set_threads(cores)
     best = max(sweep, key=sweep.get)
+    # the reported figure itself follows the protocol in full (3 warm-ups + 20 timed iterations) when that fits ~25 s: the sweep above only picks the thread count
+    per_pass = unit_count / sweep[best]
+    if f"{best} threads: 3 warm-up(s) + 20 iterations" not in notes and 23 * per_pass <= 25.0:
+        set_threads(best)
+        sweep[best] = unit_count / _timed(fn, 3, 20)
+        notes.append(f"reported value: {best} threads re-timed with 3 warm-up(s) + 20 iterations")
+    set_threads(cores)
     return sweep[best], best, {str(k): v for k, v in sweep.items()}, "median of timed passes, best thread count reported; " + "; ".join(notes)
 
 

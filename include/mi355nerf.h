@@ -240,6 +240,12 @@ typedef struct {
     int32_t mfma_bf16;             /* 0 (default): fp16 matrix-core operands (weights, MLP inputs, activations and their gradients), the
                                       reference's tiny-cuda-nn arithmetic.  1: bf16 operands (BASELINE config 5); the hash table stays
                                       fp16, accumulation fp32 */
+    int32_t blend_fp16;            /* 0 (default): the 8-corner blend of a hash level runs in fp32 (fp32 weight x widened fp16 entry, fp32 sum, ONE rounding
+                                      to the 16-bit MLP input).  1: tiny-cuda-nn's own arithmetic as published (grid encoding instantiated with T = __half
+                                      behind a half-precision network): the corner weight is rounded to fp16 and the sum runs as fp16 fused multiply-adds,
+                                      `result = fma((T)weight, entry, result)`, corners in index order (x fastest) — packed v_pk_fma_f16 on the two
+                                      feature pairs.  Changes features by ~1e-3 relative; which one the reference's un-pinned tinycudann build computes
+                                      cannot be verified in this container. */
 } mnf_field_config;
 
 /* tcnn.NetworkWithInputEncoding / tcnn.Network / tcnn.Encoding construction, ngp.py:108-169 */

@@ -147,8 +147,14 @@ def _split_mlp(flat: torch.Tensor, shapes) -> List[torch.Tensor]:
 class OracleField:
     """forward / query_density with the ngp.py call surface, torch CPU fp32."""
 
-    def __init__(self, cfg: FieldConfig, params: Dict[str, np.ndarray], precision: str = "f16", requires_grad: bool = False):
+    def __init__(self, cfg: FieldConfig, params: Dict[str, np.ndarray], precision: str = "f16", requires_grad: bool = False,
+                 blend: str = "f32"):
+        """blend: precision of the 8-corner interpolation of a hash level.  "f32" (default): fp32 weight x fp16 entry summed in fp32 (one rounding
+        when the feature enters the network).  "f16": tiny-cuda-nn's published kernel with T = __half (grid.h `kernel_grid`): the weight is cast to
+        half and `result = fma((T)weight, value, result)` runs in half precision, corners in index order.  Which of the two the reference's
+        un-pinned tinycudann computes cannot be checked here (parity unpinned); the product's mirror is mnf_field_config.blend_fp16."""
         self.cfg = cfg
+        self.blend = blend
         self.precision = precision
         self.num_semantic_classes = cfg.num_semantic_classes
         self.aabb = torch.tensor(cfg.aabb, dtype=torch.float32)
@@ -183,6 +189,7 @@ class OracleField:
             frac = pos - cell
             cell = cell.to(torch.int32).to(torch.int64) & 0xFFFFFFFF  # (uint32)(int)floorf
             acc = torch.zeros(N, F, dtype=torch.float32)
+            acc16 = np.zeros((N, F), np.float16) if self.blend == "f16" else None
             for corner in range(8):
                 w = torch.ones(N, dtype=torch.float32)
                 idx3 = []
@@ -199,6 +206,14 @@ class OracleField:
                     res = lv["res"]
                     index = ((idx3[0] + idx3[1] * res + idx3[2] * res * res) & 0xFFFFFFFF) % lv["n"]
                 acc = acc + w[:, None] * self.table[lv["offset"] + index]
+                if acc16 is not None:
+                    # half-precision fused multiply-add: the product of two halves and the half sum are exact in float64; ONE rounding to half (numpy's
+                    # float64 -> float16 conversion rounds directly)
+                    w16 = w.detach().numpy().astype(np.float16).astype(np.float64)
+                    val = self.table[lv["offset"] + index].detach().numpy().astype(np.float64)
+                    acc16 = (w16[:, None] * val + acc16.astype(np.float64)).astype(np.float16)
+            if acc16 is not None:     # the half-precision value with the fp32 blend's gradient (straight-through, as every rounding of this oracle)
+                acc = acc + (torch.from_numpy(acc16.astype(np.float32)) - acc.detach())
             outs.append(acc)
         return torch.cat(outs, -1)
 

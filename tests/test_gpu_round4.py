@@ -140,3 +140,132 @@ def test_dynamic_ray_count_schedule_async_matches_sync():
         torch.cuda.synchronize()
         RD.train_step(hip, H.hip_estimator(sc), opt, RD.Rays(o_all[:64].to(DEV), d_all[:64].to(DEV)), pix_all[:64].to(DEV), dep_all[:64].to(DEV), lab_all[:64].to(DEV), bk,
                       step=200, sync=False, stratified=False, **H.RENDER_KW)
+
+
+# ------------------------------------------------------------------ BASELINE configs 3 and 4 at the benchmark's own size, trained weights
+def _render_errors(got, ref, n):
+    """per-ray max |error| of rgb / acc / depth / composited class logits; the logits both ways: absolute (the north star's 1e-3) and relative to
+    max(1, largest |logit| of the ray) (on trained weights the logits reach +-50 and carry fp16's relative error)."""
+    errs = {k: (got[k].cpu() - ref[k]).abs().reshape(n, -1).max(dim=1).values.numpy() for k in ("rgb", "acc", "depth", "sem")}
+    sem_mag = np.maximum(1.0, ref["sem"].abs().max(dim=1).values.numpy())
+    return errs, errs["sem"] / sem_mag, sem_mag
+
+
+def test_config3_trained_scene_sparse_parity_at_1e3():
+    """BASELINE config 3 as bench.py renders it: the 2000-iteration stand-in of scene 102344529, an 800x800 view, a 24x24
+    linspace sub-sample of its rays rendered stand-alone on the GPU and through the oracle (same call shape, hence the same round schedule):
+    rgb / acc / depth within 1e-3 absolute, class logits within 1e-3 x max(1, |logit|) — both forms reported — with the tie budget (<= 2 rays up
+    to 5e-2: a sample on the alpha-threshold edge), PSNR > 50 dB, evaluated-sample totals within 0.2 %."""
+    from apnrf_amd import render as RD
+    from apnrf_amd import standin as SI
+    from oracle import render as R
+    sc = H.make_scene("102344529", n_poses=40)
+    field, est, _ = SI.train_standin(sc, DEV, steps=2000, seed=9)
+    from oracle.field import FieldConfig, OracleField
+    cfg = FieldConfig(aabb=tuple(float(x) for x in sc["aabb"]), neurons=sc["neurons"], layers=sc["layers"], num_semantic_classes=sc["C"],
+                      log2_hashmap_size=sc["log2_hashmap_size"])
+    params = {"mlp_base": field.mlp_base.params.detach().cpu().numpy(), "mlp_head": field.mlp_head.params.detach().cpu().numpy(),
+              "mlp_sem": field.mlp_sem.params.detach().cpu().numpy()}
+    orc = OracleField(cfg, params, "f16", False)
+    occ = est.binaries.cpu().numpy()
+    S_, width = 24, 800
+    focal = 0.5 * width / np.tan(np.pi / 4)
+    bk = torch.zeros(3)
+    worst_all = []
+    for pose in (0, 15):
+        idx = R.subsample_indices(width * width, S_ * S_)
+        o, d = R.generate_image_rays(R.pose_to_c2w(sc["poses"][pose]), width, width, focal, idx)
+        ref = R.render_test(1024, orc, occ, sc["aabb"][None], o, d, render_bkgd=bk, **H.RENDER_KW)
+        got = RD.render_views(field, est, o.to(DEV), d.to(DEV), S_ * S_, 1024, render_bkgd=bk, **H.RENDER_KW)
+        errs, sem_scaled, sem_mag = _render_errors(got, ref, S_ * S_)
+        worst = np.max(np.stack([errs["rgb"], errs["acc"], errs["depth"], sem_scaled]), axis=0)
+        tie = worst > 1e-3
+        mse = float(((got["rgb"].cpu() - ref["rgb"]) ** 2).mean())
+        print(f"config 3 pose {pose}: max abs rgb {errs['rgb'][~tie].max():.2e} acc {errs['acc'][~tie].max():.2e} depth {errs['depth'][~tie].max():.2e} | sem scaled "
+              f"{sem_scaled[~tie].max():.2e}, unscaled {errs['sem'].max():.2e} ({int((errs['sem'] > 1e-3).sum())} rays above 1e-3 absolute, largest |logit| {sem_mag.max():.1f}) | "
+              f"tie rays {int(tie.sum())} | PSNR {10 * np.log10(1.0 / max(mse, 1e-20)):.1f} dB | samples {int(got['total'][0])} vs {ref['total_samples']}")
+        assert worst[~tie].max() <= 1e-3 and tie.sum() <= 2 and (not tie.any() or worst[tie].max() <= 5e-2)
+        assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 50
+        assert abs(int(got["total"][0]) - ref["total_samples"]) <= max(4, 2e-3 * ref["total_samples"])
+        worst_all.append(worst)
+
+
+def test_config4_full_size_scoring_properties_and_oracle_views():
+    """BASELINE config 4 at full size (256 candidate views x 4096 rays x 2 ensemble members, trained stand-ins): the pass is deterministic, a
+    shard's rows equal the full pass's rows bit for bit (what lets the views shard over GPUs), every term is finite; eight of the views are
+    rendered by the oracle for both members and scored by the oracle's scorer: the GPU's per-view terms follow within the tolerance the 1e-3
+    render parity leaves (measured ~1e-4 relative)."""
+    from apnrf_amd import render as RD
+    from apnrf_amd import standin as SI
+    from oracle import render as R
+    from oracle import scorer as OS
+    from oracle.field import FieldConfig, OracleField
+    sc = H.make_scene("102344250", n_poses=40)
+    members = [SI.train_standin(sc, DEV, steps=300, seed=s_) for s_ in (21, 22)]
+    fields, ests = [m[0] for m in members], [m[1] for m in members]
+    poses = SI._free_space_poses(sc, 256, seed=9)
+    args = (640, 640, 320.0, 0.1, 1e-3, 0.1, 0.004, 0.01, DEV)
+    terms, score = RD.score_views(fields, ests, poses, *args, group=False)
+    terms2, _ = RD.score_views(fields, ests, poses, *args, group=False)
+    assert terms.shape == (256, 4) and torch.isfinite(terms).all() and torch.equal(terms, terms2)
+    part, _ = RD.score_views(fields, ests, poses[96:128], *args, group=False)
+    assert torch.equal(part, terms[96:128])                                       # one rank's share of an 8-GPU run == those rows of the full pass
+    assert abs(float(score) - float(RD.trajectory_score(terms))) < 1e-12
+    cfg = FieldConfig(aabb=tuple(float(x) for x in sc["aabb"]), neurons=sc["neurons"], layers=sc["layers"], num_semantic_classes=sc["C"],
+                      log2_hashmap_size=sc["log2_hashmap_size"])
+    orcs = [OracleField(cfg, {"mlp_base": f.mlp_base.params.detach().cpu().numpy(), "mlp_head": f.mlp_head.params.detach().cpu().numpy(),
+                              "mlp_sem": f.mlp_sem.params.detach().cpu().numpy()}, "f16", False) for f in fields]
+    idx = R.subsample_indices(640 * 640, 4096)
+    bk = torch.zeros(3)
+    worst = 0.0
+    for v in (0, 31, 64, 100, 129, 177, 222, 255):
+        o, d = R.generate_image_rays(R.pose_to_c2w(poses[v]), 640, 640, 320.0, idx)
+        rs = [R.render_prob_test(1024, orc, e.binaries.cpu().numpy(), sc["aabb"][None], o, d, render_bkgd=bk, **H.RENDER_KW) for orc, e in zip(orcs, ests)]
+        st = lambda key, *s: np.stack([r[key].numpy().reshape(1, 1, 64, 64, *s) for r in rs])
+        want = OS.per_view_terms(st("rgb_var", 3), st("depth_var"), st("acc"), st("sem", sc["C"]))[0]
+        got = terms[v].cpu().numpy()
+        rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-2)
+        print(f"config 4 view {v}: terms gpu {got} oracle {want} rel {rel}")
+        worst = max(worst, float(rel.max()))
+    assert worst < 2e-4, worst          # measured 2e-5 (profiles/r04_tests_full_size.txt)
+
+
+# ------------------------------------------------------------------ tcnn's fp16 hash blend (mnf_field_config.blend_fp16)
+@pytest.mark.parametrize("bf16", [False, True])
+def test_field_fp16_blend_matches_its_oracle_and_differs_from_fp32_blend_as_expected(bf16):
+    """`tcnn_blend_fp16=True`: the 8-corner blend as fp16 fused multiply-adds (tiny-cuda-nn's `fma((T)weight, value, result)`, T = __half)
+    against the oracle restating exactly that (`blend="f16"`) at the default path's tolerances; and BOTH cross comparisons, so that the
+    distance between the two blend precisions is on record: kernel fp16-blend vs oracle fp32-blend, kernel fp32-blend vs oracle fp16-blend."""
+    sc = H.make_scene(log2_hashmap_size=15, head_gain=4.0)
+    prec = "bf16" if bf16 else "f16"
+    rng = np.random.default_rng(1)
+    n = 5000 + 37
+    a = sc["aabb"]
+    pos = (rng.random((n, 3)) * (a[3:] - a[:3]) * 1.1 + a[:3] - 0.05 * (a[3:] - a[:3])).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    from oracle.field import FieldConfig, OracleField
+    cfg = FieldConfig(aabb=tuple(float(x) for x in sc["aabb"]), neurons=sc["neurons"], layers=sc["layers"], num_semantic_classes=sc["C"],
+                      log2_hashmap_size=sc["log2_hashmap_size"])
+    outs, refs = {}, {}
+    for blend in ("f32", "f16"):
+        hip = H.hip_field(sc, mfma_bf16=bf16, tcnn_blend_fp16=(blend == "f16"))
+        with torch.no_grad():
+            outs[blend] = [t.cpu().numpy() for t in hip(torch.from_numpy(pos).to(DEV), torch.from_numpy(d).to(DEV))]
+        refs[blend] = [t.numpy() for t in OracleField(cfg, sc["params"], prec, False, blend=blend)(torch.from_numpy(pos), torch.from_numpy(d))]
+    inside = refs["f32"][1][:, 0] > 0
+    tol = 8.0 if bf16 else 1.0
+
+    def worst(got, want):
+        return (float(np.abs(got[0][inside] - want[0][inside]).max()), float((np.abs(got[1] - want[1]) / (np.abs(want[1]) + 1e-6)).max()),
+                float((np.abs(got[2][inside] - want[2][inside]) / (1.0 + np.abs(want[2][inside]))).max()))
+    for kb in ("f32", "f16"):
+        for ob in ("f32", "f16"):
+            print(f"blend {prec}: kernel {kb} vs oracle {ob}: rgb max abs %.2e, sigma max rel %.2e, sem max err / (1 + |logit|) %.2e" % worst(outs[kb], refs[ob]))
+    for b in ("f32", "f16"):           # each kernel mode against the oracle of ITS arithmetic: the default path's bars
+        np.testing.assert_allclose(outs[b][1], refs[b][1], rtol=2e-3 * tol, atol=1e-6)
+        np.testing.assert_allclose(outs[b][0][inside], refs[b][0][inside], atol=1e-3 * tol, rtol=0)
+        np.testing.assert_allclose(outs[b][2][inside], refs[b][2][inside], atol=1e-3 * tol, rtol=2e-3 * tol)
+    assert not np.array_equal(outs["f32"][2], outs["f16"][2])      # the switch does change the arithmetic
+    # the two precisions are close to each other as well (features differ by fp16 rounding of the running sum): within 4x the bars
+    x = worst(outs["f16"], refs["f32"])
+    assert x[0] < 4e-3 * tol and x[1] < 1e-2 * tol and x[2] < 6e-3 * tol, x
