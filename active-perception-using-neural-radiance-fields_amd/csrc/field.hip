@@ -215,7 +215,9 @@ __device__ __forceinline__ FusedRender fr_of_kernarg() {
     return from_constant(p);
 }
 
-template <int W, int NH, int MODE, bool DENSITY_ONLY, int SAVEK = 0, bool ENC = false>
+// B16: the hash levels' 8-corner blend in tiny-cuda-nn's fp16 arithmetic (mnf_field_config.blend_fp16).  A template parameter, not a run-time branch: the
+// kernel sits at its register limits, and a wave-uniform `if` around the two blends cost the DEFAULT path 3 % (0.7116 -> 0.7325 ms per render launch).
+template <int W, int NH, int MODE, bool DENSITY_ONLY, int SAVEK = 0, bool ENC = false, bool B16 = false>
 __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs args) {
     using L = Layout<W, NH>;
     using T = TrainLayout<W, NH>;
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                     }
                 }
                 half8 lo, hi;
-                if (la.blend16) {       // (wave-uniform) tcnn's fp16 blend: the sums come out as the packed 16-bit features themselves
+                if (B16) {              // tcnn's fp16 blend: the sums come out as the packed 16-bit features themselves
                     u32x2 r[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) r[q] = hash_blend16(prep[cur][q], v[cur][q]);
@@ -645,13 +647,21 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     a.active_waves = active_waves >= 1 && active_waves <= kWavesPerBlock ? active_waves : kWavesPerBlock;
     a.levels = reinterpret_cast<const LevelMeta *>(reinterpret_cast<const char *>(f->d_frags) + (size_t)f->shape.blocks_total * 1024);
     a.io = io;
-#define MNF_LAUNCH(MODE, DO) hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO>), dim3(grid), dim3(kThreads), 0, stream, a)
+    // the fp16-blend instantiations exist for neurons = 128 (the reference yamls) only: they double the kernels of a shape
+    const bool b16 = f->cfg.blend_fp16 != 0;
+    if (b16 && (W != 128 || io.enc)) { set_error("field: blend_fp16 is built for neurons = 128 (and not for the two-launch diagnostic path)"); return MNF_ERR_UNSUPPORTED; }
+#define MNF_LAUNCH_S(MODE, DO, SAVEK)                                                                                                                  \
+    do {                                                                                                                                               \
+        if constexpr (W == 128) {                                                                                                                      \
+            if (b16) { hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO, SAVEK, false, true>), dim3(grid), dim3(kThreads), 0, stream, a); break; }   \
+        }                                                                                                                                              \
+        hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO, SAVEK, false, false>), dim3(grid), dim3(kThreads), 0, stream, a);                           \
+    } while (0)
+#define MNF_LAUNCH(MODE, DO) MNF_LAUNCH_S(MODE, DO, 0)
     if (train && train->xenc) {
-        if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else hipLaunchKernelGGL((field_kernel<W, NH, 0, false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+        if (io.mode == 1) MNF_LAUNCH_S(1, false, 2); else MNF_LAUNCH_S(0, false, 2);
     } else if (train) {
-        if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else hipLaunchKernelGGL((field_kernel<W, NH, 0, false, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+        if (io.mode == 1) MNF_LAUNCH_S(1, false, 1); else MNF_LAUNCH_S(0, false, 1);
     } else if (io.enc) {
         // two launches: gather at high occupancy, then the register-heavy MLP chain on ready-made fragments
         half8 *enc = reinterpret_cast<half8 *>(const_cast<void *>(io.enc));
@@ -678,6 +688,7 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
         if (io.mode == 0) MNF_LAUNCH(0, false); else if (io.mode == 1) MNF_LAUNCH(1, false); else MNF_LAUNCH(2, false);
     }
 #undef MNF_LAUNCH
+#undef MNF_LAUNCH_S
     return launch_status("field_kernel");
 }
 
@@ -762,6 +773,7 @@ extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
                 "field_create: num_semantic_classes must be 1..32 (got %d)", cfg->num_semantic_classes);
     MNF_REQUIRE(cfg->n_levels == 16 && cfg->n_features == 4, "field_create: only 16 levels x 4 features are supported");
     MNF_REQUIRE(cfg->log2_hashmap_size >= 8 && cfg->log2_hashmap_size <= 24, "field_create: bad log2_hashmap_size");
+    MNF_REQUIRE(!cfg->blend_fp16 || cfg->neurons == 128, "field_create: blend_fp16 is built for neurons = 128 only");
     mnf_field_s *f = new mnf_field_s();
     f->cfg = *cfg;
     grid_levels(*cfg, f->levels, &f->table_entries);

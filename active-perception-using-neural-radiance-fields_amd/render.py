@@ -327,16 +327,16 @@ def _grow_caps(st, marched, kept, R, carry):
         st["abs_m"], st["abs_k"] = max(st["abs_m"], cm), max(st["abs_k"], ck)
         st["per_m"], st["per_k"] = max(st["per_m"], cm / max(R, 1)), max(st["per_k"], ck / max(R, 1))
     else:
-        bm, bk = st["by_R"].get(R, (R * 384, R * 192))
+        bm, bk = st["by_R"].get(R, (max(R * 384, 1 << 18), R * 192))
         st["by_R"][R] = (max(bm, cm), max(bk, ck))
 
 
 def _caps_for(st, R):
     """(max_marched, max_kept) of a call with R rays: generous per-ray defaults, raised by what earlier steps of this field overflowed."""
-    bm, bk = st["by_R"].get(R, (R * 384, R * 192))
-    # (the marched bound has an absolute floor: small batches of the dynamic schedule march ~1000 samples per ray through empty-looking early grids,
-    #  and an asynchronous step cannot be repeated; the surviving bound keeps its per-ray form — the deterministic mode's grouping depends on it)
-    return max(bm, 1 << 18, st["abs_m"], int(st["per_m"] * R)), max(bk, st["abs_k"], int(st["per_k"] * R))
+    # (the default marched bound has an absolute floor: small batches of the dynamic schedule march ~1000 samples per ray through empty-looking early
+    #  grids, and an asynchronous step cannot be repeated; the surviving bound keeps its per-ray form — the deterministic mode's grouping depends on it)
+    bm, bk = st["by_R"].get(R, (max(R * 384, 1 << 18), R * 192))
+    return max(bm, st["abs_m"], int(st["per_m"] * R)), max(bk, st["abs_k"], int(st["per_k"] * R))
 
 
 def _train_state(radiance_field):

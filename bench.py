@@ -437,15 +437,15 @@ def main():
             field_ms, launches = prof("field_render")
             if launches and samples2:
                 achieved = ALGO_BYTES_PER_SAMPLE * samples2 / (field_ms * 1e-3) / 1e9
-                traffic, traffic_note = None, "no PMC profile of this kernel build is committed (profiles/r03_pmc.json)"
-                pj = os.path.join(REPO, "profiles", "r03_pmc.json")
+                traffic, traffic_note = None, "no PMC profile of this kernel build is committed (profiles/r04_pmc.json)"
+                pj = os.path.join(REPO, "profiles", "r04_pmc.json")
                 if os.path.exists(pj):
                     pm = json.load(open(pj))
                     if pm.get("field_sources_md5") == field_source_id():
                         traffic = pm["field_kernel"]["hbm_bytes_per_sample"] * samples2 / launches
-                        traffic_note = "rocprofv3 --pmc passes of this kernel build (profiles/r03_pmc.json: FETCH_SIZE + WRITE_SIZE per evaluated sample), scaled to this run's samples per launch"
+                        traffic_note = "rocprofv3 --pmc passes of this kernel build (profiles/r04_pmc.json: FETCH_SIZE + WRITE_SIZE per evaluated sample), scaled to this run's samples per launch"
                     else:
-                        traffic_note = "profiles/r03_pmc.json was measured on a different build of the kernel sources: not quoted"
+                        traffic_note = "profiles/r04_pmc.json was measured on a different build of the kernel sources: not quoted"
                 line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                     "traffic": traffic, "traffic_source": traffic_note,
                                     "kernel": "mnf::field_kernel<128,2,2,false> (hash gather + MLPs + fused compositing)",
@@ -468,6 +468,22 @@ def main():
                                              "ms_per_step": 1e3 * dtr / args.steps, "views_per_step": V,
                                              "samples_per_ray": sr / (n_per_view * V * args.steps), "samples_per_s": sr * world / dtr,
                                              "note": "synthetic.make_field_params seed 0, procedural occupancy grid: round 1's headline configuration"}
+        if args.weights == "trained" and not args.no_views1 and not args.no_kernel_timing:
+            # the same trained weights evaluated with tiny-cuda-nn's fp16 hash blend (mnf_field_config.blend_fp16): never the headline
+            bfield = SC.hip_field(scene529, dev, tcnn_blend_fp16=True)
+            bfield.load_state_dict(field.state_dict())
+            rfield = bfield.eval()
+            dtb, sb = render_pass(V, args.steps, 2, False, n_split=args.render_jobs)
+            dtb2, sb2 = render_pass(V, args.steps, 1, True, n_split=1)
+            bms, bl = prof("field_render")
+            rfield = field
+            line["render_blend_fp16"] = {"value": n_per_view * V * world * args.steps / dtb, "unit": "rays/s", "ms_per_step": 1e3 * dtb / args.steps,
+                                         "samples_per_ray": sb / (n_per_view * V * args.steps), "samples_per_s": sb * world / dtb,
+                                         "field_kernel_avg_launch_ms": bms / max(bl, 1), "field_kernel_samples_per_launch": sb2 / max(bl, 1),
+                                         "field_kernel_frac_of_hbm_peak": ALGO_BYTES_PER_SAMPLE * sb2 / max(bms * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBS,
+                                         "note": "the headline scene and weights with the hash levels' 8-corner blend as fp16 fused multiply-adds "
+                                                 "(tcnn's T = __half arithmetic as published); the stand-in was trained with the fp32 blend, so the sample "
+                                                 "counts differ slightly"}
         line["samples"] = {"timed": int(samples), "process_total": int(process_samples.item())}
         del rays
 

@@ -24,7 +24,7 @@ modes = [bool(int(x)) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else
 bwd_mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0        # mnf_field_set_backward_mode: 0 auto (fused where supported), 1 split kernels, 2 fused
 dev = "cuda:0"
 scene = SC.make_scene("102344280", n_poses=40)
-field, est, info = SI.train_standin(scene, dev, seed=9)      # the stand-in of bench.py's train legs
+field, est, info = SI.train_standin(scene, dev, seed=11)     # the stand-in of bench.py's train legs
 print("[exp_train] stand-in:", {k: v for k, v in info.items() if k != "optimizer_state"}, flush=True)
 if dtype == "bf16":
     f2 = SC.hip_field(scene, dev, mfma_bf16=True)
@@ -58,12 +58,12 @@ for R in shapes:
         outs = []
         for i in range(5):
             r, pix, dep_, lab = bs[i % 8]
-            RD.train_step(field, est, opt, r, pix, dep_, lab, bk, step=1001 + i, sync=sync, **SC.RENDER_KW)
+            RD.train_step(field, est, opt, r, pix, dep_, lab, bk, step=1001 + i, sync=sync, occ_thre=1e-2, **SC.RENDER_KW)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             r, pix, dep_, lab = bs[i % 8]
-            outs.append(RD.train_step(field, est, opt, r, pix, dep_, lab, bk, step=1001 + i, sync=sync, **SC.RENDER_KW))
+            outs.append(RD.train_step(field, est, opt, r, pix, dep_, lab, bk, step=1001 + i, sync=sync, occ_thre=1e-2, **SC.RENDER_KW))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         kept = np.mean([int(o["n_rendering_samples"]) for o in outs])
