@@ -8,6 +8,7 @@ edits:  none     re-assemble unchanged (control: must still fail)
         vmcnt    s_waitcnt vmcnt(0) in front of it (the gathers that used the pair as their scalar base have completed)
         warfix   s_waitcnt vmcnt(0) in front of every scalar write that overwrites the scalar base of a vector-memory instruction issued just before
         warnop   16 wait states there instead
+        after1 / after4   s_nop 1 / s_nop 7 AFTER every v_pk_{mul,fma,add}_f32 (round 4: the multi-pass-producer hypothesis)
         moved    the scale load (s_load_dword sN) redirected to a free register pair s[98:99] (the packed fma reads that pair): the pair
                  the in-flight gathers use as scalar base is no longer overwritten
 """
@@ -54,7 +55,7 @@ for i, line in enumerate(asm):
             raise SystemExit(f"no scale load found for s{s0} near line {i}")
         # every later reader of s{s0} up to the next write of it keeps reading the scale: copy it back AFTER the packed instruction
         out += [line.replace(f"s[{s0}:{s1}]", "s[98:99]"), f"\ts_mov_b32 s{s0}, s98"]
-    elif edit in ("warfix", "warnop"):
+    elif edit in ("warfix", "warnop", "after1", "after4"):
         out.append(line)
     else:
         raise SystemExit("unknown edit")
@@ -79,6 +80,16 @@ if edit in ("split2", "split3"):
             out += [f"\tv_sub_f32_e32 v{d0}, v{a0}, v{b0}", f"\tv_sub_f32_e32 v{d1}, v{a1}, v{b1}"]
             n += 1; continue
         out.append(line)
+if edit in ("after1", "after4"):
+    # VERDICT r03 next 7, the multi-pass-producer hypothesis: a packed-fp32 instruction takes several passes over the 64 lanes (the fault sits in lanes
+    # 48..63, the last 16-lane pass), and both sightings are a VALU consumer right behind such a producer.  Wait states AFTER every v_pk_{mul,fma,add}_f32
+    # (not in front of the consumer): after1 = s_nop 1 (2 wait states), after4 = s_nop 7 (8).
+    src, out, n = out, [], 0
+    for line in src:
+        out.append(line)
+        if re.match(r"^\s*v_pk_(mul|fma|add)_f32 ", line):
+            out.append("\ts_nop 1" if edit == "after1" else "\ts_nop 7")
+            n += 1
 if edit in ("warfix", "warnop"):
     # every scalar write (SMEM load or SALU) whose destination overlaps the scalar base (saddr) of a vector-memory instruction issued within
     # the 16 instructions before it: warfix = wait until those vector-memory instructions have COMPLETED (s_waitcnt vmcnt(0)) first;
