@@ -8,6 +8,7 @@ edits:  none     re-assemble unchanged (control: must still fail)
         vmcnt    s_waitcnt vmcnt(0) in front of it (the gathers that used the pair as their scalar base have completed)
         warfix   s_waitcnt vmcnt(0) in front of every scalar write that overwrites the scalar base of a vector-memory instruction issued just before
         warnop   16 wait states there instead
+        vwar / vwarnop    s_waitcnt vmcnt(0) / 16 wait states in front of every vector instruction that overwrites the VGPR address of a global_load issued just before
         after1 / after4   s_nop 1 / s_nop 7 AFTER every v_pk_{mul,fma,add}_f32 (round 4: the multi-pass-producer hypothesis)
         moved    the scale load (s_load_dword sN) redirected to a free register pair s[98:99] (the packed fma reads that pair): the pair
                  the in-flight gathers use as scalar base is no longer overwritten
@@ -55,7 +56,7 @@ for i, line in enumerate(asm):
             raise SystemExit(f"no scale load found for s{s0} near line {i}")
         # every later reader of s{s0} up to the next write of it keeps reading the scale: copy it back AFTER the packed instruction
         out += [line.replace(f"s[{s0}:{s1}]", "s[98:99]"), f"\ts_mov_b32 s{s0}, s98"]
-    elif edit in ("warfix", "warnop", "after1", "after4"):
+    elif edit in ("warfix", "warnop", "after1", "after4", "vwar", "vwarnop"):
         out.append(line)
     else:
         raise SystemExit("unknown edit")
@@ -90,6 +91,34 @@ if edit in ("after1", "after4"):
         if re.match(r"^\s*v_pk_(mul|fma|add)_f32 ", line):
             out.append("\ts_nop 1" if edit == "after1" else "\ts_nop 7")
             n += 1
+if edit in ("vwar", "vwarnop"):
+    # Round 4, after the priority experiment (no s_setprio: no fault): is it a write-after-read on the VECTOR address of a gather?  A vector instruction
+    # that overwrites a VGPR which a global_load issued in the 24 instructions before it uses as its address (voffset): vwar = wait until those loads have
+    # completed first (s_waitcnt vmcnt(0)); vwarnop = 16 wait states instead.
+    def vregs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+    src, out, recent, n = out, [], [], 0
+    for line in src:
+        t = line.replace(",", " ").split()
+        if t and not t[0].startswith((";", ".")) and not t[0].endswith(":"):
+            op = t[0]
+            if op.startswith("global_load"):
+                addr = vregs(t[2]) if len(t) > 2 else set()          # global_load_dwordx2 vdst, vaddr, saddr
+                recent = (recent + [(len(out), addr)])[-32:]
+            elif op.startswith(("v_", "ds_read", "ds_bpermute")) and len(t) > 1:
+                dst = vregs(t[1])
+                if op.startswith(("v_cmp", "v_cmpx")):
+                    dst = set()
+                if any(dst & addr and len(out) - j <= 24 for j, addr in recent):
+                    out.append("\ts_waitcnt vmcnt(0)" if edit == "vwar" else "\ts_nop 7\n\ts_nop 7")
+                    n += 1
+                    if edit == "vwar":
+                        recent = []
+        out.append(line)
 if edit in ("warfix", "warnop"):
     # every scalar write (SMEM load or SALU) whose destination overlaps the scalar base (saddr) of a vector-memory instruction issued within
     # the 16 instructions before it: warfix = wait until those vector-memory instructions have COMPLETED (s_waitcnt vmcnt(0)) first;
