@@ -130,6 +130,8 @@ struct ScratchSink {
     __device__ __forceinline__ void sample(float t_last, float t_next, bool, int32_t k) {
 #if MNF_SAMPLER_EXP == 1
         if (k == 0x7fffffff) { ts[0] = t_last; te[0] = t_next; }
+#elif MNF_SAMPLER_EXP == 2
+        if (k < cap) *reinterpret_cast<float2 *>(ts + 2 * (k & 0x3ff)) = float2{t_last, t_next};     /* one 8-byte store per sample (layout experiment: results invalid) */
 #else
         if (k < cap) { ts[k] = t_last; te[k] = t_next; }
 #endif
@@ -167,6 +169,9 @@ __global__ void __launch_bounds__(MNF_SAMPLER_THREADS) sample_rays_kernel(int32_
         __syncthreads();
     }
     const float *ab = boxes.ab[0];
+#if MNF_SAMPLER_EXP == 3
+    if (n_rays > 0) { for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)blockDim.x * gridDim.x) counts[r] = s_bits[r & 1023] & 1; return; }   /* staging only */
+#endif
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)blockDim.x * gridDim.x) {
         const F3 org = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
         const F3 dir = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};

@@ -49,6 +49,9 @@ __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min
 // (dt below half an ulp of t_last, or NaN) — it protects the GPU from a hang.
 __device__ __forceinline__ void skip_to(float &t_last, float dt, float target) {
     const float hd = dt * 0.5f;
+#if defined(MNF_SAMPLER_EXP) && MNF_SAMPLER_EXP == 4
+    t_last = target - hd; return;          /* timing experiment: no empty-space stepping (results invalid) */
+#endif
     if (t_last >= 0.0f && target + dt > target) {
         // dt still moves `target`, so it moves every smaller non-negative t as well: the hang guard cannot fire inside this skip and
         // the loop is one add, one compare and one exit per step (same t sequence, same exit test)

@@ -27,8 +27,11 @@ _WORKSPACES = {}
 
 
 def _workspace(key, nbytes: int) -> torch.Tensor:
-    """Cached scratch buffer; `key` is a device or (device, slot) — concurrent render jobs of one call use one slot each."""
+    """Cached scratch buffer; `key` is a device or (device, slot) — concurrent render jobs of one call use one slot each.  The buffer belongs to the
+    (device, slot) AND the stream the caller enqueues on: two members of an ensemble trained or rendered side by side on two streams must not share
+    scratch (round 4: they did, silently, through the per-device cache)."""
     device = key[0] if isinstance(key, tuple) else key
+    key = (key, torch.cuda.current_stream(device).cuda_stream) if torch.device(device).type == "cuda" else key
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
         _WORKSPACES[key] = ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -567,6 +570,50 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
         return dict(loss=None, n_rendering_samples=0, skipped=True)
     return dict(loss=loss.detach(), loss_rgb=loss_rgb.detach(), loss_dep=loss_dep.detach(), loss_sem=loss_sem.detach(),
                 n_rendering_samples=n_rendering_samples, skipped=skipped)
+
+
+_ENSEMBLE_STREAMS = {}
+
+
+def ensemble_streams(device, n: int):
+    """The streams an ensemble's members train on: the caller's current stream for member 0, one cached extra stream per further member (created
+    once per device and kept: the platform dislikes processes that keep creating streams)."""
+    device = torch.device(device)
+    extra = _ENSEMBLE_STREAMS.setdefault(device, [])
+    while len(extra) < n - 1:
+        extra.append(torch.cuda.Stream(device))
+    return [torch.cuda.current_stream(device)] + extra[:max(n - 1, 0)]
+
+
+def train_step_ensemble(members, batches, step: int, **kw):
+    """One iteration of the reference's ensemble (scripts/pipeline.py:398-412 trains the members ONE AFTER THE OTHER inside every iteration; they are
+    independent models): every member's `train_step(sync=False)` is enqueued on a stream of its own, so that the latency-bound phases of one member's
+    step (the ray marcher, the small launches, the tail of each kernel) run beside the other member's kernels — at the reference yaml's 2000 rays a
+    single step cannot fill 256 compute units (measured: 1.55 -> 1.15 ms per member step with two members, profiles/r04_exp_ensemble.txt).
+    `members`: list of (radiance_field, estimator, optimizer[, scheduler]) with `optim.FusedAdam` optimizers (the skip decision is taken on the device);
+    `batches`: one (rays, pixels, dep, sem, render_bkgd) per member.  Inputs may have been produced on the caller's stream; on return the caller's stream
+    waits for every member.  Results are those of the members stepped one after the other (they share nothing).  Returns the members' result dicts."""
+    assert len(members) == len(batches) and len(members) >= 1
+    dev = batches[0][0].origins.device
+    streams = ensemble_streams(dev, len(members))
+    cur = streams[0]
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    outs = []
+    for m, (member, (rays, pixels, dep, sem, bkgd)) in enumerate(zip(members, batches)):
+        field, est, opt = member[:3]
+        sched = member[3] if len(member) > 3 else None
+        s_ = streams[m]
+        if m:
+            s_.wait_event(ready)                       # whatever produced this member's inputs on the caller's stream comes first
+            for t in (rays.origins, rays.viewdirs, pixels, dep, sem, bkgd):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(s_)                 # the caching allocator must not hand the inputs' memory out again before this stream has read it
+        with torch.cuda.stream(s_):
+            outs.append(train_step(field, est, opt, rays, pixels, dep, sem, bkgd, step=step, scheduler=sched, sync=False, **kw))
+    for s_ in streams[1:]:
+        cur.wait_stream(s_)
+    return outs
 
 
 # ------------------------------------------------------------------ habitat_to_data.py

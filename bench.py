@@ -40,6 +40,7 @@ analytic target built from the procedural occupancy grid — bitwise reproducibl
 accumulation), so the scenes are the same on every box.  `--workload` restricts the run to one part.
 """
 import argparse
+import gc
 import ctypes
 import hashlib
 import json
@@ -345,12 +346,18 @@ def main():
         """W warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides -> seconds (max over ranks)."""
         for i in range(warmup):
             step_fn(i)
+        # Objects of earlier legs that sit in reference cycles (a torch optimizer and the field bound to it) are destroyed whenever Python's cycle
+        # collector happens to run — `mnf_field_destroy` is a dozen `hipFree` calls, each of which waits for the device: inside a timed region that drains
+        # the asynchronous pipeline.  This is what the sporadic 1.7-2x slow train legs were (profiles/r03_bench_line.json bf16 6.81 ms, a round-4 run
+        # 8.20 ms f16 right behind the in-process stand-in training, per-kernel times normal both times): collect before the region, not inside it.
+        gc.collect()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         if with_events:
             L.check(lib.mnf_profile_begin())
+        gc.disable()
         t0 = time.perf_counter()
         for i in range(steps):
             r = step_fn(warmup + i)
@@ -361,6 +368,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        gc.enable()
         if with_events:
             ms, n = ctypes.c_double(0), ctypes.c_int64(0)
             L.check(lib.mnf_profile_end(ctypes.byref(ms), ctypes.byref(n)))
@@ -599,6 +607,44 @@ def main():
                 res["instrumented_step_ms"] = 1e3 * dt_e / steps
             return res
 
+        def ensemble_leg(R_, steps):
+            """Two ensemble members (the reference trains an ensemble of two, one member after the other inside every iteration: pipeline.py:398-412) stepped in turn on one
+            stream and side by side on one stream each (`render.train_step_ensemble`): ms per iteration (= one step of each member) and per member step.  Both members start
+            from the stand-in's state (the second stand-in would cost another 12 s of the bench; the timing does not depend on the weights being different)."""
+            from apnrf_amd.nerfacc import OccGridEstimator
+            import copy
+            mem = []
+            for _ in range(2):
+                tf = SC.hip_field(scene280, dev)
+                tf.load_state_dict(tfield0.state_dict())
+                te = OccGridEstimator(torch.from_numpy(scene280["aabb"]), resolution=scene280["res"], levels=1).to(dev)
+                te.occs.copy_(test0.occs); te.binaries = test0.binaries.clone()
+                tf.train(); te.train()
+                opt = FusedAdam(tf.parameters(), lr=2e-4, eps=1e-15).bind_field(tf)
+                if opt_states.get("102344280") is not None:
+                    opt.load_state_dict(copy.deepcopy(opt_states["102344280"]))
+                    for g_ in opt.param_groups:
+                        g_["lr"] = 2e-4
+                mem.append((tf, te, opt))
+            batches = make_batches(R_)
+            bkd = torch.rand(3, generator=torch.Generator().manual_seed(7)).to(dev)
+            res = {"rays_per_member_step": R_, "members": 2, "steps": steps}
+
+            def turn(i):
+                return [RD.train_step(tf, te, opt, *((batches[(i + 3 * m) % 8][0],) + tuple(batches[(i + 3 * m) % 8][1:])), bkd, step=1000 + i, sync=False, occ_thre=1e-2, **SC.RENDER_KW)
+                        for m, (tf, te, opt) in enumerate(mem)]
+
+            def side(i):
+                return RD.train_step_ensemble(mem, [tuple(batches[(i + 3 * m) % 8]) + (bkd,) for m in range(2)], step=1000 + i, occ_thre=1e-2, **SC.RENDER_KW)
+            for label, fn in (("one_stream", turn), ("stream_per_member", side)):
+                outs = []
+                dt_e = timed(fn, steps, 6, False, outs.append)
+                res[label] = {"ms_per_iteration": 1e3 * dt_e / steps, "ms_per_member_step": 1e3 * dt_e / steps / 2,
+                              "rendering_samples_per_member_step": float(np.mean([int(o["n_rendering_samples"]) for pair in outs for o in pair])),
+                              "skipped_steps": int(sum(int(o["skipped"]) for pair in outs for o in pair))}
+            res["speedup"] = res["one_stream"]["ms_per_iteration"] / res["stream_per_member"]["ms_per_iteration"]
+            return res
+
         tsteps = max(args.steps, 10)
         dtypes = [d for d in args.train_dtypes.split(",") if d in ("f16", "bf16")]
         train = {"workload": "BASELINE config 5: scene 102344280 (trained stand-in, training continued from the same state in every leg), 8192-ray batches "
@@ -626,6 +672,9 @@ def main():
         line["train"] = train
         line["train_refyaml"] = ry
         line["train_dynamic"] = dy
+        line["train_ensemble2"] = {"workload": "an ensemble of two members (the reference's), both stepped in every iteration: in turn on one stream (the reference's loop) and side by side, "
+                                               "one stream per member (render.train_step_ensemble); asynchronous steps, same scene and start state as the train legs",
+                                   "refyaml_2000_rays": ensemble_leg(2000, max(tsteps, 20)), "config5_8192_rays": ensemble_leg(args.train_rays, tsteps)}
         if not want("render800"):
             line.update({"metric": "train-step ms", "value": train["ms_per_step"], "unit": "ms", "higher_is_better": False,
                          "ms_per_step": train["ms_per_step"], "dtype": dtypes[0]})

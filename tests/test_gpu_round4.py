@@ -269,3 +269,47 @@ def test_field_fp16_blend_matches_its_oracle_and_differs_from_fp32_blend_as_expe
     # the two precisions are close to each other as well (features differ by fp16 rounding of the running sum): within 4x the bars
     x = worst(outs["f16"], refs["f32"])
     assert x[0] < 4e-3 * tol and x[1] < 1e-2 * tol and x[2] < 6e-3 * tol, x
+
+
+def test_ensemble_members_on_their_own_streams_equal_sequential_steps():
+    """`render.train_step_ensemble`: the members of an ensemble (pipeline.py:398-412 trains them one after the other) stepped side by side on one stream each give what
+    stepping them in turn gives — same sample counts, same losses, parameters within float-atomics noise — and they do not share scratch (round 4: the cached workspace is
+    per stream; with one per device two concurrent steps overwrote each other's samples)."""
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene(log2_hashmap_size=15)
+    bk = torch.tensor([0.3, 0.6, 0.1], device=DEV)
+    data = []
+    for m in range(2):
+        o, d = H.view_rays(sc, 1 + m, h=40, w=40)
+        rng = np.random.default_rng(50 + m)
+        n = o.shape[0]
+        data.append((RD.Rays(o.to(DEV), d.to(DEV)), torch.from_numpy(rng.random((n, 3)).astype(np.float32)).to(DEV),
+                     torch.from_numpy(rng.uniform(0.5, 4.0, n).astype(np.float32)).to(DEV), torch.from_numpy(rng.integers(0, sc["C"], n)).to(DEV), bk))
+
+    def run(concurrent):
+        torch.manual_seed(5)
+        mem = []
+        for m in range(2):
+            scm = H.make_scene(log2_hashmap_size=15, seed=m)
+            f, e = H.hip_field(scm).train(), H.hip_estimator(scm)
+            mem.append((f, e, FusedAdam(f.parameters(), lr=1e-3, eps=1e-15).bind_field(f)))
+        hist = []
+        for it in range(1, 7):
+            if concurrent:
+                outs = RD.train_step_ensemble(mem, data, step=it, stratified=False, **H.RENDER_KW)
+            else:
+                outs = [RD.train_step(f, e, o, *b, step=it, sync=False, stratified=False, **H.RENDER_KW) for (f, e, o), b in zip(mem, data)]
+            hist.append(outs)
+        torch.cuda.synchronize()
+        return ([[int(o["n_rendering_samples"]) for o in outs] for outs in hist], [[float(o["loss"]) for o in outs] for outs in hist],
+                [[int(o["skipped"]) for o in outs] for outs in hist], [[p.detach().clone() for p in f.parameters() if p.numel()] for f, _, _ in mem])
+    n_a, l_a, s_a, p_a = run(False)
+    n_b, l_b, s_b, p_b = run(True)
+    assert n_a[0] == n_b[0] and min(n_a[0]) > 3000 and s_a == s_b and not any(any(x) for x in s_a)
+    assert all(abs(x - y) <= max(3, 2e-3 * x) for ra, rb in zip(n_a, n_b) for x, y in zip(ra, rb))
+    np.testing.assert_allclose(l_b, l_a, rtol=2e-3)
+    for pa, pb in zip(p_a, p_b):
+        for a, b in zip(pa, pb):
+            assert torch.nn.functional.cosine_similarity(a, b, dim=0) > 0.9999
+    assert len(RD._ENSEMBLE_STREAMS[torch.device(DEV)]) == 1                    # one extra stream, cached

@@ -16,7 +16,10 @@ from apnrf_amd import render as RD, scenes as SC, standin as SI
 
 dev = "cuda:0"
 scene = SC.make_scene("102344280", n_poses=40)
-field, est, info = SI.train_standin(scene, dev, seed=9)
+if len(sys.argv) > 1 and sys.argv[1] == "proc":      # procedural occupancy grid, no training (experiment builds whose sampler is not usable for training)
+    est = SC.hip_estimator(scene, dev)
+else:
+    field, est, info = SI.train_standin(scene, dev, seed=11)
 lib = L.load_library()
 c2w = np.stack([RD.pose_to_c2w(p) for p in scene["poses"][:8]]).astype(np.float32)
 K6 = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
