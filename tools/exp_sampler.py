@@ -36,6 +36,12 @@ for R in (8192, 2000):
     cap = int(max(64, min(2048, (1 << 27) // R)))
     scratch = torch.empty((2, R, cap), device=dev); counts = torch.empty((R,), device=dev, dtype=torch.int64)
     o, d = r.origins.contiguous(), r.viewdirs.contiguous()
+    if "same" in sys.argv:        # every lane marches the ray with the most samples: no divergence, the kernel's time is ONE ray's dependent chain
+        call_counts = torch.empty((R,), device=dev, dtype=torch.int64)
+        L.launch(lib.mnf_sample_rays_levels, L.ptr(o), L.ptr(d), R, L.ptr(b), 1, res[0], res[1], res[2], aabb_host, L.ptr(near), L.ptr(far), 1e-3, 0.004, cap,
+                 L.ptr(scratch[0]), L.ptr(scratch[1]), L.ptr(call_counts), L.ptr(est.bitgrid()[0]))
+        k = int(call_counts.argmax())
+        o, d = o[k:k + 1].repeat(R, 1).contiguous(), d[k:k + 1].repeat(R, 1).contiguous()
 
     def call():
         L.launch(lib.mnf_sample_rays_levels, L.ptr(o), L.ptr(d), R, L.ptr(b), 1, res[0], res[1], res[2], aabb_host, L.ptr(near), L.ptr(far), 1e-3, 0.004, cap,
