@@ -14,7 +14,7 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("layers,bf16,n", [(2, False, 5000), (1, False, 777), (2, True, 4097)])
+@pytest.mark.parametrize("layers,bf16,n", [(2, False, 5000), (1, False, 777), (2, True, 4097), (2, False, 300000)])   # (300 000: the split path runs its backward in two tile ranges)
 def test_fused_backward_matches_split_kernels(layers, bf16, n):
     """mode 2 (one kernel: forward recompute + backward-data + weight gradients, no activation dump) and mode 1 (dgrad + wgrad over the dump)
     are the same arithmetic — 16-bit operands rounded at the same points, fp32 accumulation — in a different summation order: every parameter
