@@ -28,6 +28,17 @@
 
 constexpr int kFusedThreads = 256;
 
+// Phase stamps of workgroup 0 (experiment builds with -DMNF_FUSED_STAMPS only: tools/exp_fused_stamps.py): shader clock at tile start and on both sides of every barrier
+#ifdef MNF_FUSED_STAMPS
+constexpr int kStampTiles = 24, kStampSlots = 24;
+__device__ unsigned long long g_fused_stamps[kStampTiles * 4 * kStampSlots];
+#define MNF_STAMP(k) do { if (blockIdx.x == 0 && lane == 0 && stamp_it < kStampTiles) g_fused_stamps[(stamp_it * 4 + q) * kStampSlots + (k)] = __builtin_readcyclecounter(); } while (0)
+#define MNF_SYNC(k) do { MNF_STAMP(2 * (k) - 1); __syncthreads(); MNF_STAMP(2 * (k)); } while (0)
+#else
+#define MNF_STAMP(k) do { } while (0)
+#define MNF_SYNC(k) __syncthreads()
+#endif
+
 struct FusedBwdArgs {
     const half8 *frags;      // forward fragment table (Layout<128, NH>)
     const half8 *fragsT;     // transposed fragment table (LayoutT<128, NH>)
@@ -41,6 +52,7 @@ struct FusedBwdArgs {
     const int64_t *n_dev;
     int C, out_fp16;
     float loss_scale;
+    int chunk, n_chunks;     // this launch covers tile range `chunk` of `n_chunks` (chunk_tiles)
 };
 
 __device__ __forceinline__ half8 pack8(const f32x16 &acc, int s) {
@@ -138,13 +150,17 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
     __shared__ half8 s_e[2][16 * 64];                   // chain (F) exchange, two buffers: block ks * 2 + ct (base), head * 8 + ks * 2 + ct (heads)
     __shared__ half8 s_sd[16 * 64];                     // packed backward S tiles: block nt * 4 + ct * 2 + s (base), (head * 2 + nt) * 4 + ct * 2 + s (heads)
     __shared__ float s_g[2 * 2 * 8 * 64];               // geo-feature gradients of the two heads: ((head * 2 + ct) * 8 + i) * 64 + lane
+    __shared__ half_t s_dyr[64 * 4];                    // the tile's rgb output gradient (through the sigmoid, loss-scaled): [sample][4], slot 3 stays 0
+    __shared__ float s_dl[64];                          // ... and its density-logit gradient
+    half_t *s_dys = reinterpret_cast<half_t *>(s_g);    // ... and its semantic output gradient [sample][32 padded classes]: lives in s_g's first 4 KB between barrier 1 and barrier 4
 
     const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform, and the compiler knows it)
     const int r = lane & 31, h = lane >> 5;
     const int head = q >> 1, e = q & 1;                 // waves 0, 1: rgb head; 2, 3: semantic head; e: the 32-feature tile of the 64 head neurons
     const int64_t n = count_here(args.n, args.n_dev);
-    const int64_t n_tiles = (n + kWaveSamples - 1) / kWaveSamples;
-    if ((int64_t)blockIdx.x >= n_tiles) return;
+    int64_t tile0, n_tiles;                             // [tile0, n_tiles): this launch's range of 64-sample tiles
+    chunk_tiles(n, args.chunk, args.n_chunks, tile0, n_tiles);
+    if (tile0 + (int64_t)blockIdx.x >= n_tiles) return;
     for (int i = threadIdx.x; i < kFwdBlocks * 64; i += kFusedThreads) s_w[i] = args.frags[i < L::o_h_out * 64 ? i : i + kHeadOut * 64];
     for (int i = threadIdx.x; i < 24 * 64; i += kFusedThreads) {
         const int b = i >> 6;
@@ -168,11 +184,47 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) a_hid[l][nt][i] = 0.f;
     }
+    s_dyr[threadIdx.x] = (half_t)0.0f;
     __syncthreads();
     const float ls = args.loss_scale;
     const int C = args.C;
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#ifdef MNF_FUSED_STAMPS
+    int stamp_it = -1;
+#endif
+    for (int64_t tile = tile0 + blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#ifdef MNF_FUSED_STAMPS
+        ++stamp_it;
+#endif
+        MNF_STAMP(0);
+        // The tile's output gradients: coalesced loads by the whole workgroup here (consecutive lanes = consecutive floats of [N,C] / [N,3] / [N]), staged to
+        // LDS behind the first barrier.  (Loaded where they are used, fragment-shaped — 16 predicated 4-byte loads per lane at a 116-byte lane stride, by both
+        // waves of the semantic head — this was 31 % of the tile: tools/exp_fused_stamps.py.)
+        float pre_sem[8], pre_o;
+        {
+            const int t = threadIdx.x;
+            const int64_t s0 = tile * kWaveSamples;
+            const int cls = t & 31;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t smp = s0 + (t >> 5) + 8 * k;
+                const bool ok = cls < C && smp < n;
+                pre_sem[k] = 0.0f;
+                if (C > 0) { const float v = args.d_sem[ok ? smp * C + cls : 0]; pre_sem[k] = ok ? v : 0.0f; }
+            }
+            if (t < 192) {
+                const int64_t gi = s0 * 3 + t;
+                const bool ok = gi < 3 * n;
+                const float y = args.rgb[ok ? gi : 0], d = args.d_rgb[ok ? gi : 0];
+                pre_o = ok ? d * y * (1.0f - y) * ls : 0.0f;                                      // sigmoid'
+            } else {
+                // trunc_exp backward (ngp.py:34-39): g * exp(min(x, 15)) with exp(x) = sigma (0 outside the aabb)
+                const int64_t col = s0 + (t - 192);
+                const bool ok = col < n;
+                const float sg = args.sigma[ok ? col : 0], d = args.d_sigma[ok ? col : 0];
+                pre_o = ok ? d * fminf(sg, 3269017.3724721107f) * ls : 0.0f;
+            }
+        }
         const half8 *enct = args.enc + tile * (kEncBlocks * 64);      // this tile's encoded inputs (uniform)
         const half8 *ft = args.fragsT;
         asm volatile("" : "+s"(ft));                                   // keep the table's address arithmetic inside the loop (scalar, cheap)
@@ -189,52 +241,61 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) xb[ct][ks] = ldg_block(enct, ks * 2 + ct, lane);
-            f32x16 aF[CT], aS[CT];
-            zero2(aF); zero2(aS);
+            half8 wa[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const half8 a = s_w[(L::o_b_in + q * 4 + ks) * 64 + lane];
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) { aF[ct] = mfma(a, xb[ct][ks], aF[ct]); aS[ct] = mfma(xb[ct][ks], a, aS[ct]); }
-            }
+            for (int ks = 0; ks < 4; ++ks) wa[ks] = s_w[(L::o_b_in + q * 4 + ks) * 64 + lane];
             uint32_t m = 0;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x16 aF, aS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { aF[i] = 0.0f; aS[i] = 0.0f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { aF = mfma(wa[ks], xb[ct][ks], aF); aS = mfma(xb[ct][ks], wa[ks], aS); }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const half8 f = relu_pack8(aF[ct], s);
+                    const half8 f = relu_pack8(aF, s);
                     s_e[0][((2 * q + s) * 2 + ct) * 64 + lane] = f;
                     m |= (uint32_t)frag_mask(f) << (8 * (ct * 2 + s));
-                    hS[0][ct][s] = relu_pack8(aS[ct], s);
+                    hS[0][ct][s] = relu_pack8(aS, s);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             mF[0] = m;
         }
-        __syncthreads();
+        MNF_SYNC(1);
+        {   // (every wave is past the previous tile's last read of s_g)
+            const int t = threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_dys[((t >> 5) + 8 * k) * 32 + (t & 31)] = sat_half(pre_sem[k] * ls);
+            if (t < 192) s_dyr[(t / 3) * 4 + (t % 3)] = sat_half(pre_o);
+            else s_dl[t - 192] = pre_o;
+        }
 #pragma unroll
         for (int l = 1; l < NH; ++l) {          // hidden layers: read buffer (l - 1) & 1, write l & 1
-            f32x16 aF[CT], aS[CT];
-            zero2(aF); zero2(aS);
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const half8 a = s_w[(L::o_b_hid + (l - 1) * 32 + q * 8 + ks) * 64 + lane];
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const half8 b = s_e[(l - 1) & 1][(ks * 2 + ct) * 64 + lane];
-                    aF[ct] = mfma(a, b, aF[ct]); aS[ct] = mfma(b, a, aS[ct]);
-                }
-            }
             uint32_t m = 0;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct) {       // one 32-column tile at a time: two accumulator tiles live instead of four (register pressure)
+                f32x16 aF, aS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { aF[i] = 0.0f; aS[i] = 0.0f; }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const half8 a = s_w[(L::o_b_hid + (l - 1) * 32 + q * 8 + ks) * 64 + lane];
+                    const half8 b = s_e[(l - 1) & 1][(ks * 2 + ct) * 64 + lane];
+                    aF = mfma(a, b, aF); aS = mfma(b, a, aS);
+                }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const half8 f = relu_pack8(aF[ct], s);
+                    const half8 f = relu_pack8(aF, s);
                     s_e[l & 1][((2 * q + s) * 2 + ct) * 64 + lane] = f;
                     m |= (uint32_t)frag_mask(f) << (8 * (ct * 2 + s));
-                    hS[l][ct][s] = relu_pack8(aS[ct], s);
+                    hS[l][ct][s] = relu_pack8(aS, s);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             mF[l] = m;
-            __syncthreads();
+            MNF_SYNC(2);
         }
         constexpr int LB = (NH - 1) & 1;        // buffer that holds the last base activation
         // base output (every wave: 16 rows): geo fragment with tcnn's 1.0 pad in the density slot
@@ -287,63 +348,52 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
                 }
             mH1 = m;
         }
-        __syncthreads();
+        MNF_SYNC(3);
         {
-            f32x16 aF[CT], aS[CT];
-            zero2(aF); zero2(aS);
             const int wbase = (head == 0 ? L::o_h_hid : oS_hid) + e * 4;
+            half8 wa[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const half8 a = s_w[(wbase + ks) * 64 + lane];
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const half8 b = s_e[LB ^ 1][(head * 8 + ks * 2 + ct) * 64 + lane];
-                    aF[ct] = mfma(a, b, aF[ct]); aS[ct] = mfma(b, a, aS[ct]);
-                }
-            }
+            for (int ks = 0; ks < 4; ++ks) wa[ks] = s_w[(wbase + ks) * 64 + lane];
             uint32_t m = 0;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x16 aF, aS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { aF[i] = 0.0f; aS[i] = 0.0f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const half8 b = s_e[LB ^ 1][(head * 8 + ks * 2 + ct) * 64 + lane];
+                    aF = mfma(wa[ks], b, aF); aS = mfma(b, wa[ks], aS);
+                }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    m |= (uint32_t)frag_mask(relu_pack8(aF[ct], s)) << (8 * (ct * 2 + s));
-                    h2S[ct][s] = relu_pack8(aS[ct], s);
+                    m |= (uint32_t)frag_mask(relu_pack8(aF, s)) << (8 * (ct * 2 + s));
+                    h2S[ct][s] = relu_pack8(aS, s);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             mH2 = m;
         }
 
         // =============================================================== backward
         const int64_t fcol0 = tile * kWaveSamples + rl;
-        // output-layer gradients as natural-order F fragments (rgb pair: 1 k-step, semantic pair: 2), and the density-logit gradient
+        // output-layer gradients as natural-order F fragments (rgb pair: 1 k-step, semantic pair: 2), from the staged copies
         half8 dyF[CT][2];
-        float dlogit[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int64_t col = fcol0 + 32 * ct;
-            const bool ok = col < n;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dyF[ct][s][j] = (half_t)0.0f;
             if (head == 0) {
-                if (ok && hl == 0) {
+                if (hl == 0) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float y = args.rgb[3 * col + k];
-                        dyF[ct][0][k] = sat_half(args.d_rgb[3 * col + k] * y * (1.0f - y) * ls);      // sigmoid'
-                    }
+                    for (int k = 0; k < 4; ++k) dyF[ct][0][k] = s_dyr[(rl + 32 * ct) * 4 + k];
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int row = 16 * s + 8 * hl + j;
-                        if (ok && row < C) dyF[ct][s][j] = sat_half(args.d_sem[col * C + row] * ls);
-                    }
+                for (int s = 0; s < 2; ++s) dyF[ct][s] = *reinterpret_cast<const half8 *>(s_dys + (rl + 32 * ct) * 32 + 16 * s + 8 * hl);
             }
-            // trunc_exp backward (ngp.py:34-39): g * exp(min(x, 15)) with exp(x) = sigma (0 outside the aabb)
-            dlogit[ct] = ok ? args.d_sigma[col] * fminf(args.sigma[col], 3269017.3724721107f) * ls : 0.0f;
         }
         const int nks_o = head == 0 ? 1 : 2;            // k-steps of the head's output layer (16 / 32 padded rows)
         {   // head output layer: weight gradient (dY_S x h2_S), then dZ2 in both orientations
@@ -373,7 +423,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
                     dzP[ct][s] = mask_by_nonzero(pack8(aS[ct], s), h2S[ct][s]);
                     s_sd[((head * 2 + e) * 4 + ct * 2 + s) * 64 + lane] = dzP[ct][s];
                 }
-            __syncthreads();
+            MNF_SYNC(4);
             // head hidden layer: weight gradient tiles (nt, e), nt = 0, 1
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -386,24 +436,24 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
             }
         }
         {   // dZ1 of the head in both orientations; F published for the geo gradient, S stays here (row owner of the head's input matrix)
-            f32x16 aF[CT], aS[CT];
-            zero2(aF); zero2(aS);
+            half8 tw[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const half8 w = ldg_block(ft, oTh + ks, lane);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const half8 b = s_e[LB][(head * 8 + ks * 2 + ct) * 64 + lane];
-                    aF[ct] = mfma(w, b, aF[ct]); aS[ct] = mfma(b, w, aS[ct]);
-                }
-            }
+            for (int ks = 0; ks < 4; ++ks) tw[ks] = ldg_block(ft, oTh + ks, lane);
             half8 dzP[CT][2], inP[CT][2];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
+                f32x16 aF, aS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { aF[i] = 0.0f; aS[i] = 0.0f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const half8 b = s_e[LB][(head * 8 + ks * 2 + ct) * 64 + lane];
+                    aF = mfma(tw[ks], b, aF); aS = mfma(b, tw[ks], aS);
+                }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    s_e[LB ^ 1][(head * 8 + (2 * e + s) * 2 + ct) * 64 + lane] = mask_by_bits(pack8(aF[ct], s), mH1 >> (8 * (ct * 2 + s)));
-                    dzP[ct][s] = mask_by_nonzero(pack8(aS[ct], s), h1S[ct][s]);
+                    s_e[LB ^ 1][(head * 8 + (2 * e + s) * 2 + ct) * 64 + lane] = mask_by_bits(pack8(aF, s), mH1 >> (8 * (ct * 2 + s)));
+                    dzP[ct][s] = mask_by_nonzero(pack8(aS, s), h1S[ct][s]);
                 }
                 // the head's input as an S tile: rgb columns 0..15 = SH, 16..31 = geo fragment rows; semantic columns 0..15 = geo fragment rows
                 f32x16 t;
@@ -419,7 +469,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
             }
             wgrad_acc(a_hi, dzP, inP);
         }
-        __syncthreads();
+        MNF_SYNC(5);
         {   // geo-feature gradient of this head: wave e takes column tile ct = e; exchanged in fp32
             f32x16 g;
 #pragma unroll
@@ -429,13 +479,13 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
 #pragma unroll
             for (int i = 0; i < 8; ++i) s_g[((head * 2 + e) * 8 + i) * 64 + lane] = g[i];
         }
-        __syncthreads();
+        MNF_SYNC(6);
         half8 dboF[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) dboF[ct][j] = (half_t)(s_g[((0 * 2 + ct) * 8 + j) * 64 + lane] + s_g[((1 * 2 + ct) * 8 + j) * 64 + lane]);
-            if (hl == 0) dboF[ct][0] = sat_half(dlogit[ct]);
+            if (hl == 0) dboF[ct][0] = sat_half(s_dl[rl + 32 * ct]);
         }
         half8 dzS[CT][2];                       // packed S tile (own rows q) of the current base pre-activation gradient
         {   // base output layer: weight gradient (0, q), then dZ(NH-1) in both orientations
@@ -462,7 +512,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
                     if (NH > 1) s_sd[(q * 4 + ct * 2 + s) * 64 + lane] = dzS[ct][s];
                 }
         }
-        __syncthreads();
+        MNF_SYNC(7);
 #pragma unroll
         for (int l = NH - 1; l >= 1; --l) {     // hidden matrix l - 1 -> l: weight gradient tiles (nt, q), then dZ(l - 1); F buffers alternate from LB
             const int cur = (LB + (NH - 1 - l)) & 1;
@@ -475,27 +525,28 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
                     for (int s = 0; s < 2; ++s) a[ct][s] = s_sd[(nt * 4 + ct * 2 + s) * 64 + lane];
                 wgrad_acc(a_hid[l - 1][nt], a, hS[l - 1]);
             }
-            f32x16 aF[CT], aS[CT];
-            zero2(aF); zero2(aS);
+            half8 tw[8];                          // this wave's transposed fragments of the matrix (one fetch, both column tiles)
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const half8 w = ldg_block(ft, LT::o_bh + (l - 1) * 32 + q * 8 + ks, lane);
+            for (int ks = 0; ks < 8; ++ks) tw[ks] = ldg_block(ft, LT::o_bh + (l - 1) * 32 + q * 8 + ks, lane);
+            static_assert(NH <= 2, "more hidden layers: s_sd is rewritten below while other waves may still read it (add a barrier)");
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
+            for (int ct = 0; ct < CT; ++ct) {       // one 32-column tile at a time (register pressure)
+                f32x16 aF, aS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { aF[i] = 0.0f; aS[i] = 0.0f; }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
                     const half8 b = s_e[cur][(ks * 2 + ct) * 64 + lane];
-                    aF[ct] = mfma(w, b, aF[ct]); aS[ct] = mfma(b, w, aS[ct]);
+                    aF = mfma(tw[ks], b, aF); aS = mfma(b, tw[ks], aS);
                 }
-            }
-            if (l > 1) __syncthreads();          // (NH <= 2 never gets here: s_sd would be rewritten while others still read it)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    s_e[cur ^ 1][((2 * q + s) * 2 + ct) * 64 + lane] = mask_by_bits(pack8(aF[ct], s), mF[l - 1] >> (8 * (ct * 2 + s)));
-                    dzS[ct][s] = mask_by_nonzero(pack8(aS[ct], s), hS[l - 1][ct][s]);
-                    if (l > 1) s_sd[(q * 4 + ct * 2 + s) * 64 + lane] = dzS[ct][s];
+                    s_e[cur ^ 1][((2 * q + s) * 2 + ct) * 64 + lane] = mask_by_bits(pack8(aF, s), mF[l - 1] >> (8 * (ct * 2 + s)));
+                    dzS[ct][s] = mask_by_nonzero(pack8(aS, s), hS[l - 1][ct][s]);
                 }
-            __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            MNF_SYNC(8);
         }
         constexpr int DB = (LB + (NH - 1)) & 1;   // buffer that holds dZ(0)
         {   // gradient of the 64 hash features: wave q takes row tile q >> 1, column tile q & 1; rows 8g + 4h + i == level 8rt + 2g + h, feature i
@@ -529,7 +580,7 @@ __global__ void __launch_bounds__(kFusedThreads, 1) fused_bwd_kernel(const Fused
                 wgrad_acc(a_in[kt], dzS, xP);
             }
         }
-        __syncthreads();        // the next tile's first layer rewrites s_e[0], s_sd and s_g
+        MNF_SYNC(9);        // the next tile's first layer rewrites s_e[0], s_sd and s_g
     }
 
     // =============================================================== weight gradients out: once per workgroup

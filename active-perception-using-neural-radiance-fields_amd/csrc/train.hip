@@ -1122,9 +1122,10 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     // (and the weight gradients, which read every range) is left behind the last dgrad.  One range = the old schedule (deterministic mode: its grouping
     // of partial sums must not change).
     static const int chunks_env = diag_env("MNF_BWD_CHUNKS") ? atoi(diag_env("MNF_BWD_CHUNKS")) : 0;
-    const bool fused_ = use_fused_backward(f, deterministic);
-    int n_chunks = (!deterministic && !fused_ && n >= ((int64_t)1 << 18)) ? 2 : 1;      // measured (profiles/r04_bwd_chunks.txt): 5.77 / 5.52 / 5.60 ms per step with 1 / 2 / 4 ranges
-    if (chunks_env >= 1 && chunks_env <= 4 && !deterministic && !fused_) n_chunks = chunks_env;
+    // measured (profiles/r04_bwd_chunks.txt): 5.77 / 5.52 / 5.60 ms per step with 1 / 2 / 4 ranges.  The fused backward takes every register of a CU: no scatter
+    // workgroup runs beside it, and a second range only costs a second flush of its weight gradients (4.33 / 4.26 ms with 1 / 2 ranges when its kernel ran 2 x 0.78 ms).
+    int n_chunks = (!deterministic && !fused && n >= ((int64_t)1 << 18)) ? 2 : 1;
+    if (chunks_env >= 1 && chunks_env <= 4 && !deterministic) n_chunks = chunks_env;
     if (!positions_normalized) {   // (the train step's forward hands over normalised positions already: FieldIO::xn_out)
         const float *ab = f->cfg.aabb;
         const int64_t blocks = ceil_div(3 * n, 256);
@@ -1143,15 +1144,18 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         fa.d_rgb = d_rgb; fa.d_sigma = d_density; fa.d_sem = d_sem; fa.rgb = rgb; fa.sigma = density; fa.dX = v.dX;
         fa.g0 = g_base; fa.g1 = g_head; fa.g2 = g_sem; fa.n = n; fa.Np = v.Np; fa.n_dev = n_dev; fa.C = f->cfg.num_semantic_classes;
         fa.out_fp16 = f->cfg.output_fp16 ? 1 : 0; fa.loss_scale = loss_scale;
-        const int64_t tiles = ceil_div(n, kWaveSamples);
-        const int fgrid = (int)(tiles < 256 ? tiles : 256);
+        const int fgrid = (int)(chunk_tiles_max < 256 ? chunk_tiles_max : 256);
         ProfScope ps("fused_backward", s);
-        if (NH == 1) hipLaunchKernelGGL((fused_bwd_kernel<1>), dim3(fgrid), dim3(kFusedThreads), 0, s, fa);
-        else hipLaunchKernelGGL((fused_bwd_kernel<2>), dim3(fgrid), dim3(kFusedThreads), 0, s, fa);
+        for (int c = 0; c < n_chunks; ++c) {      // range by range like dgrad below: the scatter of a range runs beside the next range's launch
+            fa.chunk = c; fa.n_chunks = n_chunks;
+            if (NH == 1) hipLaunchKernelGGL((fused_bwd_kernel<1>), dim3(fgrid), dim3(kFusedThreads), 0, s, fa);
+            else hipLaunchKernelGGL((fused_bwd_kernel<2>), dim3(fgrid), dim3(kFusedThreads), 0, s, fa);
+            MNF_HIP(hipEventRecord(ts->ev_chunk[c], s));
+        }
         ok = true;
     }
     const int prof_dgrad = fused ? -1 : prof_start("dgrad", s);
-    for (int c = 0; c < n_chunks; ++c) {
+    for (int c = 0; c < n_chunks && !fused; ++c) {
         a.chunk = c; a.n_chunks = n_chunks;
 #define MNF_CASE(w, nh) if (!fused && W == w && NH == nh) { launch_dgrad<w, nh>(a, grid, s); ok = true; }
 #ifdef MNF_DEV_ONLY_128x2
@@ -1551,3 +1555,11 @@ extern "C" int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf
     return launch_status("count_nan_kernel");
 }
 #endif  // MNF_BF16
+
+#if defined(MNF_FUSED_STAMPS) && !defined(MNF_BF16)
+// experiment builds only (tools/exp_fused_stamps.py): the phase stamps fused_bwd_kernel's workgroup 0 left in its last launch
+extern "C" int mnf_exp_fused_stamps(unsigned long long *out, int n) {
+    const size_t bytes = (size_t)n * sizeof(unsigned long long);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mnf::f16::g_fused_stamps), bytes < sizeof(mnf::f16::g_fused_stamps) ? bytes : sizeof(mnf::f16::g_fused_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
