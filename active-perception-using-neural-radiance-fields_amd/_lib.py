@@ -25,7 +25,8 @@ class FieldConfig(ctypes.Structure):
 class TrainOpts(ctypes.Structure):
     _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float), ("cone_angle", c_float),
                 ("alpha_thre", c_float), ("early_stop_eps", c_float), ("render_bkgd", c_float * 3), ("loss_scale", c_float),
-                ("stratified", c_int32), ("seed", c_uint64), ("render_bkgd_dev", c_void_p), ("deterministic", c_int32), ("n_levels", c_int32)]
+                ("stratified", c_int32), ("seed", c_uint64), ("render_bkgd_dev", c_void_p), ("deterministic", c_int32), ("n_levels", c_int32),
+                ("presampled", c_void_p)]
 
 
 class VanillaConfig(ctypes.Structure):
@@ -125,6 +126,12 @@ SIGNATURES = {
                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_field_forward_train_samples": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                                   c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_presample_create": (c_int32, [POINTER(c_void_p)]),
+    "mnf_presample_destroy": (None, [c_void_p]),
+    "mnf_train_presample_workspace_bytes": (c_int64, [c_int32]),
+    "mnf_train_presample": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                                      POINTER(TrainOpts), c_void_p, c_int64, c_void_p]),
+    "mnf_presample_wait": (c_int32, [c_void_p, c_void_p]),
     "mnf_train_step_workspace_bytes": (c_int64, [c_void_p, c_int32, c_int64, c_int64]),
     "mnf_train_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                  c_void_p, c_void_p, c_void_p, POINTER(TrainOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -23,6 +23,18 @@
 
 #include "field.h"
 
+// mnf_train_presample's handle: what was marched, for which rays / options, and the two events that order it
+struct mnf_presample_s {
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    void *ws = nullptr;
+    const float *rays_o = nullptr, *rays_d = nullptr;
+    const uint8_t *binaries = nullptr;
+    int32_t n_rays = 0, stratified = 0, n_levels = 0, res[3] = {0, 0, 0};
+    uint64_t seed = 0;
+    float near_plane = 0.f, far_plane = 0.f, step = 0.f, cone = 0.f, alpha_thre = 0.f;
+    int valid = 0, launched = 0;
+};
+
 namespace mnf {
 namespace {
 
@@ -46,11 +58,13 @@ __global__ void __launch_bounds__(256) planes_kernel(int32_t n, float near_plane
                                                      int64_t *__restrict__ counts, int32_t *__restrict__ skip, float *__restrict__ g_head, int64_t n_head,
                                                      float *__restrict__ g_sem, int64_t n_sem) {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < 4) { losses[r] = 0.f; counts[r] = 0; }
-    if (r == 0) *skip = 0;
-    for (int64_t i = r; i < n_head; i += (int64_t)gridDim.x * blockDim.x) g_head[i] = 0.f;
-    for (int64_t i = r; i < n_sem; i += (int64_t)gridDim.x * blockDim.x) g_sem[i] = 0.f;
-    if (r >= n) return;
+    if (losses) {      // (NULL: a presample — the planes only; nearp NULL: a presampled step — the zero-fills only)
+        if (r < 4) { losses[r] = 0.f; counts[r] = 0; }
+        if (r == 0) *skip = 0;
+        for (int64_t i = r; i < n_head; i += (int64_t)gridDim.x * blockDim.x) g_head[i] = 0.f;
+        for (int64_t i = r; i < n_sem; i += (int64_t)gridDim.x * blockDim.x) g_sem[i] = 0.f;
+    }
+    if (r >= n || !nearp) return;
     float v = near_plane;
     if (stratified) v += ((float)(philox4x32_10({(uint32_t)r, 0u, 7u, 0u}, s0, s1).x & 0xFFFFFFu) * 5.9604644775390625e-08f) * step;
     nearp[r] = v; farp[r] = far_plane;
@@ -263,6 +277,48 @@ inline int32_t scratch_cap(int32_t n_rays) {
     return (int32_t)(c < 64 ? 64 : (c > 2048 ? 2048 : c));
 }
 
+// What the parameter-independent head of a step leaves behind (mnf_train_presample): the part of StepWs the march fills.
+struct SampleWs {
+    float *nearp, *farp, *alpha_thre, *scratch_ts, *scratch_te;
+    int64_t *counts, *starts, *totals, *scan;
+    int64_t bytes;
+};
+
+SampleWs carve_sample(char *base, int64_t R, int32_t cap) {
+    SampleWs w;
+    size_t off = 0;
+    auto take = [&](size_t b) { char *p = base ? base + off : nullptr; off += (b + 255) & ~(size_t)255; return p; };
+    w.nearp = (float *)take(R * 4); w.farp = (float *)take(R * 4); w.alpha_thre = (float *)take(256);
+    w.counts = (int64_t *)take(R * 8); w.starts = (int64_t *)take(R * 8);
+    w.totals = (int64_t *)take(2048); w.scan = (int64_t *)take((size_t)mnf_scan_workspace_bytes(R));
+    w.scratch_ts = (float *)take((size_t)R * cap * 4); w.scratch_te = (float *)take((size_t)R * cap * 4);
+    w.bytes = (int64_t)off;
+    return w;
+}
+
+// near planes, alpha threshold, march, per-ray offsets, longest ray: everything of a step that reads the rays and the occupancy grid but not the parameters
+int sample_stage(const SampleWs &w, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y, int32_t res_z,
+                 const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays, const mnf_train_opts *opts, float *losses,
+                 int64_t *counts_dev, int32_t *skip_dev, float *g_head, int64_t n_head, float *g_sem, int64_t n_sem, hipStream_t s) {
+    const int64_t cells = (int64_t)res_x * res_y * res_z;
+    const int rblocks = (n_rays + 255) / 256;
+    const int32_t cap = scratch_cap(n_rays);
+    hipLaunchKernelGGL(planes_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
+                       opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp, losses, counts_dev, skip_dev, g_head,
+                       n_head, g_sem, n_sem);
+    double *mean_part = reinterpret_cast<double *>(w.totals + 8);          // 128 doubles behind the counters
+    const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
+    hipLaunchKernelGGL(mean_partial_kernel, dim3(128), dim3(256), 0, s, occs, cells * n_levels, mean_part);          // occ_grid.py:192: the mean over every level
+    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(64), 0, s, (const double *)mean_part, 128, cells * n_levels, opts->alpha_thre, w.alpha_thre);
+    int rc = mnf_sample_rays_levels(rays_o, rays_d, n_rays, binaries, n_levels, res_x, res_y, res_z, aabb_host, w.nearp, w.farp, opts->render_step_size,
+                                    opts->cone_angle, cap, w.scratch_ts, w.scratch_te, w.counts, bitgrid, (mnf_stream_t)s);
+    if (rc) return rc;
+    rc = mnf_exclusive_scan_i64(w.counts, n_rays, w.starts, w.totals, w.scan, mnf_scan_workspace_bytes(n_rays), (mnf_stream_t)s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(max_kernel, dim3(1), dim3(1024), 0, s, w.counts, (int64_t)n_rays, w.totals + 2);
+    return launch_status("sample_stage");
+}
+
 }  // namespace
 }  // namespace mnf
 
@@ -271,6 +327,64 @@ using namespace mnf;
 extern "C" int64_t mnf_train_step_workspace_bytes(mnf_field_t f, int32_t n_rays, int64_t max_marched, int64_t max_kept) {
     if (!f || n_rays <= 0 || max_marched <= 0 || max_kept <= 0) return -1;
     return carve_step(nullptr, f, n_rays, scratch_cap(n_rays), max_marched, max_kept).bytes;
+}
+
+extern "C" int mnf_presample_create(mnf_presample_t *out) {
+    MNF_REQUIRE(out, "presample_create: null pointer");
+    mnf_presample_s *p = new mnf_presample_s();
+    if (hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming) != hipSuccess) {
+        if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
+        delete p;
+        set_error("presample_create: hipEventCreate failed");
+        return MNF_ERR_HIP;
+    }
+    *out = p;
+    return MNF_OK;
+}
+
+extern "C" void mnf_presample_destroy(mnf_presample_t p) {
+    if (!p) return;
+    (void)hipEventDestroy(p->ev_ready);
+    (void)hipEventDestroy(p->ev_done);
+    delete p;
+}
+
+extern "C" int64_t mnf_train_presample_workspace_bytes(int32_t n_rays) {
+    if (n_rays <= 0) return -1;
+    return carve_sample(nullptr, n_rays, scratch_cap(n_rays)).bytes;
+}
+
+extern "C" int mnf_presample_wait(mnf_presample_t p, mnf_stream_t stream) {
+    MNF_REQUIRE(p, "presample_wait: null handle");
+    if (p->launched) MNF_HIP(hipStreamWaitEvent(as_stream(stream), p->ev_done, 0));
+    return MNF_OK;
+}
+
+extern "C" int mnf_train_presample(mnf_presample_t p, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
+                                   int32_t res_z, const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays,
+                                   const mnf_train_opts *opts, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
+    MNF_REQUIRE(p && binaries && occs && aabb_host && rays_o && rays_d && opts && workspace, "train_presample: null pointer");
+    MNF_REQUIRE(n_rays > 0 && opts->render_step_size > 0.f, "train_presample: bad sizes");
+    const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
+    MNF_REQUIRE(n_levels <= 4, "train_presample: at most 4 occupancy levels");
+    const SampleWs w = carve_sample((char *)workspace, n_rays, scratch_cap(n_rays));
+    if (workspace_bytes < w.bytes) { set_error("train_presample: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)w.bytes); return MNF_ERR_WORKSPACE; }
+    hipStream_t s = as_stream(stream), ss = shared_side_stream(2);
+    if (!ss) return MNF_ERR_HIP;
+    p->valid = 0;
+    // fork: the side stream continues from the caller's stream as it is NOW — in front of whatever the caller enqueues next (the step this march is to hide behind)
+    MNF_HIP(hipEventRecord(p->ev_ready, s));
+    MNF_HIP(hipStreamWaitEvent(ss, p->ev_ready, 0));
+    const int rc = sample_stage(w, binaries, bitgrid, occs, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, nullptr, nullptr, nullptr, nullptr, 0,
+                                nullptr, 0, ss);
+    MNF_HIP(hipEventRecord(p->ev_done, ss));
+    p->launched = 1;
+    if (rc) return rc;
+    p->ws = workspace; p->rays_o = rays_o; p->rays_d = rays_d; p->binaries = binaries; p->n_rays = n_rays; p->seed = opts->seed; p->stratified = opts->stratified;
+    p->n_levels = n_levels; p->near_plane = opts->near_plane; p->far_plane = opts->far_plane; p->step = opts->render_step_size; p->cone = opts->cone_angle;
+    p->alpha_thre = opts->alpha_thre; p->res[0] = res_x; p->res[1] = res_y; p->res[2] = res_z;
+    p->valid = 1;
+    return MNF_OK;
 }
 
 extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
@@ -284,28 +398,37 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     MNF_REQUIRE(n_rays > 0 && max_marched > 0 && max_kept > 0 && opts->render_step_size > 0.f, "train_step: bad sizes");
     hipStream_t s = as_stream(stream);
     const int32_t cap = scratch_cap(n_rays);
-    const StepWs w = carve_step((char *)workspace, f, n_rays, cap, max_marched, max_kept);
+    StepWs w = carve_step((char *)workspace, f, n_rays, cap, max_marched, max_kept);
     if (workspace_bytes < w.bytes) { set_error("train_step: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)w.bytes); return MNF_ERR_WORKSPACE; }
     const int C = f->cfg.num_semantic_classes;
-    const int64_t cells = (int64_t)res_x * res_y * res_z;
     const int rblocks = (n_rays + 255) / 256;
     MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));           // (losses, counters, skip flag, g_head, g_sem: zeroed by planes_kernel)
     int64_t *eff = w.totals + 4;                                           // [0] marched, [1] kept samples the kernels behind the guards work on
     // ---- occupancy sampling (occ_grid.py:80-238): march, density pre-pass, visibility filter
-    hipLaunchKernelGGL(planes_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
-                       opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp, losses, counts_dev, skip_dev, g_head,
-                       (int64_t)f->n_head, g_sem, (int64_t)f->n_sem);
-    double *mean_part = reinterpret_cast<double *>(w.totals + 8);          // 128 doubles behind the counters
     const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
     MNF_REQUIRE(n_levels <= 4, "train_step: at most 4 occupancy levels");
-    hipLaunchKernelGGL(mean_partial_kernel, dim3(128), dim3(256), 0, s, occs, cells * n_levels, mean_part);          // occ_grid.py:192: the mean over every level
-    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(64), 0, s, (const double *)mean_part, 128, cells * n_levels, opts->alpha_thre, w.alpha_thre);
-    int rc = mnf_sample_rays_levels(rays_o, rays_d, n_rays, binaries, n_levels, res_x, res_y, res_z, aabb_host, w.nearp, w.farp, opts->render_step_size,
-                                    opts->cone_angle, cap, w.scratch_ts, w.scratch_te, w.counts, bitgrid, stream);
-    if (rc) return rc;
-    rc = mnf_exclusive_scan_i64(w.counts, n_rays, w.starts, w.totals, w.scan, mnf_scan_workspace_bytes(n_rays), stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(max_kernel, dim3(1), dim3(1024), 0, s, w.counts, (int64_t)n_rays, w.totals + 2);
+    int rc = 0;
+    if (const mnf_presample_s *pre = opts->presampled) {
+        // the march of THIS batch ran earlier, on a side stream beside the previous step (mnf_train_presample): adopt what it left, after its last kernel
+        MNF_REQUIRE(pre->valid && pre->rays_o == rays_o && pre->rays_d == rays_d && pre->n_rays == n_rays && pre->binaries == binaries && pre->seed == opts->seed &&
+                    pre->stratified == opts->stratified && pre->n_levels == n_levels && pre->near_plane == opts->near_plane && pre->far_plane == opts->far_plane &&
+                    pre->step == opts->render_step_size && pre->cone == opts->cone_angle && pre->alpha_thre == opts->alpha_thre &&
+                    pre->res[0] == res_x && pre->res[1] == res_y && pre->res[2] == res_z,
+                    "train_step: opts->presampled was made for other rays, options or another grid");
+        MNF_HIP(hipStreamWaitEvent(s, pre->ev_done, 0));
+        const SampleWs sw = carve_sample((char *)pre->ws, n_rays, cap);
+        w.nearp = sw.nearp; w.farp = sw.farp; w.alpha_thre = sw.alpha_thre; w.counts = sw.counts; w.starts = sw.starts; w.totals = sw.totals;
+        w.scratch_ts = sw.scratch_ts; w.scratch_te = sw.scratch_te;
+        eff = w.totals + 4;
+        const_cast<mnf_presample_s *>(pre)->valid = 0;      // (the guards below may clear its counts: one use)
+        hipLaunchKernelGGL(planes_kernel, dim3(rblocks), dim3(256), 0, s, 0, 0.f, 0.f, 0.f, 0, 0u, 0u, (float *)nullptr, (float *)nullptr, losses, counts_dev,
+                           skip_dev, g_head, (int64_t)f->n_head, g_sem, (int64_t)f->n_sem);
+    } else {
+        const SampleWs sw = {w.nearp, w.farp, w.alpha_thre, w.scratch_ts, w.scratch_te, w.counts, w.starts, w.totals, w.scan, 0};
+        rc = sample_stage(sw, binaries, bitgrid, occs, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, losses, counts_dev, skip_dev, g_head,
+                          (int64_t)f->n_head, g_sem, (int64_t)f->n_sem, s);
+        if (rc) return rc;
+    }
     // a ray longer than its scratch row would have been truncated (the rows hold `cap` samples; the reference configurations stay far
     // below) and more marched samples than `max_marched` would not fit the packed arrays: both end the step here, on the device
     hipLaunchKernelGGL(guard_marched_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, w.counts, w.starts, (const int64_t *)w.totals, max_marched,

@@ -376,10 +376,81 @@ def _check_status(status):
         raise L.MnfError("train_step: a semantic class id lies outside [0, num_semantic_classes) (F.cross_entropy's device assert)")
 
 
+class Presample:
+    """A batch's march, done ahead of its train step (`presample`): the C handle, the tensors the march reads and wrote, and what it was made for."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        L.check(L.load_library().mnf_presample_create(ctypes.byref(h)))
+        self.handle = h
+        weakref.finalize(self, L.load_library().mnf_presample_destroy, h)
+        self.keep = None
+
+    def wait(self, device=None):
+        """torch's current stream waits for the march (no-op if none was launched)."""
+        L.check(L.load_library().mnf_presample_wait(self.handle, L.stream(device)))
+
+    def __del__(self):
+        try:
+            if self.keep is not None:        # dropped without a step: its buffers go back to the allocator only behind the march
+                self.wait(self.keep[0].device)
+        except Exception:
+            pass
+
+
+def _grid_version(estimator):
+    b, o = estimator.binaries, estimator.occs
+    return (b.data_ptr(), b._version, o.data_ptr(), o._version)
+
+
+@torch.no_grad()
+def presample(radiance_field, estimator, rays: Rays, near_plane=0.1, far_plane=1e10, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01,
+              stratified=None, handle: "Presample | None" = None, seed: "int | None" = None):
+    """March the NEXT batch now, beside the train step that is enqueued after this call (`mnf_train_presample`, include/mi355nerf.h): the sampler reads
+    rays and occupancy grid, not the model, and with one lane per ray it leaves most of the chip idle for ~0.2 ms of every step — the data loader's
+    "prefetch the next batch" applied to occ_grid.py:181-208.  Usage, the reference loop of scripts/pipeline.py:447-532 with the batch fetched one
+    iteration early:
+
+        tok = None
+        for step in range(n):
+            # (made in front of step `step`, used by step + 1: worth making only if neither of the two refreshes the occupancy grid)
+            nxt = presample(field, est, batches[step + 1].rays, ...) if step % 16 and (step + 1) % 16 else None
+            train_step(field, est, opt, *batches[step], step=step, presampled=tok)
+            tok = nxt
+
+    Same options as the step's (they are checked).  Draws the step's jitter seed from torch's CPU generator, as the step itself would have.  Pass
+    `handle` to recycle a consumed `Presample`.  A token that does not fit its step any more (grid refreshed in between, other options) is ignored by
+    `train_step`, which then marches itself with the token's seed: results never depend on whether the token was used."""
+    if estimator.levels > 4:
+        return None
+    lib = L.load_library()
+    o, d = L.contig(rays.origins.reshape(-1, 3), torch.float32), L.contig(rays.viewdirs.reshape(-1, 3), torch.float32)
+    L.require_gpu(o, d)
+    R = o.shape[0]
+    binaries, aabb = _grid_levels(estimator)
+    bits = estimator.bitgrid()
+    res = binaries.shape[1:]
+    opts = L.TrainOpts()
+    opts.n_levels = len(aabb) // 6
+    opts.near_plane, opts.far_plane, opts.render_step_size, opts.cone_angle, opts.alpha_thre = near_plane, far_plane, render_step_size, cone_angle, alpha_thre
+    opts.stratified = int(radiance_field.training if stratified is None else stratified)
+    opts.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+    tok = handle if handle is not None else Presample()
+    nbytes = int(lib.mnf_train_presample_workspace_bytes(R))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=o.device)
+    L.launch(lib.mnf_train_presample, tok.handle, L.ptr(binaries), L.ptr(bits[0]), L.ptr(estimator.occs), res[0], res[1], res[2],
+             (ctypes.c_float * len(aabb))(*aabb), L.ptr(o), L.ptr(d), R, ctypes.byref(opts), L.ptr(ws), nbytes)
+    tok.keep = (o, d, ws, binaries, bits)
+    tok.seed, tok.R, tok.version = int(opts.seed), R, _grid_version(estimator)
+    tok.key = (float(near_plane), float(far_plane), float(render_step_size), float(cone_angle), float(alpha_thre), int(opts.stratified))
+    tok.rays = (rays.origins, rays.viewdirs)
+    return tok
+
+
 @torch.no_grad()
 def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, sem, render_bkgd=None, near_plane=0.1, far_plane=1e10,
                            render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, early_stop_eps=1e-4, stratified=None, sync=True,
-                           deterministic=False):
+                           deterministic=False, presampled: "Presample | None" = None, seed: "int | None" = None):
     """scripts/pipeline.py:472-518 for one model as ONE C call (`mnf_train_step`, csrc/trainstep.hip): train render (occupancy
     sampling + density pre-pass + visibility filter + sem_rendering), the three-term loss and its backward.  Fills `.grad` of
     the three flat parameter vectors.  The call itself never waits for the GPU: the sample counts stay on the device.
@@ -397,6 +468,8 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         return None
     lib = L.load_library()
     o, d = L.contig(rays.origins.reshape(-1, 3), torch.float32), L.contig(rays.viewdirs.reshape(-1, 3), torch.float32)
+    if presampled is not None and presampled.keep is not None and presampled.rays[0] is rays.origins and presampled.rays[1] is rays.viewdirs:
+        o, d = presampled.keep[0], presampled.keep[1]        # (the very tensors the march read: the C side compares pointers)
     L.require_gpu(o, d, pixels, dep, sem)
     R, dev = o.shape[0], o.device
     handle = radiance_field._ensure_handle()
@@ -417,7 +490,16 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
             opts.render_bkgd[i] = bk[i]
         opts.render_bkgd_dev = None
     opts.stratified = int(radiance_field.training if stratified is None else stratified)
-    opts.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    use_pre = False
+    if presampled is not None and presampled.keep is not None:
+        # the token's seed in any case (the batch's jitter was drawn when it was presampled); its march only if it still fits this step
+        opts.seed = presampled.seed
+        use_pre = (presampled.R == R and presampled.keep[0] is o and presampled.version == _grid_version(estimator)
+                   and presampled.key == (float(near_plane), float(far_plane), float(render_step_size), float(cone_angle), float(alpha_thre), int(opts.stratified)))
+        if not use_pre:
+            presampled.wait(dev)                                               # (its buffers are released below: not before the march has run)
+    else:
+        opts.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)      # (`seed`: the jitter's Philox key, for reproducible runs)
     opts.deterministic = int(bool(deterministic))      # bitwise reproducible gradient accumulation (include/mi355nerf.h: mnf_train_opts)
     params = [radiance_field.mlp_base.params, radiance_field.mlp_head.params, radiance_field.mlp_sem.params]
     for p_ in params:
@@ -448,6 +530,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         cap_m, cap_k = _caps_for(st, R)
         nbytes = int(lib.mnf_train_step_workspace_bytes(handle, R, cap_m, cap_k))
         ws = _workspace(dev, nbytes)
+        opts.presampled = presampled.handle if (use_pre and _attempt == 0) else None      # (a repeated step marches itself: the guards cleared the token's counts)
         L.launch(lib.mnf_train_step, handle, L.ptr(binaries), L.ptr(bits[0]), L.ptr(estimator.occs), res[0], res[1], res[2],
                  (ctypes.c_float * len(aabb))(*aabb), L.ptr(o), L.ptr(d), R, L.ptr(tp), L.ptr(td), L.ptr(tl), ctypes.byref(opts),
                  L.ptr(params[0].grad), L.ptr(params[1].grad), L.ptr(params[2].grad), L.ptr(losses), L.ptr(counts), L.ptr(skip),
@@ -464,6 +547,9 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         break
     else:
         raise L.MnfError("train_step: sample bounds kept growing")
+    if presampled is not None:
+        presampled.adopted = use_pre
+        presampled.keep = None                                      # consumed (or discarded): the step is enqueued, stream order protects the buffers
     for p_ in params:
         torch.autograd.graph.increment_version(p_.grad)
     out = dict(loss=losses[0], loss_rgb=losses[1], loss_dep=losses[2], loss_sem=losses[3], counts=counts, skip=skip, _keep=bk_dev)
@@ -483,7 +569,7 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
 
 def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, sem, render_bkgd, step: int,
                near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, occ_thre=1e-3, scheduler=None,
-               data_parallel_group=None, data_parallel=False, fused=True, sync=True, stratified=None, deterministic=False):
+               data_parallel_group=None, data_parallel=False, fused=True, sync=True, stratified=None, deterministic=False, presampled=None, seed=None):
     """One model's training iteration exactly as scripts/pipeline.py:447-532 sequences it: occupancy refresh every 16th
     step (:447-470), train render (:472-489), loss 10*smoothL1(rgb) + smoothL1(depth)/5 + CE(sem)/2 (:506-511),
     backward (:518), NaN-gradient guard (:520-529), optimizer and scheduler step (:531-532).  `data_parallel=True`
@@ -503,11 +589,16 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     False = no jitter (reproducible sample sets: parity tests).  `deterministic=True` (fused path): gradients are accumulated in an
     order-independent way (64-bit fixed-point integer atomics for the hash table, ordered partial sums for the weights): with a
     seeded torch generator the whole training run is bitwise reproducible.
+    `seed` (fused path): the Philox key of the near-plane jitter (None: torch's CPU generator's next draw).
+    `presampled` (fused path): the `presample()` token of THIS batch — its march ran beside the previous iteration; ignored (the step marches itself,
+    with the token's jitter seed) if the occupancy refresh below or other options made it stale.
     Returns dict(loss, loss_rgb, loss_dep, loss_sem as device tensors, n_rendering_samples, skipped)."""
     import torch.nn.functional as F
     from .optim import FusedAdam, count_nan_gradients
     radiance_field.train()
     estimator.train()
+    if presampled is not None and presampled.keep is not None:
+        presampled.wait(rays.origins.device)       # the occupancy refresh below must not rewrite the grid under a march still in flight
     device_guard = isinstance(optimizer, FusedAdam)
     if not sync and not (fused and device_guard):
         raise ValueError("train_step(sync=False) needs fused=True and optim.FusedAdam (the skip decision is taken on the device)")
@@ -519,7 +610,7 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     if fused:
         out = fused_forward_backward(radiance_field, estimator, rays, pixels, dep, sem, render_bkgd, near_plane=near_plane,
                                      render_step_size=render_step_size, cone_angle=cone_angle, alpha_thre=alpha_thre, sync=sync,
-                                     stratified=stratified, deterministic=deterministic)
+                                     stratified=stratified, deterministic=deterministic, presampled=presampled, seed=seed)
     if out is not None:
         n_rendering_samples = out["n_rendering_samples"]
         loss, loss_rgb, loss_dep, loss_sem = out["loss"], out["loss_rgb"], out["loss_dep"], out["loss_sem"]
@@ -594,6 +685,7 @@ def train_step_ensemble(members, batches, step: int, **kw):
     `batches`: one (rays, pixels, dep, sem, render_bkgd) per member.  Inputs may have been produced on the caller's stream; on return the caller's stream
     waits for every member.  Results are those of the members stepped one after the other (they share nothing).  Returns the members' result dicts."""
     assert len(members) == len(batches) and len(members) >= 1
+    tokens = kw.pop("presampled", None) or [None] * len(members)      # one `presample()` token per member (made on the caller's stream), or None
     dev = batches[0][0].origins.device
     streams = ensemble_streams(dev, len(members))
     cur = streams[0]
@@ -606,11 +698,11 @@ def train_step_ensemble(members, batches, step: int, **kw):
         s_ = streams[m]
         if m:
             s_.wait_event(ready)                       # whatever produced this member's inputs on the caller's stream comes first
-            for t in (rays.origins, rays.viewdirs, pixels, dep, sem, bkgd):
+            for t in (rays.origins, rays.viewdirs, pixels, dep, sem, bkgd) + tuple((tokens[m].keep or ())[:3] if tokens[m] is not None else ()):
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(s_)                 # the caching allocator must not hand the inputs' memory out again before this stream has read it
         with torch.cuda.stream(s_):
-            outs.append(train_step(field, est, opt, rays, pixels, dep, sem, bkgd, step=step, scheduler=sched, sync=False, **kw))
+            outs.append(train_step(field, est, opt, rays, pixels, dep, sem, bkgd, step=step, scheduler=sched, sync=False, presampled=tokens[m], **kw))
     for s_ in streams[1:]:
         cur.wait_stream(s_)
     return outs

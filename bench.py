@@ -514,7 +514,7 @@ def main():
                 out.append((r,) + SI.analytic_targets(proc, scene280["aabb"], r.origins, r.viewdirs))
             return out
 
-        def train_leg(dtype, R_, sync, steps, with_kernels, dynamic_target=0):
+        def train_leg(dtype, R_, sync, steps, with_kernels, dynamic_target=0, presample=False):
             """ms per step of `steps` train iterations from the SAME start state (the stand-in's weights and grid are restored before every leg;
             the optimizer continues the stand-in's run); returns a dict."""
             tf = SC.hip_field(scene280, dev, mfma_bf16=(dtype == "bf16"))
@@ -550,9 +550,25 @@ def main():
                     dyn["R"] = int(min(R_, max(64, c[0] * dynamic_target / c[2])))
                 return out
 
+            pre = {"tok": None, "adopted": 0}
+
+            def tstep_presampled(i):
+                """The batch fetched one iteration early (render.presample): the march of batch i + 1 is enqueued in front of step i and runs beside it on the library's
+                side stream; step i adopts the march made in front of step i - 1.  Not across an occupancy refresh (steps 1008 + 16 j): those steps march themselves."""
+                r, pix, dep_, lab = batches[i % 8]
+                s_ = 1000 + i
+                nxt = RD.presample(tf, te, batches[(i + 1) % 8][0], **SC.RENDER_KW) if s_ % 16 and (s_ + 1) % 16 else None
+                tok = pre["tok"]
+                out = RD.train_step(tf, te, opt, r, pix, dep_, lab, bkd, step=s_, sync=False, occ_thre=1e-2, presampled=tok, **SC.RENDER_KW)
+                pre["adopted"] += int(tok is not None and tok.adopted)
+                pre["tok"] = nxt
+                return out
+
             def tstep(i):
                 if dynamic_target:
                     return tstep_dynamic(i)
+                if presample:
+                    return tstep_presampled(i)
                 r, pix, dep_, lab = batches[i % 8]
                 # occ_thre as the stand-in's own training (the reference uses 1e-3 / 1e-2 / 3e-3 by phase, pipeline.py:447-470): the refresh at
                 # step 1008 then keeps the grid the stand-in converged to, and the workload stays stationary
@@ -570,6 +586,9 @@ def main():
             res = {"ms_per_step": 1e3 * dt_t / steps, "steps": steps, "rays_per_step": R_, "dtype": dtype,
                    "host_round_trips_per_step": 1 if sync else 0, "rendering_samples_per_step": kept, "marched_samples_per_step": marched,
                    "skipped_steps": int(sum(int(o["skipped"]) for o in outs))}
+            if presample:
+                res["marches_adopted_of_steps"] = [pre["adopted"], steps + max(args.warmup, 6)]
+                return res
             # how sparse the hash-table gradient of one step is (decides whether a touched-rows exchange could beat the dense all-reduce of
             # ray-data-parallel training): fraction of the table's entries with a non-zero gradient after the last step
             n_mlp = tf.mlp_base.params.numel() - 4 * tf._table_entries()
@@ -636,18 +655,30 @@ def main():
 
             def side(i):
                 return RD.train_step_ensemble(mem, [tuple(batches[(i + 3 * m) % 8]) + (bkd,) for m in range(2)], step=1000 + i, occ_thre=1e-2, **SC.RENDER_KW)
-            for label, fn in (("one_stream", turn), ("stream_per_member", side)):
+            pre = {"tok": None}
+
+            def side_presampled(i):
+                s_ = 1000 + i
+                nxt = [RD.presample(tf, te, batches[(i + 1 + 3 * m) % 8][0], **SC.RENDER_KW) for m, (tf, te, _) in enumerate(mem)] if s_ % 16 and (s_ + 1) % 16 else None
+                out = RD.train_step_ensemble(mem, [tuple(batches[(i + 3 * m) % 8]) + (bkd,) for m in range(2)], step=s_, occ_thre=1e-2, presampled=pre["tok"], **SC.RENDER_KW)
+                pre["tok"] = nxt
+                return out
+            for label, fn in (("one_stream", turn), ("stream_per_member", side), ("stream_per_member_next_batch_presampled", side_presampled)):
                 outs = []
                 dt_e = timed(fn, steps, 6, False, outs.append)
                 res[label] = {"ms_per_iteration": 1e3 * dt_e / steps, "ms_per_member_step": 1e3 * dt_e / steps / 2,
                               "rendering_samples_per_member_step": float(np.mean([int(o["n_rendering_samples"]) for pair in outs for o in pair])),
                               "skipped_steps": int(sum(int(o["skipped"]) for pair in outs for o in pair))}
             res["speedup"] = res["one_stream"]["ms_per_iteration"] / res["stream_per_member"]["ms_per_iteration"]
+            res["speedup_presampled"] = res["one_stream"]["ms_per_iteration"] / res["stream_per_member_next_batch_presampled"]["ms_per_iteration"]
             return res
 
         tsteps = max(args.steps, 10)
         dtypes = [d for d in args.train_dtypes.split(",") if d in ("f16", "bf16")]
-        train = {"workload": "BASELINE config 5: scene 102344280 (trained stand-in, training continued from the same state in every leg), 8192-ray batches "
+        presample_note = ("next_batch_presampled: the same steps with the batch fetched one iteration early and its march (occ_grid.py:181-208: reads rays and grid, not the model) "
+                          "enqueued in front of the current step on a library side stream (render.presample / mnf_train_presample); bit-identical results "
+                          "(tests/test_gpu_round4.py), every march inside the timed region; steps next to an occupancy refresh march themselves")
+        train = {"presample": presample_note, "workload": "BASELINE config 5: scene 102344280 (trained stand-in, training continued from the same state in every leg), 8192-ray batches "
                              "of one 640x640 view, occupancy sampling + density pre-pass + differentiable render + loss (pipeline.py:506-511) + backward "
                              "+ NaN guard + FusedAdam; occupancy refresh every 16th step"}
         for dt_ in dtypes:
@@ -655,13 +686,18 @@ def main():
             leg = train_leg(dt_, args.train_rays, False, tsteps, True)
             leg["host_synchronous"] = {k: v for k, v in train_leg(dt_, args.train_rays, True, tsteps, False).items()
                                        if k in ("ms_per_step", "rendering_samples_per_step", "host_round_trips_per_step")}
+            leg["next_batch_presampled"] = {k: v for k, v in train_leg(dt_, args.train_rays, False, tsteps, False, presample=True).items()
+                                            if k in ("ms_per_step", "rendering_samples_per_step", "marches_adopted_of_steps", "skipped_steps")}
             train[dt_] = leg
-            log(f"train {dt_}: {leg['ms_per_step']:.2f} ms/step at {leg['rendering_samples_per_step']:.0f} samples (host-synchronous {leg['host_synchronous']['ms_per_step']:.2f})")
+            log(f"train {dt_}: {leg['ms_per_step']:.2f} ms/step at {leg['rendering_samples_per_step']:.0f} samples (host-synchronous {leg['host_synchronous']['ms_per_step']:.2f}, "
+                f"next batch presampled {leg['next_batch_presampled']['ms_per_step']:.2f})")
         first = train[dtypes[0]]
         train.update({k: first[k] for k in ("ms_per_step", "rays_per_step", "rendering_samples_per_step", "marched_samples_per_step", "roofline")})
         train["dtype"] = dtypes[0]
         ry = train_leg("f16", 2000, False, tsteps, True)
         ry["host_synchronous_ms_per_step"] = train_leg("f16", 2000, True, tsteps, False)["ms_per_step"]
+        ry["next_batch_presampled"] = {k: v for k, v in train_leg("f16", 2000, False, max(tsteps, 40), False, presample=True).items()
+                                       if k in ("ms_per_step", "rendering_samples_per_step", "marches_adopted_of_steps", "skipped_steps")}
         ry["workload"] = ("the reference yaml's own shape: 2000 rays per step (scripts/config_102344250.yaml:3, the cap of pipeline.py:494-504), target "
                           "262 144 samples (config:4); same scene and start state")
         if "kernels" in ry:

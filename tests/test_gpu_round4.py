@@ -313,3 +313,61 @@ def test_ensemble_members_on_their_own_streams_equal_sequential_steps():
         for a, b in zip(pa, pb):
             assert torch.nn.functional.cosine_similarity(a, b, dim=0) > 0.9999
     assert len(RD._ENSEMBLE_STREAMS[torch.device(DEV)]) == 1                    # one extra stream, cached
+
+
+def test_presampled_steps_are_bitwise_the_steps_that_march_themselves():
+    """`render.presample` + `train_step(presampled=...)`: the march of batch k+1 runs on a side stream beside step k (`mnf_train_presample`), and the step that adopts it
+    gives bit for bit what a step marching inside itself gives (deterministic accumulation, stratified near planes with the seed drawn at presample time) — through an
+    occupancy refresh in the middle (the stale token is ignored, its seed is not), with a changing ray count, and asynchronously.  Also: the C side refuses a handle
+    made for other rays."""
+    import ctypes
+    from apnrf_amd import _lib as L
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene(log2_hashmap_size=15)
+    bk = torch.tensor([0.3, 0.6, 0.1], device=DEV)
+    steps = 9
+    data = []
+    for k in range(steps + 1):
+        o, d = H.view_rays(sc, 1 + k % 3, h=36 + 2 * (k % 4), w=40)              # 1440 .. 1680 rays: the ray count changes from step to step
+        rng = np.random.default_rng(70 + k)
+        n = o.shape[0]
+        data.append((RD.Rays(o.to(DEV), d.to(DEV)), torch.from_numpy(rng.random((n, 3)).astype(np.float32)).to(DEV),
+                     torch.from_numpy(rng.uniform(0.5, 4.0, n).astype(np.float32)).to(DEV), torch.from_numpy(rng.integers(0, sc["C"], n)).to(DEV), bk))
+    kw = dict(H.RENDER_KW)
+
+    def run(pre, sync):
+        f, e = H.hip_field(sc).train(), H.hip_estimator(sc)
+        opt = FusedAdam(f.parameters(), lr=1e-3, eps=1e-15).bind_field(f)
+        RD.reserve_sample_bounds(f, 1 << 21, 1 << 20)                             # no step overflows: same bounds (the deterministic grouping depends on them) in every run
+        hist, tok, used = [], None, 0
+        if pre:
+            tok = RD.presample(f, e, data[0][0], seed=900 + 14, **kw)
+        for k in range(steps):
+            step = 14 + k                                                         # step 16 refreshes the occupancy grid: the tokens made before it (for steps 16 and 17) are stale
+            nxt = RD.presample(f, e, data[k + 1][0], seed=900 + step + 1, **kw) if pre else None
+            torch.manual_seed(1000 + step)                                        # (the refresh draws its cells from torch's generators)
+            out = RD.train_step(f, e, opt, *data[k], step=step, sync=sync, deterministic=True, presampled=tok, seed=900 + step, **kw)
+            used += int(tok is not None and tok.adopted)
+            hist.append((out["loss"], out["n_rendering_samples"]))
+            tok = nxt
+        torch.cuda.synchronize()
+        return [(float(l), int(n)) for l, n in hist], [p.detach().clone() for p in f.parameters() if p.numel()], used
+
+    h_a, p_a, _ = run(False, True)
+    for sync in (True, False):
+        h_b, p_b, used = run(True, sync)
+        assert used == steps - 2                                                  # adopted: every token but the two made in front of the refresh at step 16 (for steps 16 and 17)
+        assert [n for _, n in h_a] == [n for _, n in h_b] and min(n for _, n in h_a) > 3000
+        np.testing.assert_allclose([l for l, _ in h_b], [l for l, _ in h_a], rtol=1e-6)            # (the loss scalar is a float-atomic sum over ray blocks)
+        for a, b in zip(p_a, p_b):
+            assert torch.equal(a, b)
+    # the C boundary: a handle made for other rays is refused (MNF_ERR_INVALID), not silently used
+    f, e = H.hip_field(sc).train(), H.hip_estimator(sc)
+    opt = FusedAdam(f.parameters(), lr=1e-3, eps=1e-15).bind_field(f)
+    tok = RD.presample(f, e, data[1][0], **kw)
+    tok.rays = (data[2][0].origins, data[2][0].viewdirs)
+    tok.R = data[2][0].origins.shape[0]
+    tok.keep = (L.contig(data[2][0].origins.reshape(-1, 3), torch.float32),) + tuple(tok.keep[1:])
+    with pytest.raises(L.MnfError, match="presampled was made for other rays"):
+        RD.train_step(f, e, opt, *data[2], step=3, deterministic=True, presampled=tok, **kw)

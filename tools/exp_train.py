@@ -1,6 +1,6 @@
 """Train-step timing experiment (GPU box): ms per step for the synchronous (reference semantics: one host round trip at the end)
 and the fully asynchronous form, at BASELINE config 5's shape (8192 rays) and at the reference yaml's (2000 rays / ~262 k samples).
-    python tools/exp_train.py [f16|bf16] [steps]"""
+    python tools/exp_train.py [f16|bf16] [steps] [lr] [shapes] [sync modes] [backward mode] [presample 0|1]"""
 import os
 import sys
 import time
@@ -22,6 +22,7 @@ lr = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0          # 0: the paramete
 shapes = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [8192, 2000]
 modes = [bool(int(x)) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [True, False]
 bwd_mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0        # mnf_field_set_backward_mode: 0 auto (fused where supported), 1 split kernels, 2 fused
+presample = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False   # march batch k+1 beside step k (render.presample)
 dev = "cuda:0"
 scene = SC.make_scene("102344280", n_poses=40)
 field, est, info = SI.train_standin(scene, dev, seed=11)     # the stand-in of bench.py's train legs
@@ -61,11 +62,14 @@ for R in shapes:
             RD.train_step(field, est, opt, r, pix, dep_, lab, bk, step=1001 + i, sync=sync, occ_thre=1e-2, **SC.RENDER_KW)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        tok = RD.presample(field, est, bs[0][0], **SC.RENDER_KW) if presample else None
         for i in range(steps):
             r, pix, dep_, lab = bs[i % 8]
-            outs.append(RD.train_step(field, est, opt, r, pix, dep_, lab, bk, step=1001 + i, sync=sync, occ_thre=1e-2, **SC.RENDER_KW))
+            nxt = RD.presample(field, est, bs[(i + 1) % 8][0], **SC.RENDER_KW) if presample and (1001 + i) % 16 and (1001 + i + 1) % 16 else None      # (not across the occupancy refresh of step 1008 + 16 j)
+            outs.append(RD.train_step(field, est, opt, r, pix, dep_, lab, bk, step=1001 + i, sync=sync, occ_thre=1e-2, presampled=tok, **SC.RENDER_KW))
+            tok = nxt
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         kept = np.mean([int(o["n_rendering_samples"]) for o in outs])
         skipped = sum(int(o["skipped"]) for o in outs)
-        print(f"[exp_train] {dtype} rays {R} sync={sync} bwd_mode={bwd_mode}: {1e3 * dt:.3f} ms/step, kept {kept:.0f}, skipped {skipped}", flush=True)
+        print(f"[exp_train] {dtype} rays {R} sync={sync} bwd_mode={bwd_mode} presample={presample}: {1e3 * dt:.3f} ms/step, kept {kept:.0f}, skipped {skipped}", flush=True)
