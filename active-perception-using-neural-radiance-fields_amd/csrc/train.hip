@@ -1377,12 +1377,29 @@ struct Adam3 {
     float *p[3]; const float *g[3]; float *m[3], *v[3]; float *step[3];
     int64_t n[3];
 };
+// Both passes over the parameter vectors move 16 bytes per lane and access (one thread = one aligned quad of one vector; the up-to-three elements behind the last
+// quad of a vector one by one): with 4-byte accesses the update of the 12.6 M table parameters ran at 2.3 TB/s (167 us of the reference-yaml step's 1.29 ms).
+__device__ __forceinline__ bool quad_of(const Adam3 &a, int64_t q, int &k, int64_t &i0) {
+    const int64_t q0 = (a.n[0] + 3) >> 2, q1 = (a.n[1] + 3) >> 2, q2 = (a.n[2] + 3) >> 2;
+    if (q < q0) { k = 0; i0 = q << 2; return true; }
+    if (q < q0 + q1) { k = 1; i0 = (q - q0) << 2; return true; }
+    if (q < q0 + q1 + q2) { k = 2; i0 = (q - q0 - q1) << 2; return true; }
+    return false;
+}
+__device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __global__ void __launch_bounds__(256) count_nan3_kernel(const Adam3 a, int32_t *__restrict__ count) {
     int local = 0;
-    const int64_t n01 = a.n[0] + a.n[1], total = n01 + a.n[2];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)blockDim.x * gridDim.x) {
-        const float x = i < a.n[0] ? a.g[0][i] : (i < n01 ? a.g[1][i - a.n[0]] : a.g[2][i - n01]);
-        local += !(fabsf(x) <= 3.4028234664e38f);
+    const int64_t quads = ((a.n[0] + 3) >> 2) + ((a.n[1] + 3) >> 2) + ((a.n[2] + 3) >> 2);
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)blockDim.x * gridDim.x) {
+        int k; int64_t i0;
+        quad_of(a, q, k, i0);
+        const float *g = a.g[k] + i0;
+        if (i0 + 4 <= a.n[k] && aligned16(g)) {
+            const float4 x = *reinterpret_cast<const float4 *>(g);
+            local += !(fabsf(x.x) <= 3.4028234664e38f) + !(fabsf(x.y) <= 3.4028234664e38f) + !(fabsf(x.z) <= 3.4028234664e38f) + !(fabsf(x.w) <= 3.4028234664e38f);
+        } else {
+            for (int64_t i = i0; i < a.n[k] && i < i0 + 4; ++i) local += !(fabsf(a.g[k][i]) <= 3.4028234664e38f);
+        }
     }
     if (__ballot(local != 0) != 0ull && local) atomicAdd(count, local);
 }
@@ -1398,18 +1415,43 @@ __global__ void adam_prepare3_kernel(const Adam3 a, const int32_t *__restrict__ 
 __global__ void __launch_bounds__(256) adam_guarded3_kernel(const Adam3 a, float beta1, float beta2, float eps, const float *__restrict__ hyper,
                                                             _Float16 *__restrict__ half_out, int64_t half_from) {
     if (hyper[2] != 0.0f) return;
-    const int64_t n01 = a.n[0] + a.n[1], total = n01 + a.n[2];
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)blockDim.x * gridDim.x) {
-        const int k = j < a.n[0] ? 0 : (j < n01 ? 1 : 2);
-        const int64_t i = k == 0 ? j : (k == 1 ? j - a.n[0] : j - n01);
+    const int64_t quads = ((a.n[0] + 3) >> 2) + ((a.n[1] + 3) >> 2) + ((a.n[2] + 3) >> 2);
+    auto one = [&](float gi, float &mi, float &vi, float &pi, float step_size, float bc2_sqrt) {      // (the scalar kernel's arithmetic, operation for operation)
+        mi = mi + (gi - mi) * (1.0f - beta1);
+        vi = vi * beta2 + (1.0f - beta2) * gi * gi;
+        pi = pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    };
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)blockDim.x * gridDim.x) {
+        int k; int64_t i0;
+        quad_of(a, q, k, i0);
         const float step_size = hyper[4 * k], bc2_sqrt = hyper[4 * k + 1];
-        const float gi = a.g[k][i];
-        const float mi = a.m[k][i] + (gi - a.m[k][i]) * (1.0f - beta1);
-        const float vi = a.v[k][i] * beta2 + (1.0f - beta2) * gi * gi;
-        a.m[k][i] = mi; a.v[k][i] = vi;
-        const float pn = a.p[k][i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
-        a.p[k][i] = pn;
-        if (k == 0 && half_out && i >= half_from) half_out[i - half_from] = (_Float16)pn;
+        const bool mirror = k == 0 && half_out && i0 >= half_from;
+        if (i0 + 4 <= a.n[k] && aligned16(a.g[k] + i0) && aligned16(a.m[k] + i0) && aligned16(a.v[k] + i0) && aligned16(a.p[k] + i0)) {
+            const float4 g = *reinterpret_cast<const float4 *>(a.g[k] + i0);
+            float4 m = *reinterpret_cast<const float4 *>(a.m[k] + i0), v = *reinterpret_cast<const float4 *>(a.v[k] + i0), p = *reinterpret_cast<const float4 *>(a.p[k] + i0);
+            one(g.x, m.x, v.x, p.x, step_size, bc2_sqrt); one(g.y, m.y, v.y, p.y, step_size, bc2_sqrt);
+            one(g.z, m.z, v.z, p.z, step_size, bc2_sqrt); one(g.w, m.w, v.w, p.w, step_size, bc2_sqrt);
+            *reinterpret_cast<float4 *>(a.m[k] + i0) = m; *reinterpret_cast<float4 *>(a.v[k] + i0) = v; *reinterpret_cast<float4 *>(a.p[k] + i0) = p;
+            if (k == 0 && half_out && i0 < half_from && i0 + 4 > half_from) {      // the quad the mirror starts inside
+                const float pe[4] = {p.x, p.y, p.z, p.w};
+                for (int e = 0; e < 4; ++e) if (i0 + e >= half_from) half_out[i0 + e - half_from] = (_Float16)pe[e];
+            }
+            if (mirror) {
+                _Float16 *h = half_out + (i0 - half_from);
+                if ((reinterpret_cast<uintptr_t>(h) & 7) == 0) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 o; o[0] = (_Float16)p.x; o[1] = (_Float16)p.y; o[2] = (_Float16)p.z; o[3] = (_Float16)p.w;
+                    *reinterpret_cast<h4 *>(h) = o;
+                } else { h[0] = (_Float16)p.x; h[1] = (_Float16)p.y; h[2] = (_Float16)p.z; h[3] = (_Float16)p.w; }
+            }
+        } else {
+            for (int64_t i = i0; i < a.n[k] && i < i0 + 4; ++i) {
+                float mi = a.m[k][i], vi = a.v[k][i], pi = a.p[k][i];
+                one(a.g[k][i], mi, vi, pi, step_size, bc2_sqrt);
+                a.m[k][i] = mi; a.v[k][i] = vi; a.p[k][i] = pi;
+                if (k == 0 && half_out && i >= half_from) half_out[i - half_from] = (_Float16)pi;
+            }
+        }
     }
 }
 
@@ -1534,11 +1576,11 @@ extern "C" int mnf_field_optimizer_step(mnf_field_t f, float *const *params_host
     const int64_t total = n[0] + n[1] + n[2];
     if (count_nonfinite) {
         MNF_REQUIRE(skip_dev, "field_optimizer_step: counting non-finite gradients needs the skip flag");
-        const int64_t blocks = ceil_div(total, 256 * 8);
+        const int64_t blocks = ceil_div(total, 256 * 4 * 4);
         hipLaunchKernelGGL(count_nan3_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, a, skip_dev);
     }
     hipLaunchKernelGGL(adam_prepare3_kernel, dim3(1), dim3(64), 0, s, a, (const int32_t *)skip_dev, lr, beta1, beta2, hyper_dev);
-    const int64_t blocks = ceil_div(total, 256 * 4);
+    const int64_t blocks = ceil_div(total, 256 * 4 * 2);
     hipLaunchKernelGGL(adam_guarded3_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, a, beta1, beta2, eps, (const float *)hyper_dev,
                        reinterpret_cast<_Float16 *>(f->d_table), (int64_t)f->n_base_mlp);
     int rc = launch_status("adam_guarded3_kernel");
