@@ -515,6 +515,10 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         host, ev, r_then = pending.pop(0)                       # (whatever ray count that step had: the bounds are the field's)
         ev.synchronize()
         c = host.tolist()
+        if len(c) > 4 and c[4] > 0:                             # that step was skipped on the device (no samples, a bound, non-finite gradients): train_step(sync=False)
+            st["skipped_steps"] = st.get("skipped_steps", 0) + 1      # had already advanced the LR scheduler for it — it owes one scheduler step
+            st["sched_debt"] = st.get("sched_debt", 0) + 1
+        c = c[:4]
         st["last_counts"] = (r_then, int(c[0]), int(c[1]))       # latest_step_counts(): the dynamic ray-count schedule without a host round trip
         st.setdefault("pinned", []).append((host, ev))
         _check_status(c[3])
@@ -558,8 +562,9 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         out.update(n_rendering_samples=int(c[1]), n_marched=int(c[0]))
     else:
         pool = st.setdefault("pinned", [])                         # (pinned host buffer, event) pairs are recycled: at most 3 are in flight
-        host, ev = pool.pop() if pool else (torch.empty(4, dtype=torch.int64).pin_memory(), torch.cuda.Event())
-        host.copy_(counts, non_blocking=True)
+        host, ev = pool.pop() if pool else (torch.zeros(5, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+        host[4] = 0                                                 # (slot 4: the step's final skip flag, filled by train_step behind the optimizer's guard)
+        host[:4].copy_(counts, non_blocking=True)
         ev.record(torch.cuda.current_stream(dev))
         st["pending"].append((host, ev, R))
         estimator.last_sampling = {"n_marched": counts[0]}
@@ -583,7 +588,8 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     device and the iteration is enqueued without waiting for the GPU:
       sync=True   (default) ONE host round trip at the end (the reference has one per parameter plus two inside the sampler):
                   returns n_rendering_samples as an int and skipped as a bool, steps the scheduler only if the optimizer stepped.
-      sync=False  no round trip at all: n_rendering_samples and skipped are device tensors, the scheduler advances every call.
+      sync=False  no round trip at all: n_rendering_samples and skipped are device tensors; the scheduler advances every call, and a step whose skip
+                  flag arrives raised (one or two calls later, with its counts) gives its scheduler step back: the schedule counts optimizer updates.
     Any other optimizer is stepped from the host after reading the flag (sync=True only).
     `stratified` (fused path): None = jitter the near planes as the reference does in training mode (occ_grid.py:187-189);
     False = no jitter (reproducible sample sets: parity tests).  `deterministic=True` (fused path): gradients are accumulated in an
@@ -643,8 +649,18 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
         # raised — one C call for guard + three updates + handle refresh when the optimizer is bound to the field (`bind_field`)
         optimizer.step(skip=skip, count_nonfinite=True)
         if not sync:
+            st = _train_state(radiance_field)
+            if out is not None and st["pending"]:
+                # the step's FINAL skip flag (the optimizer's non-finite guard included) travels with its counts; when it arrives — one or two calls later — a
+                # skipped step takes back the scheduler step it was given here: the schedule counts optimizer updates, as pipeline.py:491 / :520-532 do
+                host, ev, _ = st["pending"][-1]
+                host[4:5].copy_(skip.reshape(1), non_blocking=True)
+                ev.record(torch.cuda.current_stream(rays.origins.device))
             if scheduler is not None:
-                scheduler.step()
+                if st.get("sched_debt", 0) > 0:
+                    st["sched_debt"] -= 1
+                else:
+                    scheduler.step()
             return dict(loss=loss.detach(), loss_rgb=loss_rgb.detach(), loss_dep=loss_dep.detach(), loss_sem=loss_sem.detach(),
                         n_rendering_samples=n_rendering_samples, skipped=skip)
         skipped = bool(skip.item() > 0)                                        # one host round trip per iteration

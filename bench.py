@@ -693,6 +693,7 @@ def main():
                 f"next batch presampled {leg['next_batch_presampled']['ms_per_step']:.2f})")
         first = train[dtypes[0]]
         train.update({k: first[k] for k in ("ms_per_step", "rays_per_step", "rendering_samples_per_step", "marched_samples_per_step", "roofline")})
+        train["ms_per_step_next_batch_presampled"] = first["next_batch_presampled"]["ms_per_step"]
         train["dtype"] = dtypes[0]
         ry = train_leg("f16", 2000, False, tsteps, True)
         ry["host_synchronous_ms_per_step"] = train_leg("f16", 2000, True, tsteps, False)["ms_per_step"]

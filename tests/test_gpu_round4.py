@@ -371,3 +371,36 @@ def test_presampled_steps_are_bitwise_the_steps_that_march_themselves():
     tok.keep = (L.contig(data[2][0].origins.reshape(-1, 3), torch.float32),) + tuple(tok.keep[1:])
     with pytest.raises(L.MnfError, match="presampled was made for other rays"):
         RD.train_step(f, e, opt, *data[2], step=3, deterministic=True, presampled=tok, **kw)
+
+
+def test_async_scheduler_counts_optimizer_updates_not_calls():
+    """`train_step(sync=False)` advances the LR scheduler at every call, also for iterations the device-side guard skipped; the reference `continue`s before
+    `optimizer.step()` / `scheduler.step()` (pipeline.py:491, :520-532).  The step's final skip flag now travels to the host with its counts, and a skipped step gives its
+    scheduler step back one or two calls later: after the run the scheduler has stepped once per optimizer update."""
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene(log2_hashmap_size=15)
+    bk = torch.tensor([0.3, 0.6, 0.1], device=DEV)
+    o, d = H.view_rays(sc, 1, h=40, w=40)
+    rng = np.random.default_rng(3)
+    n = o.shape[0]
+    batch = (RD.Rays(o.to(DEV), d.to(DEV)), torch.from_numpy(rng.random((n, 3)).astype(np.float32)).to(DEV),
+             torch.from_numpy(rng.uniform(0.5, 4.0, n).astype(np.float32)).to(DEV), torch.from_numpy(rng.integers(0, sc["C"], n)).to(DEV), bk)
+    f, e = H.hip_field(sc).train(), H.hip_estimator(sc)
+    opt = FusedAdam(f.parameters(), lr=1e-3, eps=1e-15).bind_field(f)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.99)
+    st = RD._train_state(f)
+    st["by_R"][n] = (1 << 18, 64)                                                  # a surviving-sample bound every early step overflows: skipped on the device, the bound grows late
+    outs = [RD.train_step(f, e, opt, *batch, step=1 + k, sync=False, stratified=False, scheduler=sched, **H.RENDER_KW) for k in range(12)]
+    torch.cuda.synchronize()
+    skipped = sum(int(o_["skipped"]) > 0 for o_ in outs)
+    updates = int(opt.state[f.mlp_base.params]["step"].item()) if "step" in opt.state[f.mlp_base.params] else None
+    assert 1 <= skipped <= 4 and updates == 12 - skipped
+    # flags of the last one or two steps may still be in flight at the last call: settle them with calls that cannot skip
+    for k in range(3):
+        outs.append(RD.train_step(f, e, opt, *batch, step=20 + k, sync=False, stratified=False, scheduler=sched, **H.RENDER_KW))
+    torch.cuda.synchronize()
+    assert not any(int(o_["skipped"]) for o_ in outs[12:])
+    assert st.get("skipped_steps", 0) == skipped and st.get("sched_debt", 0) == 0
+    assert sched.last_epoch == 15 - skipped                                        # one scheduler step per optimizer update
+    np.testing.assert_allclose(opt.param_groups[0]["lr"], 1e-3 * 0.99 ** (15 - skipped), rtol=1e-6)
