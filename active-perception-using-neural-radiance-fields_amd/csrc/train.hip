@@ -12,6 +12,7 @@
 //
 // Gradients of activations travel in fp16 scaled by `loss_scale` (tcnn does the same with its default scale of
 // 128); parameter gradients are accumulated and returned in fp32, un-scaled.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -247,11 +248,14 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradJob *__restrict__
                                                     int split, const half_t *__restrict__ act, int64_t n_cap, const int64_t *n_dev, int rows,
                                                     float inv_scale, float *g0, float *g1, float *g2, float *__restrict__ partials) {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= n_groups * split) return;
+    // a workgroup = four consecutive groups on the SAME range of tiles: groups of one matrix share operand tiles (each dOut / In tile of a hidden matrix is read by
+    // two of its four groups), and read by waves of one workgroup at about the same time the second read is a cache hit instead of a second trip to HBM
+    const int grp = (blockIdx.x / split) * 4 + (threadIdx.x >> 6);
+    const int part = blockIdx.x % split;
+    if (grp >= n_groups) return;
+    const int wid = grp * split + part;                       // slot of this wave's partial sums (deterministic mode)
     const int64_t n_tiles = (count_here(n_cap, n_dev) + 63) / 64;
-    const WgradGroup gp = groups[wid / split];
-    const int part = wid % split;
+    const WgradGroup gp = groups[grp];
     const int64_t t0 = n_tiles * part / split, t1 = n_tiles * (part + 1) / split;
     const int r = lane & 31, h = lane >> 5;
     const bool o2 = gp.no > 1, i2 = gp.ni > 1;   // wave-uniform
@@ -861,8 +865,10 @@ static TrainTables build_tables(int C) {
         return first;
     };
     matrix(0, b_in, W, 64, 64, T::rdZ0, W / 32, T::rX, 2, C_IDENT);
+    const size_t hid_g0 = tt.groups.size();
     for (int l = 0; l < NH - 1; ++l)
         matrix(0, b_hid + (int64_t)l * W * W, W, W, W, T::rdZ0 + (l + 1) * W, W / 32, T::rH0 + l * W, W / 32, C_IDENT);
+    const size_t hid_g1 = tt.groups.size();
     matrix(0, b_out, 16, W, W, T::rdBO, 1, T::rH0 + (NH - 1) * W, W / 32, C_IDENT);
     // rgb head: in = [SH(16) | geo fragment(16)] (contiguous rows rS..rS+31): SH rows map to columns 0..15
     {
@@ -875,6 +881,9 @@ static TrainTables build_tables(int C) {
     matrix(2, s_in, Wh, 16, 16, T::rdZs1, Wh / 32, T::rG, 1, C_GEO_SEM);
     matrix(2, s_hid, Wh, Wh, Wh, T::rdZs2, Wh / 32, T::rHS1, Wh / 32, C_IDENT);
     matrix(2, s_out, sem_pad, Wh, Wh, T::rdYs, 1, T::rHS2, Wh / 32, C_IDENT);
+    // wgrad_kernel runs four consecutive groups in one workgroup on the same tiles: the groups of a hidden matrix (W = 128: 2 x 2 groups that share every operand tile
+    // pairwise) go first, so that a set of four is one hidden matrix; behind them base-in (two groups, same In tiles) + base-out (two groups, same dOut tile), then the heads
+    std::rotate(tt.groups.begin(), tt.groups.begin() + hid_g0, tt.groups.begin() + hid_g1);
     return tt;
 }
 
@@ -1194,7 +1203,7 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     static const bool no_wgrad = diag_env("MNF_NO_WGRAD") != nullptr;    // timing experiments: the scatter alone on the chip
     if (!no_wgrad && !fused) {
         ProfScope ps("wgrad", s);
-        hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * split, 4)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
+        hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(ceil_div(n_groups, 4) * split)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
                            split, v.act, n, n_dev, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem, partials);
         if (partials)
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * 4 * 1024, 256)), dim3(256), 0, s, ts->d_jobs, ts->d_groups,
