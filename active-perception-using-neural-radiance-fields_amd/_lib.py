@@ -79,6 +79,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_field_optimizer_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p,
                                            c_int32, c_void_p, c_void_p]),
+    "mnf_field_optimizer_step_report": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p,
+                                           c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_count_nan": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_scan_workspace_bytes": (c_int64, [c_int64]),
     "mnf_pack_info": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -1412,8 +1412,15 @@ __global__ void __launch_bounds__(256) count_nan3_kernel(const Adam3 a, int32_t 
     }
     if (__ballot(local != 0) != 0ull && local) atomicAdd(count, local);
 }
-__global__ void adam_prepare3_kernel(const Adam3 a, const int32_t *__restrict__ skip, float lr, float beta1, float beta2, float *__restrict__ hyper) {
+__global__ void adam_prepare3_kernel(const Adam3 a, const int32_t *__restrict__ skip, float lr, float beta1, float beta2, float *__restrict__ hyper,
+                                     const int64_t *__restrict__ counts, long long *__restrict__ report) {
     const int k = threadIdx.x;
+    // the step's report to the host, written straight into pinned host memory: the train step's four counters and its FINAL skip flag (this launch runs behind
+    // the non-finite count).  Two device-to-host copies did this before; each cost the stream ~5 us of copy plus ~18 us of bubble around it.
+    if (report && k >= 3 && k < 8) {
+        report[k - 3] = k < 7 ? (counts ? (long long)counts[k - 3] : 0ll) : (long long)(skip ? *skip : 0);
+        __threadfence_system();
+    }
     if (k >= 3) return;
     const bool sk = skip && *skip != 0;
     float st = *a.step[k];
@@ -1569,9 +1576,9 @@ extern "C" int mnf_adam_step_guarded(float *params, const float *grads, float *e
 
 // pipeline.py:520-532 for one model as ONE call: the non-finite-gradient guard over the three parameter vectors, the three Adam updates
 // (skipped on the device when the flag is raised) with the fp16 table mirror, and the handle's MLP fragments re-derived.
-extern "C" int mnf_field_optimizer_step(mnf_field_t f, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
-                                        float *const *exp_avg_sq_host, float *const *step_dev_host, float lr, float beta1, float beta2, float eps,
-                                        int32_t *skip_dev, int32_t count_nonfinite, float *hyper_dev, mnf_stream_t stream) {
+static int optimizer_step_impl(mnf_field_t f, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                               float *const *exp_avg_sq_host, float *const *step_dev_host, float lr, float beta1, float beta2, float eps,
+                               int32_t *skip_dev, int32_t count_nonfinite, float *hyper_dev, const int64_t *counts_dev, int64_t *report_host, mnf_stream_t stream) {
     MNF_REQUIRE(f && params_host && grads_host && exp_avg_host && exp_avg_sq_host && step_dev_host && hyper_dev, "field_optimizer_step: null argument");
     MNF_REQUIRE(f->params_loaded, "field_optimizer_step: the handle holds no parameters yet (mnf_field_set_params)");
     const int64_t n[3] = {f->n_base, f->n_head, f->n_sem};
@@ -1588,13 +1595,30 @@ extern "C" int mnf_field_optimizer_step(mnf_field_t f, float *const *params_host
         const int64_t blocks = ceil_div(total, 256 * 4 * 4);
         hipLaunchKernelGGL(count_nan3_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, a, skip_dev);
     }
-    hipLaunchKernelGGL(adam_prepare3_kernel, dim3(1), dim3(64), 0, s, a, (const int32_t *)skip_dev, lr, beta1, beta2, hyper_dev);
+    hipLaunchKernelGGL(adam_prepare3_kernel, dim3(1), dim3(64), 0, s, a, (const int32_t *)skip_dev, lr, beta1, beta2, hyper_dev, counts_dev,
+                       reinterpret_cast<long long *>(report_host));
     const int64_t blocks = ceil_div(total, 256 * 4 * 2);
     hipLaunchKernelGGL(adam_guarded3_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, a, beta1, beta2, eps, (const float *)hyper_dev,
                        reinterpret_cast<_Float16 *>(f->d_table), (int64_t)f->n_base_mlp);
     int rc = launch_status("adam_guarded3_kernel");
     if (rc) return rc;
     return mnf_field_refresh_weights(f, params_host[0], params_host[1], params_host[2], stream);
+}
+
+extern "C" int mnf_field_optimizer_step(mnf_field_t f, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                                        float *const *exp_avg_sq_host, float *const *step_dev_host, float lr, float beta1, float beta2, float eps,
+                                        int32_t *skip_dev, int32_t count_nonfinite, float *hyper_dev, mnf_stream_t stream) {
+    return optimizer_step_impl(f, params_host, grads_host, exp_avg_host, exp_avg_sq_host, step_dev_host, lr, beta1, beta2, eps, skip_dev, count_nonfinite, hyper_dev,
+                               nullptr, nullptr, stream);
+}
+
+extern "C" int mnf_field_optimizer_step_report(mnf_field_t f, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                                               float *const *exp_avg_sq_host, float *const *step_dev_host, float lr, float beta1, float beta2, float eps,
+                                               int32_t *skip_dev, int32_t count_nonfinite, float *hyper_dev, const int64_t *counts_dev, int64_t *report_host,
+                                               mnf_stream_t stream) {
+    MNF_REQUIRE(report_host, "field_optimizer_step_report: null report buffer");
+    return optimizer_step_impl(f, params_host, grads_host, exp_avg_host, exp_avg_sq_host, step_dev_host, lr, beta1, beta2, eps, skip_dev, count_nonfinite, hyper_dev,
+                               counts_dev, report_host, stream);
 }
 
 extern "C" int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf_stream_t stream) {

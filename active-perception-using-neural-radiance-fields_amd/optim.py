@@ -46,7 +46,7 @@ class FusedAdam(torch.optim.Optimizer):
             st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
         return st
 
-    def _step_field(self, field, skip, count_nonfinite):
+    def _step_field(self, field, skip, count_nonfinite, report=None):
         """The bound field's three vectors in ONE C call (`mnf_field_optimizer_step`): guard, three updates, fragment refresh."""
         lib = L.load_library()
         ps = [field.mlp_base.params, field.mlp_head.params, field.mlp_sem.params]
@@ -60,16 +60,25 @@ class FusedAdam(torch.optim.Optimizer):
             hy = self._scratch["field"] = torch.zeros(12, dtype=torch.float32, device=dev)
         arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
         beta1, beta2 = group["betas"]
-        L.launch(lib.mnf_field_optimizer_step, handle, arr(ps), arr(grads), arr([s_["exp_avg"] for s_ in sts]), arr([s_["exp_avg_sq"] for s_ in sts]),
-                 arr([s_["step"] for s_ in sts]), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), L.ptr(skip), int(count_nonfinite), L.ptr(hy))
+        common = (handle, arr(ps), arr(grads), arr([s_["exp_avg"] for s_ in sts]), arr([s_["exp_avg_sq"] for s_ in sts]),
+                  arr([s_["step"] for s_ in sts]), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), L.ptr(skip), int(count_nonfinite), L.ptr(hy))
+        if report is not None:      # (device counters or None, pinned host int64[5]): the step-count kernel writes counts + final skip flag into host memory
+            counts, host = report
+            L.launch(lib.mnf_field_optimizer_step_report, *common, L.ptr(counts), ctypes.c_void_p(host.data_ptr()))
+            self.reported = True
+        else:
+            L.launch(lib.mnf_field_optimizer_step, *common)
         for p in ps:
             torch.autograd.graph.increment_version(p)
         field._mark_current()
 
     @torch.no_grad()
-    def step(self, closure=None, skip=None, count_nonfinite=False):
+    def step(self, closure=None, skip=None, count_nonfinite=False, report=None):
         """`skip`: optional device int32 scalar; non-zero = leave every parameter, moment and step count untouched.
-        `count_nonfinite=True` (needs `skip`): the NaN / Inf count of the gradients is added to `skip` first (pipeline.py:520-529)."""
+        `count_nonfinite=True` (needs `skip`): the NaN / Inf count of the gradients is added to `skip` first (pipeline.py:520-529).
+        `report=(counts_dev or None, pinned int64[5])`: with a bound field the call also writes the train step's four counters and the final skip flag into the
+        pinned buffer (`mnf_field_optimizer_step_report`); `self.reported` says whether it did."""
+        self.reported = False
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -79,7 +88,7 @@ class FusedAdam(torch.optim.Optimizer):
         if field is not None and field.mlp_base.params.is_cuda and len(self.param_groups) == 1 and all(
                 p.grad is not None and p.dtype == torch.float32 and p.is_contiguous() for p in (field.mlp_base.params, field.mlp_head.params, field.mlp_sem.params)) and all(
                 q.numel() == 0 or any(q is p for p in (field.mlp_base.params, field.mlp_head.params, field.mlp_sem.params)) for q in self.param_groups[0]["params"]):
-            self._step_field(field, skip, count_nonfinite)
+            self._step_field(field, skip, count_nonfinite, report)
             return loss
         if count_nonfinite:
             count_nan_gradients([p for g_ in self.param_groups for p in g_["params"]], out=skip)

@@ -450,7 +450,7 @@ def presample(radiance_field, estimator, rays: Rays, near_plane=0.1, far_plane=1
 @torch.no_grad()
 def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, sem, render_bkgd=None, near_plane=0.1, far_plane=1e10,
                            render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, early_stop_eps=1e-4, stratified=None, sync=True,
-                           deterministic=False, presampled: "Presample | None" = None, seed: "int | None" = None):
+                           deterministic=False, presampled: "Presample | None" = None, seed: "int | None" = None, _defer_report=False):
     """scripts/pipeline.py:472-518 for one model as ONE C call (`mnf_train_step`, csrc/trainstep.hip): train render (occupancy
     sampling + density pre-pass + visibility filter + sem_rendering), the three-term loss and its backward.  Fills `.grad` of
     the three flat parameter vectors.  The call itself never waits for the GPU: the sample counts stay on the device.
@@ -564,9 +564,12 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         pool = st.setdefault("pinned", [])                         # (pinned host buffer, event) pairs are recycled: at most 3 are in flight
         host, ev = pool.pop() if pool else (torch.zeros(5, dtype=torch.int64).pin_memory(), torch.cuda.Event())
         host[4] = 0                                                 # (slot 4: the step's final skip flag, filled by train_step behind the optimizer's guard)
-        host[:4].copy_(counts, non_blocking=True)
-        ev.record(torch.cuda.current_stream(dev))
-        st["pending"].append((host, ev, R))
+        if _defer_report:
+            out["_report"] = (host, ev, R)                          # train_step: the optimizer call writes counters + final skip flag into `host`, no copy on the stream
+        else:
+            host[:4].copy_(counts, non_blocking=True)
+            ev.record(torch.cuda.current_stream(dev))
+            st["pending"].append((host, ev, R))
         estimator.last_sampling = {"n_marched": counts[0]}
         out.update(n_rendering_samples=counts[1], n_marched=counts[0])
     return out
@@ -616,7 +619,8 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     if fused:
         out = fused_forward_backward(radiance_field, estimator, rays, pixels, dep, sem, render_bkgd, near_plane=near_plane,
                                      render_step_size=render_step_size, cone_angle=cone_angle, alpha_thre=alpha_thre, sync=sync,
-                                     stratified=stratified, deterministic=deterministic, presampled=presampled, seed=seed)
+                                     stratified=stratified, deterministic=deterministic, presampled=presampled, seed=seed,
+                                     _defer_report=(not sync and device_guard))
     if out is not None:
         n_rendering_samples = out["n_rendering_samples"]
         loss, loss_rgb, loss_dep, loss_sem = out["loss"], out["loss_rgb"], out["loss_dep"], out["loss_sem"]
@@ -647,15 +651,19 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     if device_guard:
         # pipeline.py:520-532: the non-finite count is added to the same flag and the update leaves everything untouched when it is
         # raised — one C call for guard + three updates + handle refresh when the optimizer is bound to the field (`bind_field`)
-        optimizer.step(skip=skip, count_nonfinite=True)
+        rep_ = out.get("_report") if out is not None else None
+        optimizer.step(skip=skip, count_nonfinite=True, report=(out["counts"], rep_[0]) if rep_ is not None else None)
         if not sync:
             st = _train_state(radiance_field)
-            if out is not None and st["pending"]:
-                # the step's FINAL skip flag (the optimizer's non-finite guard included) travels with its counts; when it arrives — one or two calls later — a
-                # skipped step takes back the scheduler step it was given here: the schedule counts optimizer updates, as pipeline.py:491 / :520-532 do
-                host, ev, _ = st["pending"][-1]
-                host[4:5].copy_(skip.reshape(1), non_blocking=True)
+            # the step's counters and its FINAL skip flag (the optimizer's non-finite guard included) travel to pinned host memory; when they arrive — one or two
+            # calls later — a skipped step takes back the scheduler step it was given here: the schedule counts optimizer updates, as pipeline.py:491 / :520-532 do
+            if rep_ is not None:
+                host, ev, r_ = rep_
+                if not optimizer.reported:                         # (an optimizer not bound to the field: the copies the bound one's step-count kernel replaces)
+                    host[:4].copy_(out["counts"], non_blocking=True)
+                    host[4:5].copy_(skip.reshape(1).to(torch.int64), non_blocking=True)
                 ev.record(torch.cuda.current_stream(rays.origins.device))
+                st["pending"].append((host, ev, r_))
             if scheduler is not None:
                 if st.get("sched_debt", 0) > 0:
                     st["sched_debt"] -= 1

@@ -148,6 +148,14 @@ int mnf_adam_step_guarded(float *params, const float *grads, float *exp_avg, flo
 int mnf_field_optimizer_step(mnf_field_t f, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
                              float *const *exp_avg_sq_host, float *const *step_dev_host, float lr, float beta1, float beta2, float eps,
                              int32_t *skip_dev, int32_t count_nonfinite, float *hyper_dev, mnf_stream_t stream);
+/* The same call with the step's report to the host: counts_dev (mnf_train_step's 4 device counters, or NULL) and the final value of *skip_dev are written by the
+ * step-count kernel straight into report_host — 5 x int64 of PINNED host memory (device-accessible) — behind the non-finite count: an asynchronous training loop
+ * learns sample counts and skipped steps without a device-to-host copy on the stream (each such copy cost the stream ~25 us).  Readable once an event recorded
+ * behind the call has completed. */
+int mnf_field_optimizer_step_report(mnf_field_t f, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                                    float *const *exp_avg_sq_host, float *const *step_dev_host, float lr, float beta1, float beta2, float eps,
+                                    int32_t *skip_dev, int32_t count_nonfinite, float *hyper_dev, const int64_t *counts_dev,
+                                    int64_t *report_host, mnf_stream_t stream);
 
 /* Adds the number of NaN / Inf entries of `values` to *count (device int32): the gradient guard of pipeline.py:520-529. */
 int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf_stream_t stream);
