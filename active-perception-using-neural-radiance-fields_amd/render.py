@@ -447,6 +447,35 @@ def presample(radiance_field, estimator, rays: Rays, near_plane=0.1, far_plane=1
     return tok
 
 
+def presampled_batches(batches, radiance_field, estimator, first_step: int = 0, refresh_every: int = 16, **render_kw):
+    """The reference loop's batches with the march of each one done an iteration early: wraps any iterable of batches (each a tuple or list whose first element is
+    the batch's `Rays`) and yields `(step, batch, token)`; pass `presampled=token` to `train_step`.  The next batch is drawn from `batches` and its march enqueued
+    (`presample`) BEFORE the current one is yielded, i.e. before the caller enqueues the current step, beside which it then runs.  Batches on either side of an
+    occupancy refresh (`step % refresh_every == 0`, as `update_every_n_steps`) are not presampled — their steps march themselves.  `render_kw`: the render
+    options the steps will use (near_plane, render_step_size, cone_angle, alpha_thre, stratified).
+
+        for step, (rays, pixels, dep, sem), tok in presampled_batches(loader, field, est, **RENDER_KW):
+            train_step(field, est, opt, rays, pixels, dep, sem, bkgd, step=step, sync=False, presampled=tok, **RENDER_KW)"""
+    it = iter(batches)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    step, tok = first_step, None
+    while True:
+        try:
+            nxt = next(it)
+        except StopIteration:
+            nxt = None
+        nxt_tok = None
+        if nxt is not None and step % refresh_every and (step + 1) % refresh_every:
+            nxt_tok = presample(radiance_field, estimator, nxt[0], **render_kw)
+        yield step, cur, tok
+        if nxt is None:
+            return
+        cur, tok, step = nxt, nxt_tok, step + 1
+
+
 @torch.no_grad()
 def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, sem, render_bkgd=None, near_plane=0.1, far_plane=1e10,
                            render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01, early_stop_eps=1e-4, stratified=None, sync=True,

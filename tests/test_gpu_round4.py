@@ -362,6 +362,23 @@ def test_presampled_steps_are_bitwise_the_steps_that_march_themselves():
         np.testing.assert_allclose([l for l, _ in h_b], [l for l, _ in h_a], rtol=1e-6)            # (the loss scalar is a float-atomic sum over ray blocks)
         for a, b in zip(p_a, p_b):
             assert torch.equal(a, b)
+    # the loop helper: same trajectory again (jitter seeds differ from run to run here, so stratified=False), tokens adopted except around the refresh
+    def run_helper(pre):
+        f, e = H.hip_field(sc).train(), H.hip_estimator(sc)
+        opt = FusedAdam(f.parameters(), lr=1e-3, eps=1e-15).bind_field(f)
+        RD.reserve_sample_bounds(f, 1 << 21, 1 << 20)
+        adopted, ns = 0, []
+        src = RD.presampled_batches(data[:steps], f, e, first_step=14, stratified=False, **kw) if pre else ((14 + k, b, None) for k, b in enumerate(data[:steps]))
+        for step, b, tok in src:
+            torch.manual_seed(1000 + step)
+            out = RD.train_step(f, e, opt, *b, step=step, sync=False, deterministic=True, stratified=False, presampled=tok, **kw)
+            adopted += int(tok is not None and tok.adopted)
+            ns.append(out["n_rendering_samples"])
+        torch.cuda.synchronize()
+        return [int(n) for n in ns], [p.detach().clone() for p in f.parameters() if p.numel()], adopted
+    n_p, p_p, adopted = run_helper(True)
+    n_q, p_q, _ = run_helper(False)
+    assert adopted == steps - 3 and n_p == n_q and all(torch.equal(a, b) for a, b in zip(p_p, p_q))      # (no token for the first batch, none around step 16)
     # the C boundary: a handle made for other rays is refused (MNF_ERR_INVALID), not silently used
     f, e = H.hip_field(sc).train(), H.hip_estimator(sc)
     opt = FusedAdam(f.parameters(), lr=1e-3, eps=1e-15).bind_field(f)
