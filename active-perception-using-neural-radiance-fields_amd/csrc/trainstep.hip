@@ -53,16 +53,33 @@ __device__ __forceinline__ U4 philox4x32_10(U4 ctr, uint32_t k0, uint32_t k1) {
 
 // occ_grid.py:181-189: near / far planes, stratified jitter near += U[0,1) * step (Philox counter (ray, 0, 7, 0), key = seed)
 // Also the step's small zero-fills (loss terms, counters, skip flag, the two small gradient vectors): five separate memsets were five launches of ~5 us.
+// The step's fills: what were seven memsets (losses, counters, skip flag, the three gradient vectors, the pre-pass's density array and its work counter) — launches of ~5 us
+// each, the 50 MB one with a ~13 us bubble in front of it.
+struct StepFills {
+    float *g_base, *g_head, *g_sem, *sigma;
+    int64_t n_base, n_head, n_sem, n_sigma;
+    int32_t *ray_counter;
+};
+__device__ __forceinline__ void fill_zero(float *p, int64_t n, int64_t tid, int64_t threads) {
+    if (!p) return;
+    const int64_t head = ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) / 4;      // floats in front of the first 16-byte boundary
+    const int64_t h = head < n ? head : n;
+    for (int64_t i = tid; i < h; i += threads) p[i] = 0.f;
+    float4 *q = reinterpret_cast<float4 *>(p + h);
+    const int64_t nq = (n - h) / 4;
+    for (int64_t i = tid; i < nq; i += threads) q[i] = float4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = h + nq * 4 + tid; i < n; i += threads) p[i] = 0.f;
+}
 __global__ void __launch_bounds__(256) planes_kernel(int32_t n, float near_plane, float far_plane, float step, int32_t stratified, uint32_t s0,
                                                      uint32_t s1, float *__restrict__ nearp, float *__restrict__ farp, float *__restrict__ losses,
-                                                     int64_t *__restrict__ counts, int32_t *__restrict__ skip, float *__restrict__ g_head, int64_t n_head,
-                                                     float *__restrict__ g_sem, int64_t n_sem) {
+                                                     int64_t *__restrict__ counts, int32_t *__restrict__ skip, const StepFills z) {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (losses) {      // (NULL: a presample — the planes only; nearp NULL: a presampled step — the zero-fills only)
         if (r < 4) { losses[r] = 0.f; counts[r] = 0; }
-        if (r == 0) *skip = 0;
-        for (int64_t i = r; i < n_head; i += (int64_t)gridDim.x * blockDim.x) g_head[i] = 0.f;
-        for (int64_t i = r; i < n_sem; i += (int64_t)gridDim.x * blockDim.x) g_sem[i] = 0.f;
+        if (r == 0) { *skip = 0; if (z.ray_counter) *z.ray_counter = 0; }
+        const int64_t threads = (int64_t)gridDim.x * blockDim.x;
+        fill_zero(z.g_base, z.n_base, r, threads); fill_zero(z.g_head, z.n_head, r, threads); fill_zero(z.g_sem, z.n_sem, r, threads);
+        fill_zero(z.sigma, z.n_sigma, r, threads);
     }
     if (r >= n || !nearp) return;
     float v = near_plane;
@@ -296,16 +313,17 @@ SampleWs carve_sample(char *base, int64_t R, int32_t cap) {
     return w;
 }
 
+inline int fill_blocks(int rblocks) { return rblocks > 2048 ? rblocks : 2048; }      // enough threads for the 50 MB gradient fill (16 bytes per thread and pass)
+
 // near planes, alpha threshold, march, per-ray offsets, longest ray: everything of a step that reads the rays and the occupancy grid but not the parameters
 int sample_stage(const SampleWs &w, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y, int32_t res_z,
                  const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays, const mnf_train_opts *opts, float *losses,
-                 int64_t *counts_dev, int32_t *skip_dev, float *g_head, int64_t n_head, float *g_sem, int64_t n_sem, hipStream_t s) {
+                 int64_t *counts_dev, int32_t *skip_dev, const StepFills &fills, hipStream_t s) {
     const int64_t cells = (int64_t)res_x * res_y * res_z;
     const int rblocks = (n_rays + 255) / 256;
     const int32_t cap = scratch_cap(n_rays);
-    hipLaunchKernelGGL(planes_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
-                       opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp, losses, counts_dev, skip_dev, g_head,
-                       n_head, g_sem, n_sem);
+    hipLaunchKernelGGL(planes_kernel, dim3(losses ? fill_blocks(rblocks) : rblocks), dim3(256), 0, s, n_rays, opts->near_plane, opts->far_plane, opts->render_step_size,
+                       opts->stratified, (uint32_t)opts->seed, (uint32_t)(opts->seed >> 32), w.nearp, w.farp, losses, counts_dev, skip_dev, fills);
     double *mean_part = reinterpret_cast<double *>(w.totals + 8);          // 128 doubles behind the counters
     const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
     hipLaunchKernelGGL(mean_partial_kernel, dim3(128), dim3(256), 0, s, occs, cells * n_levels, mean_part);          // occ_grid.py:192: the mean over every level
@@ -375,8 +393,7 @@ extern "C" int mnf_train_presample(mnf_presample_t p, const uint8_t *binaries, c
     // fork: the side stream continues from the caller's stream as it is NOW — in front of whatever the caller enqueues next (the step this march is to hide behind)
     MNF_HIP(hipEventRecord(p->ev_ready, s));
     MNF_HIP(hipStreamWaitEvent(ss, p->ev_ready, 0));
-    const int rc = sample_stage(w, binaries, bitgrid, occs, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, nullptr, nullptr, nullptr, nullptr, 0,
-                                nullptr, 0, ss);
+    const int rc = sample_stage(w, binaries, bitgrid, occs, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, nullptr, nullptr, nullptr, StepFills{}, ss);
     MNF_HIP(hipEventRecord(p->ev_done, ss));
     p->launched = 1;
     if (rc) return rc;
@@ -402,12 +419,13 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     if (workspace_bytes < w.bytes) { set_error("train_step: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)w.bytes); return MNF_ERR_WORKSPACE; }
     const int C = f->cfg.num_semantic_classes;
     const int rblocks = (n_rays + 255) / 256;
-    MNF_HIP(hipMemsetAsync(g_base, 0, (size_t)f->n_base * 4, s));           // (losses, counters, skip flag, g_head, g_sem: zeroed by planes_kernel)
+    // (losses, counters, skip flag, the three gradient vectors, the pre-pass's density array and work counter: zeroed by planes_kernel)
     int64_t *eff = w.totals + 4;                                           // [0] marched, [1] kept samples the kernels behind the guards work on
     // ---- occupancy sampling (occ_grid.py:80-238): march, density pre-pass, visibility filter
     const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
     MNF_REQUIRE(n_levels <= 4, "train_step: at most 4 occupancy levels");
     int rc = 0;
+    StepFills fills = {g_base, g_head, g_sem, w.sigma, (int64_t)f->n_base, (int64_t)f->n_head, (int64_t)f->n_sem, max_marched, nullptr};
     if (const mnf_presample_s *pre = opts->presampled) {
         // the march of THIS batch ran earlier, on a side stream beside the previous step (mnf_train_presample): adopt what it left, after its last kernel
         MNF_REQUIRE(pre->valid && pre->rays_o == rays_o && pre->rays_d == rays_d && pre->n_rays == n_rays && pre->binaries == binaries && pre->seed == opts->seed &&
@@ -421,12 +439,13 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
         w.scratch_ts = sw.scratch_ts; w.scratch_te = sw.scratch_te;
         eff = w.totals + 4;
         const_cast<mnf_presample_s *>(pre)->valid = 0;      // (the guards below may clear its counts: one use)
-        hipLaunchKernelGGL(planes_kernel, dim3(rblocks), dim3(256), 0, s, 0, 0.f, 0.f, 0.f, 0, 0u, 0u, (float *)nullptr, (float *)nullptr, losses, counts_dev,
-                           skip_dev, g_head, (int64_t)f->n_head, g_sem, (int64_t)f->n_sem);
+        fills.ray_counter = reinterpret_cast<int32_t *>(w.totals + 7);
+        hipLaunchKernelGGL(planes_kernel, dim3(fill_blocks(rblocks)), dim3(256), 0, s, 0, 0.f, 0.f, 0.f, 0, 0u, 0u, (float *)nullptr, (float *)nullptr, losses, counts_dev,
+                           skip_dev, fills);
     } else {
         const SampleWs sw = {w.nearp, w.farp, w.alpha_thre, w.scratch_ts, w.scratch_te, w.counts, w.starts, w.totals, w.scan, 0};
-        rc = sample_stage(sw, binaries, bitgrid, occs, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, losses, counts_dev, skip_dev, g_head,
-                          (int64_t)f->n_head, g_sem, (int64_t)f->n_sem, s);
+        fills.ray_counter = reinterpret_cast<int32_t *>(w.totals + 7);
+        rc = sample_stage(sw, binaries, bitgrid, occs, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, losses, counts_dev, skip_dev, fills, s);
         if (rc) return rc;
     }
     // a ray longer than its scratch row would have been truncated (the rows hold `cap` samples; the reference configurations stay far
@@ -442,7 +461,13 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
         io.n = max_marched; io.n_dev64 = eff; io.density = w.sigma;
         rc = launch_field(f, io, true, s);
     } else {
-        rc = mnf_field_density_rays(f, rays_o, rays_d, w.ray, w.ts, w.te, w.starts, w.counts, n_rays, max_marched, opts->early_stop_eps, w.sigma, stream);
+        // mnf_field_density_rays without its two memsets (density array, work counter: planes_kernel's fills): ray-major, skips what lies behind T < eps / 2
+        FieldIO io = {};
+        io.mode = 3; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = w.ray; io.t_starts = w.ts; io.t_ends = w.te; io.n = max_marched;
+        io.chunk_starts = w.starts; io.chunk_cnts = w.counts; io.n_rays = n_rays; io.ray_counter = fills.ray_counter;
+        io.sdt_stop = opts->early_stop_eps > 0.0f ? -logf(opts->early_stop_eps) + 0.6931472f : INFINITY;
+        io.density = w.sigma;
+        rc = launch_field(f, io, true, s);
     }
     if (rc) return rc;
     const int vgrid = n_rays < 65535 ? n_rays : 65535;
