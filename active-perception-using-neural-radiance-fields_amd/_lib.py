@@ -130,9 +130,9 @@ SIGNATURES = {
                                                   c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_presample_create": (c_int32, [POINTER(c_void_p)]),
     "mnf_presample_destroy": (None, [c_void_p]),
-    "mnf_train_presample_workspace_bytes": (c_int64, [c_int32]),
+    "mnf_train_presample_workspace_bytes": (c_int64, [c_int32, c_int64]),
     "mnf_train_presample": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
-                                      POINTER(TrainOpts), c_void_p, c_int64, c_void_p]),
+                                      POINTER(TrainOpts), c_int64, c_void_p, c_int64, c_void_p]),
     "mnf_presample_wait": (c_int32, [c_void_p, c_void_p]),
     "mnf_train_step_workspace_bytes": (c_int64, [c_void_p, c_int32, c_int64, c_int64]),
     "mnf_train_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,

@@ -32,6 +32,7 @@ struct mnf_presample_s {
     int32_t n_rays = 0, stratified = 0, n_levels = 0, res[3] = {0, 0, 0};
     uint64_t seed = 0;
     float near_plane = 0.f, far_plane = 0.f, step = 0.f, cone = 0.f, alpha_thre = 0.f;
+    int64_t max_marched = 0;
     int valid = 0, launched = 0;
 };
 
@@ -59,6 +60,7 @@ struct StepFills {
     float *g_base, *g_head, *g_sem, *sigma;
     int64_t n_base, n_head, n_sem, n_sigma;
     int32_t *ray_counter;
+    const int64_t *adopt;      // a presampled step: the four counters its march's guard left (status bits != 0: the step is skipped), or NULL
 };
 __device__ __forceinline__ void fill_zero(float *p, int64_t n, int64_t tid, int64_t threads) {
     if (!p) return;
@@ -75,8 +77,8 @@ __global__ void __launch_bounds__(256) planes_kernel(int32_t n, float near_plane
                                                      int64_t *__restrict__ counts, int32_t *__restrict__ skip, const StepFills z) {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (losses) {      // (NULL: a presample — the planes only; nearp NULL: a presampled step — the zero-fills only)
-        if (r < 4) { losses[r] = 0.f; counts[r] = 0; }
-        if (r == 0) { *skip = 0; if (z.ray_counter) *z.ray_counter = 0; }
+        if (r < 4) { losses[r] = 0.f; counts[r] = z.adopt ? z.adopt[r] : 0; }
+        if (r == 0) { *skip = (z.adopt && z.adopt[3] != 0) ? 1 : 0; if (z.ray_counter) *z.ray_counter = 0; }
         const int64_t threads = (int64_t)gridDim.x * blockDim.x;
         fill_zero(z.g_base, z.n_base, r, threads); fill_zero(z.g_head, z.n_head, r, threads); fill_zero(z.g_sem, z.n_sem, r, threads);
         fill_zero(z.sigma, z.n_sigma, r, threads);
@@ -227,11 +229,13 @@ __global__ void __launch_bounds__(256) guard_marched_kernel(int32_t n_rays, int6
     const bool bad = tot > max_marched || longest > row_cap;
     if (bad && r < n_rays) { counts[r] = 0; starts[r] = 0; }
     if (r == 0) {
-        counts_dev[0] = tot; counts_dev[2] = longest;
         eff[0] = bad ? 0 : tot;
-        if (bad) {
-            atomicOr(reinterpret_cast<unsigned long long *>(counts_dev + 3), (unsigned long long)((tot > max_marched ? 1 : 0) | (longest > row_cap ? 2 : 0)));
-            atomicAdd(skip, 1);
+        const unsigned long long bits = (unsigned long long)((tot > max_marched ? 1 : 0) | (longest > row_cap ? 2 : 0));
+        if (!skip) {      // a presample: its own four counters (the step's planes_kernel adopts them: PreReport)
+            counts_dev[0] = tot; counts_dev[1] = 0; counts_dev[2] = longest; counts_dev[3] = (int64_t)bits;
+        } else {
+            counts_dev[0] = tot; counts_dev[2] = longest;
+            if (bad) { atomicOr(reinterpret_cast<unsigned long long *>(counts_dev + 3), bits); atomicAdd(skip, 1); }
         }
     }
 }
@@ -299,9 +303,10 @@ struct SampleWs {
     float *nearp, *farp, *alpha_thre, *scratch_ts, *scratch_te;
     int64_t *counts, *starts, *totals, *scan;
     int64_t bytes;
+    float *ts, *te; int64_t *ray;      // a presample's packed samples (max_marched > 0)
 };
 
-SampleWs carve_sample(char *base, int64_t R, int32_t cap) {
+SampleWs carve_sample(char *base, int64_t R, int32_t cap, int64_t max_marched = 0) {
     SampleWs w;
     size_t off = 0;
     auto take = [&](size_t b) { char *p = base ? base + off : nullptr; off += (b + 255) & ~(size_t)255; return p; };
@@ -309,9 +314,13 @@ SampleWs carve_sample(char *base, int64_t R, int32_t cap) {
     w.counts = (int64_t *)take(R * 8); w.starts = (int64_t *)take(R * 8);
     w.totals = (int64_t *)take(2048); w.scan = (int64_t *)take((size_t)mnf_scan_workspace_bytes(R));
     w.scratch_ts = (float *)take((size_t)R * cap * 4); w.scratch_te = (float *)take((size_t)R * cap * 4);
+    w.ts = w.te = nullptr; w.ray = nullptr;
+    if (max_marched > 0) { w.ts = (float *)take(max_marched * 4); w.te = (float *)take(max_marched * 4); w.ray = (int64_t *)take(max_marched * 8); }
     w.bytes = (int64_t)off;
     return w;
 }
+
+constexpr int kPreReport = 160;      // int64 words into a presample's `totals` block (2048 bytes: counters 0-7, 128 doubles of the mean from word 8): its guard's four counters
 
 inline int fill_blocks(int rblocks) { return rblocks > 2048 ? rblocks : 2048; }      // enough threads for the 50 MB gradient fill (16 bytes per thread and pass)
 
@@ -367,9 +376,9 @@ extern "C" void mnf_presample_destroy(mnf_presample_t p) {
     delete p;
 }
 
-extern "C" int64_t mnf_train_presample_workspace_bytes(int32_t n_rays) {
-    if (n_rays <= 0) return -1;
-    return carve_sample(nullptr, n_rays, scratch_cap(n_rays)).bytes;
+extern "C" int64_t mnf_train_presample_workspace_bytes(int32_t n_rays, int64_t max_marched) {
+    if (n_rays <= 0 || max_marched <= 0) return -1;
+    return carve_sample(nullptr, n_rays, scratch_cap(n_rays), max_marched).bytes;
 }
 
 extern "C" int mnf_presample_wait(mnf_presample_t p, mnf_stream_t stream) {
@@ -380,12 +389,13 @@ extern "C" int mnf_presample_wait(mnf_presample_t p, mnf_stream_t stream) {
 
 extern "C" int mnf_train_presample(mnf_presample_t p, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
                                    int32_t res_z, const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays,
-                                   const mnf_train_opts *opts, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
+                                   const mnf_train_opts *opts, int64_t max_marched, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
     MNF_REQUIRE(p && binaries && occs && aabb_host && rays_o && rays_d && opts && workspace, "train_presample: null pointer");
-    MNF_REQUIRE(n_rays > 0 && opts->render_step_size > 0.f, "train_presample: bad sizes");
+    MNF_REQUIRE(n_rays > 0 && max_marched > 0 && opts->render_step_size > 0.f, "train_presample: bad sizes");
     const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
     MNF_REQUIRE(n_levels <= 4, "train_presample: at most 4 occupancy levels");
-    const SampleWs w = carve_sample((char *)workspace, n_rays, scratch_cap(n_rays));
+    const int32_t cap = scratch_cap(n_rays);
+    const SampleWs w = carve_sample((char *)workspace, n_rays, cap, max_marched);
     if (workspace_bytes < w.bytes) { set_error("train_presample: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)w.bytes); return MNF_ERR_WORKSPACE; }
     hipStream_t s = as_stream(stream), ss = shared_side_stream(2);
     if (!ss) return MNF_ERR_HIP;
@@ -393,13 +403,18 @@ extern "C" int mnf_train_presample(mnf_presample_t p, const uint8_t *binaries, c
     // fork: the side stream continues from the caller's stream as it is NOW — in front of whatever the caller enqueues next (the step this march is to hide behind)
     MNF_HIP(hipEventRecord(p->ev_ready, s));
     MNF_HIP(hipStreamWaitEvent(ss, p->ev_ready, 0));
-    const int rc = sample_stage(w, binaries, bitgrid, occs, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, nullptr, nullptr, nullptr, StepFills{}, ss);
+    int rc = sample_stage(w, binaries, bitgrid, occs, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, nullptr, nullptr, nullptr, StepFills{}, ss);
+    if (!rc) {      // the bound check of the step (its four counters go to the handle's own words: the adopting step copies them) and the packing of the scratch rows
+        hipLaunchKernelGGL(guard_marched_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, ss, n_rays, w.counts, w.starts, (const int64_t *)w.totals, max_marched,
+                           (int64_t)cap, w.totals + 4, w.totals + kPreReport, (int32_t *)nullptr);
+        rc = mnf_compact_samples(w.scratch_ts, w.scratch_te, cap, w.starts, w.counts, n_rays, w.ts, w.te, w.ray, (mnf_stream_t)ss);
+    }
     MNF_HIP(hipEventRecord(p->ev_done, ss));
     p->launched = 1;
     if (rc) return rc;
     p->ws = workspace; p->rays_o = rays_o; p->rays_d = rays_d; p->binaries = binaries; p->n_rays = n_rays; p->seed = opts->seed; p->stratified = opts->stratified;
     p->n_levels = n_levels; p->near_plane = opts->near_plane; p->far_plane = opts->far_plane; p->step = opts->render_step_size; p->cone = opts->cone_angle;
-    p->alpha_thre = opts->alpha_thre; p->res[0] = res_x; p->res[1] = res_y; p->res[2] = res_z;
+    p->alpha_thre = opts->alpha_thre; p->res[0] = res_x; p->res[1] = res_y; p->res[2] = res_z; p->max_marched = max_marched;
     p->valid = 1;
     return MNF_OK;
 }
@@ -425,21 +440,22 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
     MNF_REQUIRE(n_levels <= 4, "train_step: at most 4 occupancy levels");
     int rc = 0;
-    StepFills fills = {g_base, g_head, g_sem, w.sigma, (int64_t)f->n_base, (int64_t)f->n_head, (int64_t)f->n_sem, max_marched, nullptr};
+    StepFills fills = {g_base, g_head, g_sem, w.sigma, (int64_t)f->n_base, (int64_t)f->n_head, (int64_t)f->n_sem, max_marched, nullptr, nullptr};
     if (const mnf_presample_s *pre = opts->presampled) {
         // the march of THIS batch ran earlier, on a side stream beside the previous step (mnf_train_presample): adopt what it left, after its last kernel
         MNF_REQUIRE(pre->valid && pre->rays_o == rays_o && pre->rays_d == rays_d && pre->n_rays == n_rays && pre->binaries == binaries && pre->seed == opts->seed &&
                     pre->stratified == opts->stratified && pre->n_levels == n_levels && pre->near_plane == opts->near_plane && pre->far_plane == opts->far_plane &&
                     pre->step == opts->render_step_size && pre->cone == opts->cone_angle && pre->alpha_thre == opts->alpha_thre &&
-                    pre->res[0] == res_x && pre->res[1] == res_y && pre->res[2] == res_z,
-                    "train_step: opts->presampled was made for other rays, options or another grid");
+                    pre->res[0] == res_x && pre->res[1] == res_y && pre->res[2] == res_z && pre->max_marched == max_marched,
+                    "train_step: opts->presampled was made for other rays, options, sample bound or another grid");
         MNF_HIP(hipStreamWaitEvent(s, pre->ev_done, 0));
-        const SampleWs sw = carve_sample((char *)pre->ws, n_rays, cap);
+        const SampleWs sw = carve_sample((char *)pre->ws, n_rays, cap, max_marched);
         w.nearp = sw.nearp; w.farp = sw.farp; w.alpha_thre = sw.alpha_thre; w.counts = sw.counts; w.starts = sw.starts; w.totals = sw.totals;
-        w.scratch_ts = sw.scratch_ts; w.scratch_te = sw.scratch_te;
+        w.scratch_ts = sw.scratch_ts; w.scratch_te = sw.scratch_te; w.ts = sw.ts; w.te = sw.te; w.ray = sw.ray;
         eff = w.totals + 4;
         const_cast<mnf_presample_s *>(pre)->valid = 0;      // (the guards below may clear its counts: one use)
         fills.ray_counter = reinterpret_cast<int32_t *>(w.totals + 7);
+        fills.adopt = w.totals + kPreReport;
         hipLaunchKernelGGL(planes_kernel, dim3(fill_blocks(rblocks)), dim3(256), 0, s, 0, 0.f, 0.f, 0.f, 0, 0u, 0u, (float *)nullptr, (float *)nullptr, losses, counts_dev,
                            skip_dev, fills);
     } else {
@@ -448,12 +464,14 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
         rc = sample_stage(sw, binaries, bitgrid, occs, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, losses, counts_dev, skip_dev, fills, s);
         if (rc) return rc;
     }
-    // a ray longer than its scratch row would have been truncated (the rows hold `cap` samples; the reference configurations stay far
-    // below) and more marched samples than `max_marched` would not fit the packed arrays: both end the step here, on the device
-    hipLaunchKernelGGL(guard_marched_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, w.counts, w.starts, (const int64_t *)w.totals, max_marched,
-                       (int64_t)cap, eff, counts_dev, skip_dev);
-    rc = mnf_compact_samples(w.scratch_ts, w.scratch_te, cap, w.starts, w.counts, n_rays, w.ts, w.te, w.ray, stream);
-    if (rc) return rc;
+    if (!opts->presampled) {      // (a presample has done both)
+        // a ray longer than its scratch row would have been truncated (the rows hold `cap` samples; the reference configurations stay far
+        // below) and more marched samples than `max_marched` would not fit the packed arrays: both end the step here, on the device
+        hipLaunchKernelGGL(guard_marched_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, w.counts, w.starts, (const int64_t *)w.totals, max_marched,
+                           (int64_t)cap, eff, counts_dev, skip_dev);
+        rc = mnf_compact_samples(w.scratch_ts, w.scratch_te, cap, w.starts, w.counts, n_rays, w.ts, w.te, w.ray, stream);
+        if (rc) return rc;
+    }
     static const bool prepass_flat = diag_env("MNF_PREPASS_FLAT") != nullptr;    // experiment: every marched sample, full lanes, no early termination
     if (prepass_flat) {
         FieldIO io = {};

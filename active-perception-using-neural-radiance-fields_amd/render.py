@@ -436,12 +436,13 @@ def presample(radiance_field, estimator, rays: Rays, near_plane=0.1, far_plane=1
     opts.stratified = int(radiance_field.training if stratified is None else stratified)
     opts.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
     tok = handle if handle is not None else Presample()
-    nbytes = int(lib.mnf_train_presample_workspace_bytes(R))
+    cap_m = _caps_for(_train_state(radiance_field), R)[0]      # the adopting step's bound on marched samples (the march's guard and compaction run here too)
+    nbytes = int(lib.mnf_train_presample_workspace_bytes(R, cap_m))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=o.device)
     L.launch(lib.mnf_train_presample, tok.handle, L.ptr(binaries), L.ptr(bits[0]), L.ptr(estimator.occs), res[0], res[1], res[2],
-             (ctypes.c_float * len(aabb))(*aabb), L.ptr(o), L.ptr(d), R, ctypes.byref(opts), L.ptr(ws), nbytes)
+             (ctypes.c_float * len(aabb))(*aabb), L.ptr(o), L.ptr(d), R, ctypes.byref(opts), cap_m, L.ptr(ws), nbytes)
     tok.keep = (o, d, ws, binaries, bits)
-    tok.seed, tok.R, tok.version = int(opts.seed), R, _grid_version(estimator)
+    tok.seed, tok.R, tok.version, tok.cap_m = int(opts.seed), R, _grid_version(estimator), cap_m
     tok.key = (float(near_plane), float(far_plane), float(render_step_size), float(cone_angle), float(alpha_thre), int(opts.stratified))
     tok.rays = (rays.origins, rays.viewdirs)
     return tok
@@ -563,7 +564,12 @@ def fused_forward_backward(radiance_field, estimator, rays: Rays, pixels, dep, s
         cap_m, cap_k = _caps_for(st, R)
         nbytes = int(lib.mnf_train_step_workspace_bytes(handle, R, cap_m, cap_k))
         ws = _workspace(dev, nbytes)
-        opts.presampled = presampled.handle if (use_pre and _attempt == 0) else None      # (a repeated step marches itself: the guards cleared the token's counts)
+        # (a repeated step marches itself: the guards cleared the token's counts; so does a step whose bound has grown since its token was made)
+        adopt = use_pre and _attempt == 0 and presampled.cap_m == cap_m
+        if use_pre and _attempt == 0 and not adopt:
+            use_pre = False
+            presampled.wait(dev)
+        opts.presampled = presampled.handle if adopt else None
         L.launch(lib.mnf_train_step, handle, L.ptr(binaries), L.ptr(bits[0]), L.ptr(estimator.occs), res[0], res[1], res[2],
                  (ctypes.c_float * len(aabb))(*aabb), L.ptr(o), L.ptr(d), R, L.ptr(tp), L.ptr(td), L.ptr(tl), ctypes.byref(opts),
                  L.ptr(params[0].grad), L.ptr(params[1].grad), L.ptr(params[2].grad), L.ptr(losses), L.ptr(counts), L.ptr(skip),

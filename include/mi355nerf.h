@@ -410,16 +410,16 @@ typedef struct {
  * side stream, forked from `stream` as it is at the call — call it BEFORE enqueuing the current iteration and it marches beside that iteration's kernels —
  * and mnf_train_step adopts the result when opts->presampled names the handle (it waits for the march on its own stream; same rays / options / seed / grid
  * pointers required, MNF_ERR_INVALID otherwise; one use).  Results are bit-identical to marching inside the step.  The caller keeps rays, grid and `workspace`
- * (mnf_train_presample_workspace_bytes(n_rays) device bytes) untouched until the adopting step has been enqueued, and must not refresh the occupancy grid in
+ * (mnf_train_presample_workspace_bytes(n_rays, max_marched) device bytes; max_marched: the adopting step's bound, checked there — the march's guard and the packing of its samples run in the presample too) untouched until the adopting step has been enqueued, and must not refresh the occupancy grid in
  * between without mnf_presample_wait (then simply do not pass the handle: the step marches itself).
  * Replaces nothing in the reference's call list: a scheduling entry point (the data loader's "next batch" prefetch applied to the sampler). */
 typedef struct mnf_presample_s *mnf_presample_t;
 int mnf_presample_create(mnf_presample_t *out);
 void mnf_presample_destroy(mnf_presample_t p);
-int64_t mnf_train_presample_workspace_bytes(int32_t n_rays);
+int64_t mnf_train_presample_workspace_bytes(int32_t n_rays, int64_t max_marched);
 int mnf_train_presample(mnf_presample_t p, const uint8_t *binaries, const uint32_t *bitgrid, const float *occs, int32_t res_x, int32_t res_y,
                         int32_t res_z, const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays,
-                        const mnf_train_opts *opts, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
+                        const mnf_train_opts *opts, int64_t max_marched, void *workspace, int64_t workspace_bytes, mnf_stream_t stream);
 /* make `stream` wait for the handle's march (no-op if none was launched) */
 int mnf_presample_wait(mnf_presample_t p, mnf_stream_t stream);
 

@@ -385,6 +385,7 @@ def test_presampled_steps_are_bitwise_the_steps_that_march_themselves():
     tok = RD.presample(f, e, data[1][0], **kw)
     tok.rays = (data[2][0].origins, data[2][0].viewdirs)
     tok.R = data[2][0].origins.shape[0]
+    tok.cap_m = RD._caps_for(RD._train_state(f), tok.R)[0]
     tok.keep = (L.contig(data[2][0].origins.reshape(-1, 3), torch.float32),) + tuple(tok.keep[1:])
     with pytest.raises(L.MnfError, match="presampled was made for other rays"):
         RD.train_step(f, e, opt, *data[2], step=3, deterministic=True, presampled=tok, **kw)
