@@ -422,3 +422,42 @@ def test_async_scheduler_counts_optimizer_updates_not_calls():
     assert st.get("skipped_steps", 0) == skipped and st.get("sched_debt", 0) == 0
     assert sched.last_epoch == 15 - skipped                                        # one scheduler step per optimizer update
     np.testing.assert_allclose(opt.param_groups[0]["lr"], 1e-3 * 0.99 ** (15 - skipped), rtol=1e-6)
+
+
+def test_presampled_step_beyond_its_marched_bound_is_skipped_like_a_step_that_marches_itself():
+    """The bound check of the march runs inside the presample (its own counters) and the adopting step copies them: a batch that marches more samples than `max_marched`
+    must come out of a presampled step exactly as out of a plain one — skip flag raised, status bit 1, the marched count reported, zero gradients, parameters untouched —
+    and the bounds must grow from the late report as they do without a presample."""
+    from apnrf_amd import render as RD
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene(log2_hashmap_size=15)
+    bk = torch.tensor([0.3, 0.6, 0.1], device=DEV)
+    o, d = H.view_rays(sc, 2, h=40, w=40)
+    rng = np.random.default_rng(5)
+    n = o.shape[0]
+    batch = (RD.Rays(o.to(DEV), d.to(DEV)), torch.from_numpy(rng.random((n, 3)).astype(np.float32)).to(DEV),
+             torch.from_numpy(rng.uniform(0.5, 4.0, n).astype(np.float32)).to(DEV), torch.from_numpy(rng.integers(0, sc["C"], n)).to(DEV), bk)
+    res = []
+    for pre in (False, True):
+        f, e = H.hip_field(sc).train(), H.hip_estimator(sc)
+        opt = FusedAdam(f.parameters(), lr=1e-3, eps=1e-15).bind_field(f)
+        st = RD._train_state(f)
+        st["by_R"][n] = (4096, 1 << 20)                                            # far fewer marched samples than this batch has
+        p0 = [p.detach().clone() for p in f.parameters() if p.numel()]
+        tok = RD.presample(f, e, batch[0], seed=7, stratified=False, **H.RENDER_KW) if pre else None
+        out = RD.fused_forward_backward(f, e, *batch[:4], render_bkgd=bk, sync=False, stratified=False, presampled=tok, seed=7, **H.RENDER_KW)
+        torch.cuda.synchronize()
+        assert (tok.adopted if pre else True)
+        counts, skip = out["counts"].tolist(), int(out["skip"])
+        g = [float(p.grad.abs().max()) for p in f.parameters() if p.numel()]
+        res.append((counts, skip, g))
+        assert skip >= 1 and counts[3] & 1 and counts[0] > 4096 and counts[1] == 0 and max(g) == 0.0
+        opt.step(skip=out["skip"], count_nonfinite=True)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(p0, [p.detach() for p in f.parameters() if p.numel()]))
+        # the late report grows the bounds: the next step of the same batch fits
+        tok = RD.presample(f, e, batch[0], seed=8, stratified=False, **H.RENDER_KW) if pre else None
+        out2 = RD.fused_forward_backward(f, e, *batch[:4], render_bkgd=bk, sync=False, stratified=False, presampled=tok, seed=8, **H.RENDER_KW)
+        torch.cuda.synchronize()
+        assert int(out2["skip"]) == 0 and int(out2["counts"][1]) > 3000 and int(out2["counts"][0]) == counts[0]
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
