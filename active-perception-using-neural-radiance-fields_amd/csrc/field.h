@@ -40,6 +40,7 @@ struct mnf_field_s {
     void *train_state;        // lazily built by train.hip (transposed fragments, weight-gradient job table)
     int bwd_mode = 0;         // mnf_field_set_backward_mode: 0 auto (fused backward where supported), 1 split kernels (dgrad + wgrad), 2 fused required
 };
+inline bool field_rows_supported(const mnf_field_s *f) { return f->cfg.neurons == 128 && !f->cfg.blend_fp16; }
 
 namespace mnf {
 
@@ -90,6 +91,12 @@ struct FieldIO {
     float *xn_out;                           // mode 1, optional: the aabb-normalised positions [n,3] (ngp.py:177-178) instead: the scatter's own input
     // ... or, in mode 2, composites straight into the renderer's per-ray accumulators
     FusedRender fr;
+    // The train step's two passes over the hash table made one (neurons = 128, fp32 blend: field_rows_supported): the density pre-pass (mode 3) leaves every sample's
+    // 64 encoded features behind as one 128-byte row, rows_out[sample] — exactly the 16-bit values its own MLP consumed — and the training forward (mode 1) reads
+    // row rows_src[k] of rows_in for its sample k (one cache line) instead of gathering 128 table entries again.
+    void *rows_out;
+    const void *rows_in;
+    const int64_t *rows_src;
 };
 
 // Training-time activation storage handed to the forward kernel (layout: field_dev.h, TrainLayout)

@@ -217,10 +217,12 @@ __device__ __forceinline__ FusedRender fr_of_kernarg() {
 
 // B16: the hash levels' 8-corner blend in tiny-cuda-nn's fp16 arithmetic (mnf_field_config.blend_fp16).  A template parameter, not a run-time branch: the
 // kernel sits at its register limits, and a wave-uniform `if` around the two blends cost the DEFAULT path 3 % (0.7116 -> 0.7325 ms per render launch).
-template <int W, int NH, int MODE, bool DENSITY_ONLY, int SAVEK = 0, bool ENC = false, bool B16 = false>
+template <int W, int NH, int MODE, bool DENSITY_ONLY, int SAVEK = 0, int ENC = 0, bool B16 = false>
 __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs args) {
     using L = Layout<W, NH>;
     using T = TrainLayout<W, NH>;
+    // ENC: 0 the kernel encodes; 1 the features come from encode_kernel's scratch in fragment order (two-launch diagnostic path); 2 they come from the rows the
+    // density pre-pass left (FieldIO::rows_in / rows_src: one 128-byte line per sample instead of 128 gathers); 3 the kernel encodes AND leaves those rows (rows_out)
     // SAVEK: 0 inference; 1 training with the full activation dump (split backward: dgrad + wgrad kernels); 2 training for the fused backward
     // (csrc/fused_bwd.h): only the encoded inputs leave the kernel — the hash features and the SH fragment, in B-fragment order, 160 B per sample
     constexpr bool SAVE = SAVEK == 1;
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     const int64_t n_tiles_all = (n + kWaveSamples - 1) / kWaveSamples;
     if (n_tiles_all == 0) return;
     int64_t tile0 = 0, n_tiles = n_tiles_all;
-    if (ENC && args.io.n_chunks > 1) { tile0 = n_tiles_all * args.io.chunk / args.io.n_chunks; n_tiles = n_tiles_all * (args.io.chunk + 1) / args.io.n_chunks; }
+    if (ENC == 1 && args.io.n_chunks > 1) { tile0 = n_tiles_all * args.io.chunk / args.io.n_chunks; n_tiles = n_tiles_all * (args.io.chunk + 1) / args.io.n_chunks; }
     const int wpb = MODE == 3 ? kWavesPerBlock : args.active_waves;
     const int64_t n_groups = (n_tiles - tile0 + wpb - 1) / wpb;
     int64_t g_first = 0, g_end = 1, g_step = 1;
@@ -316,7 +318,21 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         // ---- hash encode: all 16 levels of this lane's sample (one k-step = 4 levels = 32 gathers in flight),
         //      then trade halves with lane^32 ----
         half8 bfeat[CT][4];
-        if (ENC) {
+        if (ENC == 2) {
+            // this lane's sample: its row of 64 features as the pre-pass encoded them, eight 16-byte pieces of one line; then the usual trade with lane ^ 32
+            const bool have = valid;
+            const half8 *src = reinterpret_cast<const half8 *>(la.io.rows_in) + (have ? la.io.rows_src[col] : 0) * 8;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                half8 lo = src[2 * kb], hi = src[2 * kb + 1];
+                if (!have) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { lo[j] = (half_t)0.0f; hi[j] = (half_t)0.0f; }
+                }
+                exchange_halves(lo, hi);
+                bfeat[0][kb] = lo; bfeat[1][kb] = hi;
+            }
+        } else if (ENC == 1) {
             // features were produced by encode_kernel, already in fragment order
             const half8 *src = reinterpret_cast<const half8 *>(la.io.enc) + tile * 512 + lane;
 #pragma unroll
@@ -368,6 +384,12 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                     for (int q = 0; q < 4; ++q) hash_blend(prep[cur][q], v[cur][q], f + 4 * q);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
+                }
+                if (ENC == 3) {      // the sample's features 16 kb .. 16 kb + 15, as the MLP is about to see them
+                    if (valid) {
+                        half8 *dst = reinterpret_cast<half8 *>(la.io.rows_out) + col * 8 + 2 * kb;
+                        dst[0] = lo; dst[1] = hi;
+                    }
                 }
                 exchange_halves(lo, hi);
                 bfeat[0][kb] = lo; bfeat[1][kb] = hi;
@@ -653,12 +675,22 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
 #define MNF_LAUNCH_S(MODE, DO, SAVEK)                                                                                                                  \
     do {                                                                                                                                               \
         if constexpr (W == 128) {                                                                                                                      \
-            if (b16) { hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO, SAVEK, false, true>), dim3(grid), dim3(kThreads), 0, stream, a); break; }   \
+            if (b16) { hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO, SAVEK, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a); break; }   \
         }                                                                                                                                              \
-        hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO, SAVEK, false, false>), dim3(grid), dim3(kThreads), 0, stream, a);                           \
+        hipLaunchKernelGGL((field_kernel<W, NH, MODE, DO, SAVEK, 0, false>), dim3(grid), dim3(kThreads), 0, stream, a);                           \
     } while (0)
 #define MNF_LAUNCH(MODE, DO) MNF_LAUNCH_S(MODE, DO, 0)
-    if (train && train->xenc) {
+    // the feature rows of FieldIO (pre-pass writes, training forward reads): instantiated for neurons = 128 with the fp32 blend (field_rows_supported)
+    const bool rows_ok = W == 128 && !b16 && !io.enc;
+    if ((io.rows_in || io.rows_out) && !rows_ok) { set_error("field: feature rows are built for neurons = 128 with the fp32 blend"); return MNF_ERR_UNSUPPORTED; }
+    if (train && io.rows_in && io.mode == 1) {
+        if constexpr (W == 128) {
+            if (train->xenc) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 2, 2, false>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 1, 2, false>), dim3(grid), dim3(kThreads), 0, stream, a);
+        }
+    } else if (density_only && io.mode == 3 && io.rows_out) {
+        if constexpr (W == 128) hipLaunchKernelGGL((field_kernel<W, NH, 3, true, 0, 3, false>), dim3(grid), dim3(kThreads), 0, stream, a);
+    } else if (train && train->xenc) {
         if (io.mode == 1) MNF_LAUNCH_S(1, false, 2); else MNF_LAUNCH_S(0, false, 2);
     } else if (train) {
         if (io.mode == 1) MNF_LAUNCH_S(1, false, 1); else MNF_LAUNCH_S(0, false, 1);
@@ -674,13 +706,13 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
         if (io.mlp_waves > 0 && io.mlp_waves <= kWavesPerBlock) a.active_waves = io.mlp_waves;
         if (io.phase == 1) {
         } else if (density_only) {
-            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, true, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, true, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-            else hipLaunchKernelGGL((field_kernel<W, NH, 2, true, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, true, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, true, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else hipLaunchKernelGGL((field_kernel<W, NH, 2, true, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
         } else {
-            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, false, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-            else hipLaunchKernelGGL((field_kernel<W, NH, 2, false, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+            if (io.mode == 0) hipLaunchKernelGGL((field_kernel<W, NH, 0, false, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else if (io.mode == 1) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+            else hipLaunchKernelGGL((field_kernel<W, NH, 2, false, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
         }
     } else if (density_only) {
         if (io.mode == 0) MNF_LAUNCH(0, true); else if (io.mode == 1) MNF_LAUNCH(1, true); else if (io.mode == 3) MNF_LAUNCH(3, true); else MNF_LAUNCH(2, true);

@@ -125,7 +125,8 @@ __global__ void __launch_bounds__(64) visibility_kernel(int32_t n_rays, const in
                                                         const float *__restrict__ ts, const float *__restrict__ te, const float *__restrict__ sig,
                                                         float early_stop_eps, const float *__restrict__ alpha_thre_dev,
                                                         int64_t *__restrict__ kept_cnts, const int64_t *__restrict__ kept_starts,
-                                                        float *__restrict__ o_ts, float *__restrict__ o_te, int64_t *__restrict__ o_ray) {
+                                                        float *__restrict__ o_ts, float *__restrict__ o_te, int64_t *__restrict__ o_ray,
+                                                        int64_t *__restrict__ o_src /* optional: the marched index of every survivor */) {
     const int lane = threadIdx.x;
     const float alpha_thre = alpha_thre_dev[0];
     for (int32_t r = blockIdx.x; r < n_rays; r += gridDim.x) {
@@ -151,6 +152,7 @@ __global__ void __launch_bounds__(64) visibility_kernel(int32_t n_rays, const in
             if (WRITE && vis) {
                 const int64_t dst = out + __popcll(m & ((1ull << lane) - 1ull));
                 o_ts[dst] = a; o_te[dst] = b; o_ray[dst] = r;
+                if (o_src) o_src[dst] = k;
             }
             const int nk = __popcll(m);
             out += nk; kept += nk;
@@ -266,6 +268,7 @@ struct StepWs {
     int64_t *ray;
     float *k_ts, *k_te, *k_rgb, *k_sigma, *k_sem, *k_pos, *k_w, *k_tr, *k_dsig, *k_drgb, *k_dsem;   // kept
     int64_t *k_ray;
+    void *rows; int64_t *k_src;        // the pre-pass's feature rows [max_marched][64] x 16 bit and every surviving sample's row (field_rows_supported)
     float *o_rgb, *o_acc, *o_dep, *o_sem, *g_rgb, *g_dep, *g_sem;   // per ray
     void *field_ws;
     int64_t field_ws_bytes, bytes;
@@ -287,6 +290,8 @@ StepWs carve_step(char *base, mnf_field_t f, int64_t R, int32_t cap, int64_t max
     w.k_dsig = (float *)take(max_kept * 4); w.k_drgb = (float *)take(max_kept * 12); w.k_dsem = (float *)take((size_t)max_kept * C * 4);
     w.o_rgb = (float *)take(R * 12); w.o_acc = (float *)take(R * 4); w.o_dep = (float *)take(R * 4); w.o_sem = (float *)take((size_t)R * C * 4);
     w.g_rgb = (float *)take(R * 12); w.g_dep = (float *)take(R * 4); w.g_sem = (float *)take((size_t)R * C * 4);
+    w.rows = nullptr; w.k_src = nullptr;
+    if (field_rows_supported(f)) { w.rows = take((size_t)max_marched * 128); w.k_src = (int64_t *)take(max_kept * 8); }
     w.field_ws_bytes = mnf_field_train_workspace_bytes(f, max_kept);
     w.field_ws = take((size_t)w.field_ws_bytes);
     w.bytes = (int64_t)off;
@@ -472,6 +477,7 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
         rc = mnf_compact_samples(w.scratch_ts, w.scratch_te, cap, w.starts, w.counts, n_rays, w.ts, w.te, w.ray, stream);
         if (rc) return rc;
     }
+    bool use_rows = false;
     static const bool prepass_flat = diag_env("MNF_PREPASS_FLAT") != nullptr;    // experiment: every marched sample, full lanes, no early termination
     if (prepass_flat) {
         FieldIO io = {};
@@ -485,24 +491,28 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
         io.chunk_starts = w.starts; io.chunk_cnts = w.counts; io.n_rays = n_rays; io.ray_counter = fills.ray_counter;
         io.sdt_stop = opts->early_stop_eps > 0.0f ? -logf(opts->early_stop_eps) + 0.6931472f : INFINITY;
         io.density = w.sigma;
+        static const bool no_rows = diag_env("MNF_NO_ROWS") != nullptr;      // A/B timing: both passes gather
+        use_rows = w.rows != nullptr && !no_rows;
+        io.rows_out = use_rows ? w.rows : nullptr;       // (NULL where the rows are not built: the forward then gathers for itself)
         rc = launch_field(f, io, true, s);
     }
     if (rc) return rc;
     const int vgrid = n_rays < 65535 ? n_rays : 65535;
     hipLaunchKernelGGL(visibility_kernel<false>, dim3(vgrid), dim3(64), 0, s, n_rays, w.starts, w.counts, w.ts, w.te, w.sigma, opts->early_stop_eps,
-                       w.alpha_thre, w.kept_cnts, (const int64_t *)nullptr, (float *)nullptr, (float *)nullptr, (int64_t *)nullptr);
+                       w.alpha_thre, w.kept_cnts, (const int64_t *)nullptr, (float *)nullptr, (float *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
     rc = mnf_exclusive_scan_i64(w.kept_cnts, n_rays, w.kept_starts, w.totals + 1, w.scan, mnf_scan_workspace_bytes(n_rays), stream);
     if (rc) return rc;
     hipLaunchKernelGGL(guard_kept_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, w.kept_cnts, w.kept_starts, (const int64_t *)w.totals, max_kept, eff,
                        counts_dev, skip_dev);
     hipLaunchKernelGGL(visibility_kernel<true>, dim3(vgrid), dim3(64), 0, s, n_rays, w.starts, w.counts, w.ts, w.te, w.sigma, opts->early_stop_eps,
-                       w.alpha_thre, (int64_t *)nullptr, w.kept_starts, w.k_ts, w.k_te, w.k_ray);
+                       w.alpha_thre, (int64_t *)nullptr, w.kept_starts, w.k_ts, w.k_te, w.k_ray, use_rows ? w.k_src : (int64_t *)nullptr);
     // ---- sem_rendering (utils.py:362-461): field with saved activations, compositing
     {
         FieldIO io = {};
         io.mode = 1; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = w.k_ray; io.t_starts = w.k_ts; io.t_ends = w.k_te;
         io.n = max_kept; io.n_dev64 = eff + 1;
         io.rgb = w.k_rgb; io.density = w.k_sigma; io.sem = w.k_sem; io.xn_out = w.k_pos;        // aabb-normalised: what the backward's scatter reads
+        if (use_rows) { io.rows_in = w.rows; io.rows_src = w.k_src; }                            // every survivor's features: the row the pre-pass left, not 128 gathers
         rc = forward_train(f, io, w.field_ws, w.field_ws_bytes, s, opts->deterministic != 0);
         if (rc) return rc;
     }
