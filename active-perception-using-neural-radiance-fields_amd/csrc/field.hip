@@ -230,6 +230,9 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
     __shared__ half8 s_w[kBlocks * 64];
     __shared__ half_t s_stage[SAVE ? kWavesPerBlock * kStageHalves : 1];   // training: per-wave transpose tile of the activation dump
+    // ENC 3: per-wave image of the tile's 64 feature rows (8 KB), so that they leave as whole lines — where LDS has the 64 KB (not beside the weights of four hidden layers)
+    constexpr bool ROWS_LDS = ENC == 3 && (kBlocks + kWavesPerBlock * 8) * 1024 <= 160 * 1024;
+    __shared__ half8 s_rows[ROWS_LDS ? kWavesPerBlock * 512 : 1];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -385,8 +388,11 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { lo[j] = (half_t)f[j]; hi[j] = (half_t)f[8 + j]; }
                 }
-                if (ENC == 3) {      // the sample's features 16 kb .. 16 kb + 15, as the MLP is about to see them
-                    if (valid) {
+                if (ENC == 3) {      // the sample's features 16 kb .. 16 kb + 15, as the MLP is about to see them: pieces 2 kb, 2 kb + 1 of its row (swizzled: a row is 128 bytes)
+                    if (ROWS_LDS) {
+                        half8 *img = s_rows + wave * 512 + lane * 8;
+                        img[(2 * kb) ^ (lane & 7)] = lo; img[(2 * kb + 1) ^ (lane & 7)] = hi;
+                    } else if (valid) {
                         half8 *dst = reinterpret_cast<half8 *>(la.io.rows_out) + col * 8 + 2 * kb;
                         dst[0] = lo; dst[1] = hi;
                     }
@@ -396,6 +402,18 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_setprio(1);
+            if (ROWS_LDS) {
+                // the tile's rows are consecutive in rows_out (the lanes' samples are consecutive): eight stores of 1 KB each instead of 16-byte pieces at a 128-byte lane
+                // stride (the pre-pass took 453 us with those, 399 without rows)
+                half8 *dst = reinterpret_cast<half8 *>(la.io.rows_out) + (col - lane) * 8;
+                const half8 *img = s_rows + wave * 512;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int piece = i * 64 + lane, row = piece >> 3;
+                    const half8 v = img[row * 8 + ((piece & 7) ^ (row & 7))];
+                    if (col - lane + row < n_eff) dst[piece] = v;
+                }
+            }
         }
 
         // the mask-dump base of this tile
