@@ -1017,7 +1017,8 @@ static bool use_fused_backward(mnf_field_t f, bool deterministic) {
 }
 
 // the binned scatter's plan for an upper bound of n samples: levels [first, 16) (all hashed, one size, whole bins), lists per level, items per list
-constexpr int kBinLevel0Default = 11;      // measured (tools/r03_bins_step.sh, profiles/r03_bins_step_*.txt): step time flat from 10 to 12, worse below and above
+constexpr int kBinLevel0Default = 12;      // measured: round 3 (tools/r03_bins_step.sh, profiles/r03_bins_step_*.txt) the step time was flat from 10 to 12, worse below and above (11 then);
+                                           // round 4, with wgrad's lighter traffic, 12 is 60 us ahead of 11 at 1.0 M samples (3.393 -> 3.327 ms, four alternations on one box) and equal at 0.25 M
 static void bin_plan(const mnf_field_s *f, int64_t n, int want, int &first_binned, uint32_t &nb, uint32_t &cap) {
     first_binned = 16; nb = 0; cap = 0;
     if (n < 8192) return;                    // small batches: the walk alone (pass B costs ~20 us whatever it is given)

@@ -618,8 +618,8 @@ def main():
                     kernels[label] = e
                     total_ms += ms / steps
                 if "hash_scatter" in kernels:
-                    kernels["hash_scatter"]["note"] = ("levels 0-10: the walk, bound by the memory-side atomic unit: ~21 G 64-byte requests/s whatever they carry "
-                                                       "(profiles/r03_atomic_microbench.txt), on a second stream beside wgrad; levels 11-15 (hash_scatter_bins): per-bin "
+                    kernels["hash_scatter"]["note"] = ("levels 0-11: the walk, bound by the memory-side atomic unit: ~21 G 64-byte requests/s whatever they carry "
+                                                       "(profiles/r03_atomic_microbench.txt), on a second stream beside wgrad; levels 12-15 (hash_scatter_bins): per-bin "
                                                        "item lists through HBM + LDS sums, on a third stream; the three overlap, so their times do not add up")
                 res["kernels"] = kernels
                 res["timed_kernels_ms_per_step"] = total_ms
