@@ -624,7 +624,7 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
 
     With `optim.FusedAdam` the decision "skip this iteration" (no surviving sample, non-finite gradient) is taken on the
     device and the iteration is enqueued without waiting for the GPU:
-      sync=True   (default) ONE host round trip at the end (the reference has one per parameter plus two inside the sampler):
+      sync=True   (default) ONE host round trip, behind the enqueued optimizer call (the reference has one per parameter plus two inside the sampler):
                   returns n_rendering_samples as an int and skipped as a bool, steps the scheduler only if the optimizer stepped.
       sync=False  no round trip at all: n_rendering_samples and skipped are device tensors; the scheduler advances every call, and a step whose skip
                   flag arrives raised (one or two calls later, with its counts) gives its scheduler step back: the schedule counts optimizer updates.
@@ -651,6 +651,54 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
 
     estimator.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre)
     out = None
+    if fused and sync and device_guard and not data_parallel:
+        # The reference's loop form (n_rendering_samples and the skip decision on the host after every iteration) with ONE host round trip and no bubble on the GPU: render +
+        # loss + backward AND the guarded optimizer call are enqueued first, then the host waits once for the five words the optimizer's step-count kernel wrote into pinned
+        # memory.  (Rounds 1-3 read the counts between backward and optimizer — the GPU idled through a round trip and the optimizer's launch — and the flag after it.)
+        # A step beyond its sample bounds has raised the flag on the device: its optimizer call changed nothing, the bounds grow and the step is repeated.
+        st = _train_state(radiance_field)
+        dev = rays.origins.device
+        if seed is None and (presampled is None or presampled.keep is None):
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # one draw per iteration, whatever the number of attempts
+        c = None
+        for attempt in range(4):
+            out = fused_forward_backward(radiance_field, estimator, rays, pixels, dep, sem, render_bkgd, near_plane=near_plane,
+                                         render_step_size=render_step_size, cone_angle=cone_angle, alpha_thre=alpha_thre, sync=False,
+                                         stratified=stratified, deterministic=deterministic, presampled=presampled if attempt == 0 else None, seed=seed,
+                                         _defer_report=True)
+            if out is None:
+                break
+            if presampled is not None and attempt == 0:
+                seed = presampled.seed
+            host, ev, _ = out["_report"]
+            optimizer.step(skip=out["skip"], count_nonfinite=True, report=(out["counts"], host))
+            if not optimizer.reported:
+                host[:4].copy_(out["counts"], non_blocking=True)
+                host[4:5].copy_(out["skip"].reshape(1).to(torch.int64), non_blocking=True)
+            ev.record(torch.cuda.current_stream(dev))
+            ev.synchronize()                                            # the iteration's one host round trip
+            c = host.tolist()
+            st.setdefault("pinned", []).append((host, ev))
+            _check_status(c[3])
+            if c[3] & _ST_ROW:
+                out = None                                              # a ray longer than a scratch row: the autograd path below (the flagged optimizer call changed nothing)
+                break
+            if c[3] & (_ST_MARCHED | _ST_KEPT):
+                _grow_caps(st, c[0], c[1], rays.origins.reshape(-1, 3).shape[0], carry=False)
+                continue
+            break
+        else:
+            raise L.MnfError("train_step: sample bounds kept growing")
+        if out is not None:
+            skipped = c[4] > 0
+            estimator.last_sampling = {"n_marched": int(c[0])}
+            if not skipped and scheduler is not None:
+                scheduler.step()
+            if int(c[1]) == 0:
+                return dict(loss=None, n_rendering_samples=0, skipped=True)
+            return dict(loss=out["loss"].detach(), loss_rgb=out["loss_rgb"].detach(), loss_dep=out["loss_dep"].detach(), loss_sem=out["loss_sem"].detach(),
+                        n_rendering_samples=int(c[1]), skipped=skipped)
+        fused = False
     if fused:
         out = fused_forward_backward(radiance_field, estimator, rays, pixels, dep, sem, render_bkgd, near_plane=near_plane,
                                      render_step_size=render_step_size, cone_angle=cone_angle, alpha_thre=alpha_thre, sync=sync,
