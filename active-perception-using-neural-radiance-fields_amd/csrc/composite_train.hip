@@ -212,13 +212,15 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const int64_t *__rest
         suffix += total;
         if (valid) {
             d_sig[k] = ds * dt;
-            d_rgb[3 * k] = w * gc0; d_rgb[3 * k + 1] = w * gc1; d_rgb[3 * k + 2] = w * gc2;
+            if (d_rgb) { d_rgb[3 * k] = w * gc0; d_rgb[3 * k + 1] = w * gc1; d_rgb[3 * k + 2] = w * gc2; }
         }
         __syncthreads();
-        for (int c = 0; c < C; ++c) lds[lane * stride + c] = w * gs_lds[c];
-        __syncthreads();
-        if (C > 0) stage_rows<false>(lds, d_sem + (s0 + base) * C, nv, C, stride, lane);
-        __syncthreads();
+        if (d_sem) {      // (NULL, with d_rgb: the caller forms w * g_rgb[ray] and w * g_sem[ray] itself — the train step's backward-data kernel)
+            for (int c = 0; c < C; ++c) lds[lane * stride + c] = w * gs_lds[c];
+            __syncthreads();
+            if (C > 0) stage_rows<false>(lds, d_sem + (s0 + base) * C, nv, C, stride, lane);
+            __syncthreads();
+        }
     }
 }
 
@@ -264,7 +266,7 @@ extern "C" int mnf_composite_train_backward(const int64_t *chunk_starts, const i
     MNF_REQUIRE(n_classes >= 0 && n_classes <= kMaxClasses, "composite_train_backward: n_classes %d not in [0, %d]", n_classes,
                 kMaxClasses);
     MNF_REQUIRE(chunk_starts && chunk_cnts && t_starts && t_ends && sigmas && rgbs && weights && trans && out_acc && out_depth &&
-                    d_sigmas && d_rgbs && ((sems && d_sems) || n_classes == 0),
+                    d_sigmas && (sems || n_classes == 0) && ((d_rgbs == nullptr) == (d_sems == nullptr) || n_classes == 0),
                 "composite_train_backward: null pointer");
     ProfScope ps("composite_train_backward", as_stream(stream));
     if (n_classes <= 32)

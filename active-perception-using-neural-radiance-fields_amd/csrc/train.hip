@@ -20,6 +20,16 @@
 
 #include "field_dev.h"
 
+namespace mnf {
+// The train step's output gradients in factored form: d_rgb[s] = w[s] * g_rgb[ray[s]], d_sem[s][c] = w[s] * g_sem[ray[s]][c] — what sem_rendering's backward
+// (composite_train.hip) would write per sample, 128 bytes each at 29 classes, and the backward-data kernel would read back at a 116-byte lane stride.  Given the
+// factors the kernel forms the products itself (same fp32 multiplications): 12 bytes per sample plus per-ray vectors that stay in cache.
+struct FactoredGrad { const float *w; const int64_t *ray; const float *g_rgb, *g_sem; };
+// set by trainstep.hip for the NEXT backward on this thread; taken (and cleared) by backward_impl
+void set_factored_output_gradient(const FactoredGrad &fg);
+bool take_factored_output_gradient(FactoredGrad &fg);
+}  // namespace mnf
+
 MNF_DT_BEGIN
 
 // ------------------------------------------------------------------ transposed-fragment bookkeeping
@@ -67,6 +77,7 @@ struct BwdArgs {
     float loss_scale;
     int chunk, n_chunks;
     TrainBuf train;
+    FactoredGrad fg;                        // fg.w != NULL: d_rgb / d_sem are not read, the products are formed here
 };
 
 // fp32 -> fp16 with saturation at the largest finite half: a loss-scaled gradient that leaves the fp16 range is clipped
@@ -153,6 +164,24 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
             const bool ok = col < n;
 #pragma unroll
             for (int j = 0; j < 8; ++j) dyr[ct][0][j] = (half_t)0.0f;
+            if (args.fg.w) {      // (wave-uniform) factored output gradients: one weight per sample, the ray's vectors from cache
+                const float wv = ok ? args.fg.w[col] : 0.0f;
+                const int64_t ry = ok ? args.fg.ray[col] : 0;
+                if (ok && h == 0) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float y = args.rgb[3 * col + k];
+                        dyr[ct][0][k] = sat_half(wv * args.fg.g_rgb[3 * ry + k] * y * (1.0f - y) * ls);   // sigmoid'
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = 16 * s + 8 * h + j;
+                        dys[ct][s][j] = (ok && row < args.C) ? sat_half(wv * args.fg.g_sem[ry * args.C + row] * ls) : (half_t)0.0f;
+                    }
+            } else {
             if (ok && h == 0) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -167,6 +196,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
                     const int row = 16 * s + 8 * h + j;
                     dys[ct][s][j] = (ok && row < args.C) ? sat_half(args.d_sem[col * args.C + row] * ls) : (half_t)0.0f;
                 }
+            }
             // trunc_exp backward (ngp.py:34-39): g * exp(min(x, 15)) with exp(x) = sigma (0 outside the aabb)
             dlogit[ct] = ok ? args.d_sigma[col] * fminf(args.sigma[col], 3269017.3724721107f) * ls : 0.0f;
         }
@@ -1093,8 +1123,10 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
         MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
     }
+    FactoredGrad fg = {nullptr, nullptr, nullptr, nullptr};
+    const bool factored = take_factored_output_gradient(fg);
     if (n == 0) return MNF_OK;
-    MNF_REQUIRE(positions && d_rgb && d_density && d_sem && rgb && density, "field_backward: null pointer");
+    MNF_REQUIRE(positions && d_density && rgb && density && (factored || (d_rgb && d_sem)), "field_backward: null pointer");
     int rc = ensure_train_state(f);
     if (rc) return rc;
     TrainState *ts = reinterpret_cast<TrainState *>(f->train_state);
@@ -1121,7 +1153,9 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
                        reinterpret_cast<const half_t *>(f->d_frags), ts->d_fragT, n_frag, ts->d_bin_cursors, 16 * kMaxBins);
     const bool fused = use_fused_backward(f, deterministic);
     if (f->bwd_mode == 2 && !fused) { set_error("field_backward: the fused backward serves neurons = 128, layers <= 2, non-deterministic mode only"); return MNF_ERR_UNSUPPORTED; }
+    if (factored && fused) { set_error("field_backward: the fused backward reads per-sample output gradients"); return MNF_ERR_UNSUPPORTED; }
     BwdArgs a;
+    a.fg = fg;
     a.fragsT = reinterpret_cast<const half8 *>(ts->d_fragT);
     a.d_rgb = d_rgb; a.d_sigma = d_density; a.d_sem = d_sem; a.rgb = rgb; a.sigma = density;
     a.dX = v.dX; a.n = n; a.n_dev = n_dev; a.C = f->cfg.num_semantic_classes; a.loss_scale = loss_scale;
@@ -1337,6 +1371,13 @@ MNF_DT_END
 
 #ifndef MNF_BF16   // ---- operand-type independent: compiled once
 namespace mnf {
+static thread_local FactoredGrad t_factored = {nullptr, nullptr, nullptr, nullptr};
+void set_factored_output_gradient(const FactoredGrad &fg) { t_factored = fg; }
+bool take_factored_output_gradient(FactoredGrad &fg) {
+    fg = t_factored;
+    t_factored = FactoredGrad{nullptr, nullptr, nullptr, nullptr};
+    return fg.w != nullptr;
+}
 // ------------------------------------------------------------------ optimizer step (pipeline.py:173-178, :531)
 // torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) on one flat parameter vector in a single pass
 // (torch's foreach implementation is six passes over the 25 M table entries): lerp of the first moment, addcmul of the

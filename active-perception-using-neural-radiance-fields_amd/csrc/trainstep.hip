@@ -37,6 +37,9 @@ struct mnf_presample_s {
 };
 
 namespace mnf {
+// train.hip: the next backward on this thread forms its per-sample output gradients from these factors (w[s] * g[ray[s]]) instead of reading them
+struct FactoredGrad { const float *w; const int64_t *ray; const float *g_rgb, *g_sem; };
+void set_factored_output_gradient(const FactoredGrad &fg);
 namespace {
 
 constexpr float kEps = 1.1920928955078125e-07f;
@@ -530,9 +533,13 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
                        w.g_rgb, w.g_dep, w.g_sem, losses, counts_dev + 3, skip_dev);
     rc = launch_status("loss_kernel");
     if (rc) return rc;
+    // the rgb / semantic output gradients of a sample are its weight times its ray's loss gradient: the split backward forms them itself from (k_w, k_ray, g_rgb, g_sem)
+    // — 12 bytes per sample and cached per-ray vectors instead of 128 bytes written here and read there; the fused backward (mode 2) reads the per-sample arrays
+    const bool factored = f->bwd_mode != 2 && C > 0;
     rc = mnf_composite_train_backward(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, C, max_kept, bk, w.k_w, w.k_tr, w.o_acc,
-                                      w.o_dep, w.g_rgb, nullptr, w.g_dep, w.g_sem, w.k_dsig, w.k_drgb, w.k_dsem, stream);
+                                      w.o_dep, w.g_rgb, nullptr, w.g_dep, w.g_sem, w.k_dsig, factored ? nullptr : w.k_drgb, factored ? nullptr : w.k_dsem, stream);
     if (rc) return rc;
+    if (factored) set_factored_output_gradient(FactoredGrad{w.k_w, w.k_ray, w.g_rgb, w.g_sem});
     return backward(f, w.k_pos, max_kept, eff + 1, w.k_drgb, w.k_dsig, w.k_dsem, w.k_rgb, w.k_sigma, w.field_ws, w.field_ws_bytes, opts->loss_scale, g_base,
                     g_head, g_sem, false, true, opts->deterministic != 0, s);
 }

@@ -119,7 +119,9 @@ int mnf_composite_train_forward(const int64_t *chunk_starts, const int64_t *chun
                                 float *trans, float *alphas, mnf_stream_t stream);
 
 /* Its adjoint (what torch autograd derives for the reference's op chain): gradients of the four per-ray outputs
- * (any of g_* may be NULL = zero) -> d_sigmas [N], d_rgbs [N,3], d_sems [N,C]. */
+ * (any of g_* may be NULL = zero) -> d_sigmas [N], d_rgbs [N,3], d_sems [N,C].  d_rgbs and d_sems may BOTH be NULL: they are
+ * weights[s] * g_rgb[ray] and weights[s] * g_sem[ray], which a caller that has the weights can form itself (mnf_train_step's
+ * backward-data kernel does: 128 bytes per sample less to write and to read back). */
 int mnf_composite_train_backward(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
                                  const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
                                  const float *sems, int32_t n_classes, int64_t n_samples, const float *bkgd,
