@@ -102,7 +102,7 @@ struct FieldIO {
 // Training-time activation storage handed to the forward kernel (layout: field_dev.h, TrainLayout)
 struct TrainBuf {
     void *act;        // [tiles][rows][64] 16-bit elements
-    uint8_t *masks;   // [tiles][mask_blocks][CT][64]
+    uint8_t *masks;   // [tiles][64 lanes][mask_bytes]: a record per lane (field_dev.h TrainLayout)
     int64_t Np;
     int32_t rows;
     void *xenc;       // fused backward (csrc/fused_bwd.h): instead of `act` / `masks`, [tiles][kEncBlocks][64] x 16 B — the tile's hash features

@@ -417,7 +417,9 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
         }
 
         // the mask-dump base of this tile
-        uint8_t *mdump = SAVE ? la.train.masks + (tile * T::mask_blocks * CT) * 64 + lane : nullptr;
+        uint8_t *mdump = SAVE ? la.train.masks + (tile * 64 + lane) * T::mask_bytes : nullptr;      // this lane's mask record of the tile
+        u32x4 mpiece = {0u, 0u, 0u, 0u};
+        constexpr int kMaskUsed = T::mask_blocks * CT;
         if (SAVE) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) save_pair<false>(from_constant(&la.train), tile, T::rX + 16 * ks, lane, stage, bfeat[0][ks], bfeat[1][ks]);
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int k = 0; k < L::KSW; ++k) {
                 save_pair<true>(from_constant(&la.train), tile, T::rH0 + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) mdump[((T::mH0 + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
+                for (int ct = 0; ct < CT; ++ct) mask_put<kMaskUsed>(mpiece, mdump, (T::mH0 + k) * CT + ct, frag_mask(hb[ct][k]));
             }
         }
 #pragma unroll
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                 for (int k = 0; k < L::KSW; ++k) {
                     save_pair<true>(from_constant(&la.train), tile, T::rH0 + (l + 1) * W + 16 * k, lane, stage, hb[0][k], hb[1][k]);
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) mdump[((T::mH0 + (l + 1) * L::KSW + k) * CT + ct) * 64] = frag_mask(hb[ct][k]);
+                    for (int ct = 0; ct < CT; ++ct) mask_put<kMaskUsed>(mpiece, mdump, (T::mH0 + (l + 1) * L::KSW + k) * CT + ct, frag_mask(hb[ct][k]));
                 }
             }
         }
@@ -507,7 +509,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             for (int k = 0; k < L::KSh; ++k) {
                 save_pair<true>(from_constant(&la.train), tile, row0 + 16 * k, lane, stage, a[0][k], a[1][k]);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) mdump[((mblk + k) * CT + ct) * 64] = frag_mask(a[ct][k]);
+                for (int ct = 0; ct < CT; ++ct) mask_put<kMaskUsed>(mpiece, mdump, (mblk + k) * CT + ct, frag_mask(a[ct][k]));
             }
         };
         // rgb head (ngp.py:143-156, :202-213)

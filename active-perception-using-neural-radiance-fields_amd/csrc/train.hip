@@ -105,9 +105,9 @@ __device__ __forceinline__ void dense_tile(const half8 *__restrict__ w_lds, int 
 
 // One backward layer through a ReLU: dz[ct][2rt+s] = pack(W^T(rt,:) * dOut[ct]) masked by the saved activation,
 // stored feature-major at row0 for the weight gradient.
-template <int RT_OUT, int KS>
+template <int RT_OUT, int KS, int NP>
 __device__ __forceinline__ void dense_mask(const half8 *__restrict__ w_lds, int lane, int h, const half8 (&b)[CT][KS],
-                                           const uint8_t *__restrict__ masks, const TrainBuf &tb, int64_t tile, int row0,
+                                           const u32x4 (&mrec)[NP], int mblock0, const TrainBuf &tb, int64_t tile, int row0,
                                            half_t *stage, half8 (&o)[CT][RT_OUT * 2]) {
 #pragma unroll
     for (int rt = 0; rt < RT_OUT; ++rt) {
@@ -117,7 +117,9 @@ __device__ __forceinline__ void dense_mask(const half8 *__restrict__ w_lds, int 
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const uint32_t m = masks[((rt * 2 + s) * CT + ct) * 64];
+                // byte (mblock0 + rt * 2 + s) * CT + ct of the lane's mask record (indices are constants once the loops are unrolled)
+                const int mb = (mblock0 + rt * 2 + s) * CT + ct;
+                const uint32_t m = mrec[mb >> 4][(mb >> 2) & 3] >> (8 * (mb & 3));
                 // pack two values per conversion first, then clear the halves whose ReLU was inactive with ONE and: element 2i is
                 // bit i of the mask byte, element 2i+1 bit 4+i (frag_mask_bit); a sign-extended 1-bit field extract is an
                 // all-ones / all-zeros word.  (Selecting per element before the conversion cost 4.5 instructions per value.)
@@ -154,7 +156,14 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
 
     for (int64_t tile = tile0 + (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWavesPerBlock) {
         const int64_t fcol0 = tile * kWaveSamples + c;
-        const uint8_t *mdump = args.train.masks + (tile * T::mask_blocks * CT) * 64 + lane;
+        // the lane's ReLU-mask record of the tile: mask_bytes / 16 loads here instead of a byte load per fragment where it is used
+        constexpr int kMaskPieces = T::mask_bytes / 16;
+        u32x4 mrec[kMaskPieces];
+        {
+            const u32x4 *mp = reinterpret_cast<const u32x4 *>(args.train.masks + (tile * 64 + lane) * T::mask_bytes);
+#pragma unroll
+            for (int i = 0; i < kMaskPieces; ++i) mrec[i] = mp[i];
+        }
         // ---- output-layer gradients, built directly as natural-order B fragments ----
         half8 dyr[CT][1], dys[CT][2];
         float dlogit[CT];
@@ -206,11 +215,11 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
         // ---- heads ----
         half8 dz2[CT][L::KSh], dz1[CT][L::KSh];
         f32x16 dgeo_r[CT], dgeo_s[CT];
-        dense_mask<L::RTh, 1>(s_w + L::o_r3 * 64, lane, h, dyr, mdump + T::mHH2 * CT * 64, args.train, tile, T::rdZr2, stage, dz2);
-        dense_mask<L::RTh, L::KSh>(s_w + L::o_r2 * 64, lane, h, dz2, mdump + T::mHH1 * CT * 64, args.train, tile, T::rdZr1, stage, dz1);
+        dense_mask<L::RTh, 1>(s_w + L::o_r3 * 64, lane, h, dyr, mrec, T::mHH2, args.train, tile, T::rdZr2, stage, dz2);
+        dense_mask<L::RTh, L::KSh>(s_w + L::o_r2 * 64, lane, h, dz2, mrec, T::mHH1, args.train, tile, T::rdZr1, stage, dz1);
         dense_tile<L::KSh>(s_w + L::o_r1 * 64, lane, dz1, dgeo_r);
-        dense_mask<L::RTh, 2>(s_w + L::o_s3 * 64, lane, h, dys, mdump + T::mHS2 * CT * 64, args.train, tile, T::rdZs2, stage, dz2);
-        dense_mask<L::RTh, L::KSh>(s_w + L::o_s2 * 64, lane, h, dz2, mdump + T::mHS1 * CT * 64, args.train, tile, T::rdZs1, stage, dz1);
+        dense_mask<L::RTh, 2>(s_w + L::o_s3 * 64, lane, h, dys, mrec, T::mHS2, args.train, tile, T::rdZs2, stage, dz2);
+        dense_mask<L::RTh, L::KSh>(s_w + L::o_s2 * 64, lane, h, dz2, mrec, T::mHS1, args.train, tile, T::rdZs1, stage, dz1);
         dense_tile<L::KSh>(s_w + L::o_s1 * 64, lane, dz1, dgeo_s);
         // ---- base output gradient: geo rows from both heads, row 0 = density logit ----
         half8 dbo[CT][1];
@@ -223,12 +232,12 @@ __global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(const BwdArgs args) 
         save_pair<true>(args.train, tile, T::rdBO, lane, stage, dbo[0][0], dbo[1][0]);
         // ---- base MLP ----
         half8 dz[CT][L::KSW];
-        dense_mask<L::RT, 1>(s_w + L::o_bo * 64, lane, h, dbo, mdump + (T::mH0 + (NH - 1) * L::KSW) * CT * 64, args.train, tile,
+        dense_mask<L::RT, 1>(s_w + L::o_bo * 64, lane, h, dbo, mrec, T::mH0 + (NH - 1) * L::KSW, args.train, tile,
                              T::rdZ0 + (NH - 1) * W, stage, dz);
 #pragma unroll
         for (int l = NH - 2; l >= 0; --l) {
             half8 dn[CT][L::KSW];
-            dense_mask<L::RT, L::KSW>(s_w + (L::o_bh + l * L::RT * L::KSW) * 64, lane, h, dz, mdump + (T::mH0 + l * L::KSW) * CT * 64,
+            dense_mask<L::RT, L::KSW>(s_w + (L::o_bh + l * L::RT * L::KSW) * 64, lane, h, dz, mrec, T::mH0 + l * L::KSW,
                                       args.train, tile, T::rdZ0 + l * W, stage, dn);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
@@ -834,7 +843,7 @@ struct TrainTables {
     std::vector<int32_t> fragT;
     std::vector<WgradJob> jobs;
     std::vector<WgradGroup> groups;
-    int rows, mask_blocks;
+    int rows, mask_blocks, mask_bytes;
 };
 
 static void add_jobs(std::vector<WgradJob> &jobs, int buf, int64_t off, int n_out_real, int stride, int n_in_real,
@@ -870,7 +879,7 @@ static TrainTables build_tables(int C) {
     constexpr int Wh = W / 2;
     const int sem_pad = ((C + 15) / 16) * 16;
     TrainTables tt;
-    tt.rows = T::rows; tt.mask_blocks = T::mask_blocks;
+    tt.rows = T::rows; tt.mask_blocks = T::mask_blocks; tt.mask_bytes = T::mask_bytes;
     // parameter offsets (reference state_dict layout)
     int64_t b_in = 0, b_hid = (int64_t)W * 64, b_out = b_hid + (int64_t)(NH - 1) * W * W;
     int64_t h_in = 0, h_hid = (int64_t)Wh * 32, h_out = h_hid + (int64_t)Wh * Wh;
@@ -1069,7 +1078,7 @@ static WsView carve_train(const TrainTables &tt, const mnf_field_s *f, void *bas
     size_t off = 0;
     auto take = [&](size_t b) { char *p = base ? (char *)base + off : nullptr; off += (b + 255) & ~(size_t)255; return p; };
     v.act = (half_t *)take((size_t)tt.rows * v.Np * 2);
-    v.masks = (uint8_t *)take((size_t)(v.Np / 64) * tt.mask_blocks * CT * 64);
+    v.masks = (uint8_t *)take((size_t)v.Np * tt.mask_bytes);      // [tile][lane] records
     v.dX = (float *)take((size_t)v.Np * 64 * 4);
     v.xn = (float *)take((size_t)v.Np * 3 * 4);
     v.repl = (float *)take((size_t)kReplicas * kReplMaxEntries * 4 * sizeof(float));   // private copies of the coarsest levels' gradient (scatter)
