@@ -75,6 +75,19 @@ __device__ __forceinline__ void rows_to_lds(const float (&v)[CB], float *__restr
     }
 }
 
+// The same two halves for a class-major block, g[class * sstride + sample] (the train step's private logit buffer: FieldIO::sem_stride): lane = sample.
+template <int CB>
+__device__ __forceinline__ void rows_load_soa(float (&v)[CB], const float *g, int64_t sstride, int n_rows, int C, int lane) {
+#pragma unroll
+    for (int j = 0; j < CB; ++j) v[j] = (j < C && lane < n_rows) ? g[j * sstride + lane] : 0.0f;
+}
+template <int CB>
+__device__ __forceinline__ void rows_to_lds_soa(const float (&v)[CB], float *__restrict__ lds, int n_rows, int C, int stride, int lane) {
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+        if (j < C && lane < n_rows) lds[lane * stride + j] = v[j];
+}
+
 template <int CB>
 __global__ void __launch_bounds__(64) composite_fwd_kernel(const int64_t *__restrict__ starts, const int64_t *__restrict__ cnts,
                                                            const float *__restrict__ ts, const float *__restrict__ te,
@@ -83,7 +96,7 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(const int64_t *__rest
                                                            float *__restrict__ o_rgb, float *__restrict__ o_acc,
                                                            float *__restrict__ o_dep, float *__restrict__ o_sem,
                                                            float *__restrict__ w_out, float *__restrict__ t_out,
-                                                           float *__restrict__ a_out) {
+                                                           float *__restrict__ a_out, int64_t sstride) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
     const int stride = C | 1;
@@ -104,7 +117,7 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(const int64_t *__rest
             na = ts[k]; nb = te[k]; nsg = sig[k];
             nc0 = rgb[3 * k]; nc1 = rgb[3 * k + 1]; nc2 = rgb[3 * k + 2];
         }
-        if (C > 0) rows_load<CB>(rows, sem + (s0 + base) * C, nv, C, lane);
+        if (C > 0) { if (sstride) rows_load_soa<CB>(rows, sem + s0 + base, sstride, nv, C, lane); else rows_load<CB>(rows, sem + (s0 + base) * C, nv, C, lane); }
     };
     if (cnt > 0) request(0);
     for (int base = 0; base < cnt; base += 64) {
@@ -112,7 +125,7 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(const int64_t *__rest
         const bool valid = lane < nv;
         const int64_t k = s0 + base + lane;
         const float a = na, b = nb, sg = nsg, c0 = nc0, c1 = nc1, c2 = nc2;
-        if (C > 0) rows_to_lds<CB>(rows, lds, nv, C, stride, lane);
+        if (C > 0) { if (sstride) rows_to_lds_soa<CB>(rows, lds, nv, C, stride, lane); else rows_to_lds<CB>(rows, lds, nv, C, stride, lane); }
         if (base + 64 < cnt) request(base + 64);
         const float s = sg * (b - a);
         const float incl = wave_inclusive_scan(s, lane);
@@ -155,7 +168,7 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const int64_t *__rest
                                                            const float *__restrict__ o_dep, const float *__restrict__ g_rgb,
                                                            const float *__restrict__ g_acc, const float *__restrict__ g_dep,
                                                            const float *__restrict__ g_sem, float *__restrict__ d_sig,
-                                                           float *__restrict__ d_rgb, float *__restrict__ d_sem) {
+                                                           float *__restrict__ d_rgb, float *__restrict__ d_sem, int64_t sstride) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
     const int stride = C | 1;
@@ -188,7 +201,7 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const int64_t *__rest
             na = ts[k]; ne = te[k]; nsg = sig[k]; nw = w_in[k]; nT = t_in[k];
             nc0 = rgb[3 * k]; nc1 = rgb[3 * k + 1]; nc2 = rgb[3 * k + 2];
         }
-        if (C > 0) rows_load<CB>(rows, sem + (s0 + base) * C, nv, C, lane);
+        if (C > 0) { if (sstride) rows_load_soa<CB>(rows, sem + s0 + base, sstride, nv, C, lane); else rows_load<CB>(rows, sem + (s0 + base) * C, nv, C, lane); }
     };
     request((n_blocks - 1) * 64);
     for (int b = n_blocks - 1; b >= 0; --b) {
@@ -197,7 +210,7 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const int64_t *__rest
         const bool valid = lane < nv;
         const int64_t k = s0 + base + lane;
         const float a = na, e = ne, sg = nsg, c0 = nc0, c1 = nc1, c2 = nc2, w = nw, T = nT;
-        if (C > 0) rows_to_lds<CB>(rows, lds, nv, C, stride, lane);
+        if (C > 0) { if (sstride) rows_to_lds_soa<CB>(rows, lds, nv, C, stride, lane); else rows_to_lds<CB>(rows, lds, nv, C, stride, lane); }
         if (b > 0) request(base - 64);
         __syncthreads();
         const float dt = e - a;
@@ -231,11 +244,13 @@ size_t lds_bytes(int C) { return (size_t)(64 * (C | 1) + kMaxClasses) * sizeof(f
 
 using namespace mnf;
 
-extern "C" int mnf_composite_train_forward(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
-                                           const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
-                                           const float *sems, int32_t n_classes, int64_t n_samples, const float *bkgd,
-                                           float *out_rgb, float *out_acc, float *out_depth, float *out_sem, float *weights,
-                                           float *trans, float *alphas, mnf_stream_t stream) {
+namespace mnf {
+// sem_stride != 0: `sems` is class-major, sems[class * sem_stride + sample] (the train step's private buffer); 0: [sample][C] as the public entry points take it
+int composite_train_forward_impl(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                 const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                                 const float *sems, int64_t sem_stride, int32_t n_classes, int64_t n_samples, const float *bkgd,
+                                 float *out_rgb, float *out_acc, float *out_depth, float *out_sem, float *weights,
+                                 float *trans, float *alphas, mnf_stream_t stream) {
     if (n_rays == 0) return MNF_OK;
     MNF_REQUIRE(n_classes >= 0 && n_classes <= kMaxClasses, "composite_train_forward: n_classes %d not in [0, %d]", n_classes,
                 kMaxClasses);
@@ -247,17 +262,28 @@ extern "C" int mnf_composite_train_forward(const int64_t *chunk_starts, const in
     if (n_classes <= 32)
         hipLaunchKernelGGL(composite_fwd_kernel<32>, dim3(n_rays), dim3(64), lds_bytes(n_classes), as_stream(stream), chunk_starts,
                            chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, n_classes, bkgd, out_rgb, out_acc, out_depth, out_sem,
-                           weights, trans, alphas);
+                           weights, trans, alphas, sem_stride);
     else
         hipLaunchKernelGGL(composite_fwd_kernel<kMaxClasses>, dim3(n_rays), dim3(64), lds_bytes(n_classes), as_stream(stream), chunk_starts,
                            chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, n_classes, bkgd, out_rgb, out_acc, out_depth, out_sem,
-                           weights, trans, alphas);
+                           weights, trans, alphas, sem_stride);
     return launch_status("composite_fwd_kernel");
 }
+}  // namespace mnf
 
-extern "C" int mnf_composite_train_backward(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+extern "C" int mnf_composite_train_forward(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                           const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                                           const float *sems, int32_t n_classes, int64_t n_samples, const float *bkgd,
+                                           float *out_rgb, float *out_acc, float *out_depth, float *out_sem, float *weights,
+                                           float *trans, float *alphas, mnf_stream_t stream) {
+    return composite_train_forward_impl(chunk_starts, chunk_cnts, n_rays, t_starts, t_ends, sigmas, rgbs, sems, 0, n_classes, n_samples, bkgd, out_rgb, out_acc,
+                                        out_depth, out_sem, weights, trans, alphas, stream);
+}
+
+namespace mnf {
+int composite_train_backward_impl(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
                                             const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
-                                            const float *sems, int32_t n_classes, int64_t n_samples, const float *bkgd,
+                                            const float *sems, int64_t sem_stride, int32_t n_classes, int64_t n_samples, const float *bkgd,
                                             const float *weights, const float *trans, const float *out_acc,
                                             const float *out_depth,
                                             const float *g_rgb, const float *g_acc, const float *g_depth, const float *g_sem,
@@ -272,10 +298,22 @@ extern "C" int mnf_composite_train_backward(const int64_t *chunk_starts, const i
     if (n_classes <= 32)
         hipLaunchKernelGGL(composite_bwd_kernel<32>, dim3(n_rays), dim3(64), lds_bytes(n_classes), as_stream(stream), chunk_starts,
                            chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, n_classes, bkgd, weights, trans, out_acc, out_depth, g_rgb, g_acc,
-                           g_depth, g_sem, d_sigmas, d_rgbs, d_sems);
+                           g_depth, g_sem, d_sigmas, d_rgbs, d_sems, sem_stride);
     else
         hipLaunchKernelGGL(composite_bwd_kernel<kMaxClasses>, dim3(n_rays), dim3(64), lds_bytes(n_classes), as_stream(stream), chunk_starts,
                            chunk_cnts, t_starts, t_ends, sigmas, rgbs, sems, n_classes, bkgd, weights, trans, out_acc, out_depth, g_rgb, g_acc,
-                           g_depth, g_sem, d_sigmas, d_rgbs, d_sems);
+                           g_depth, g_sem, d_sigmas, d_rgbs, d_sems, sem_stride);
     return launch_status("composite_bwd_kernel");
+}
+}  // namespace mnf
+
+extern "C" int mnf_composite_train_backward(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays,
+                                            const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                                            const float *sems, int32_t n_classes, int64_t n_samples, const float *bkgd,
+                                            const float *weights, const float *trans, const float *out_acc,
+                                            const float *out_depth,
+                                            const float *g_rgb, const float *g_acc, const float *g_depth, const float *g_sem,
+                                            float *d_sigmas, float *d_rgbs, float *d_sems, mnf_stream_t stream) {
+    return composite_train_backward_impl(chunk_starts, chunk_cnts, n_rays, t_starts, t_ends, sigmas, rgbs, sems, 0, n_classes, n_samples, bkgd, weights, trans,
+                                         out_acc, out_depth, g_rgb, g_acc, g_depth, g_sem, d_sigmas, d_rgbs, d_sems, stream);
 }

@@ -97,6 +97,9 @@ struct FieldIO {
     void *rows_out;
     const void *rows_in;
     const int64_t *rows_src;
+    // modes 0, 1: `sem` class-major, sem[class * sem_stride + sample], instead of [sample][C] (0): a wave then writes 128-byte runs instead of 4-byte pieces at a
+    // C * 4-byte lane stride (the train step's private logit buffer: 75 us of the 650 us training forward at 1.0 M samples were those stores)
+    int64_t sem_stride;
 };
 
 // Training-time activation storage handed to the forward kernel (layout: field_dev.h, TrainLayout)

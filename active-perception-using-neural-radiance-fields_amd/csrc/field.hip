@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int row = 8 * g + 4 * h + i;
-                        if (row < la.C) la.io.sem[scol * la.C + row] = out_sem[ct][4 * g + i];
+                        if (row < la.C) la.io.sem[la.io.sem_stride ? row * la.io.sem_stride + scol : scol * la.C + row] = out_sem[ct][4 * g + i];
                     }
             }
         }

@@ -40,6 +40,14 @@ namespace mnf {
 // train.hip: the next backward on this thread forms its per-sample output gradients from these factors (w[s] * g[ray[s]]) instead of reading them
 struct FactoredGrad { const float *w; const int64_t *ray; const float *g_rgb, *g_sem; };
 void set_factored_output_gradient(const FactoredGrad &fg);
+// composite_train.hip: the public entry points with the logits class-major, sems[class * sem_stride + sample] (0: [sample][C])
+int composite_train_forward_impl(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays, const float *t_starts, const float *t_ends, const float *sigmas,
+                                 const float *rgbs, const float *sems, int64_t sem_stride, int32_t n_classes, int64_t n_samples, const float *bkgd, float *out_rgb,
+                                 float *out_acc, float *out_depth, float *out_sem, float *weights, float *trans, float *alphas, mnf_stream_t stream);
+int composite_train_backward_impl(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays, const float *t_starts, const float *t_ends, const float *sigmas,
+                                  const float *rgbs, const float *sems, int64_t sem_stride, int32_t n_classes, int64_t n_samples, const float *bkgd, const float *weights,
+                                  const float *trans, const float *out_acc, const float *out_depth, const float *g_rgb, const float *g_acc, const float *g_depth,
+                                  const float *g_sem, float *d_sigmas, float *d_rgbs, float *d_sems, mnf_stream_t stream);
 namespace {
 
 constexpr float kEps = 1.1920928955078125e-07f;
@@ -515,6 +523,7 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
         io.mode = 1; io.rays_o = rays_o; io.rays_d = rays_d; io.ray_idx64 = w.k_ray; io.t_starts = w.k_ts; io.t_ends = w.k_te;
         io.n = max_kept; io.n_dev64 = eff + 1;
         io.rgb = w.k_rgb; io.density = w.k_sigma; io.sem = w.k_sem; io.xn_out = w.k_pos;        // aabb-normalised: what the backward's scatter reads
+        io.sem_stride = max_kept;                                                                // the step's own logit buffer is class-major: w.k_sem[class * max_kept + sample]
         if (use_rows) { io.rows_in = w.rows; io.rows_src = w.k_src; }                            // every survivor's features: the row the pre-pass left, not 128 gathers
         rc = forward_train(f, io, w.field_ws, w.field_ws_bytes, s, opts->deterministic != 0);
         if (rc) return rc;
@@ -525,8 +534,8 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
         hipLaunchKernelGGL(set3_kernel, dim3(1), dim3(1), 0, s, bkd, opts->render_bkgd[0], opts->render_bkgd[1], opts->render_bkgd[2]);
         bk = bkd;
     }
-    rc = mnf_composite_train_forward(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, C, max_kept, bk, w.o_rgb, w.o_acc,
-                                     w.o_dep, w.o_sem, w.k_w, w.k_tr, nullptr, stream);
+    rc = composite_train_forward_impl(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, max_kept, C, max_kept, bk, w.o_rgb, w.o_acc,
+                                      w.o_dep, w.o_sem, w.k_w, w.k_tr, nullptr, stream);
     if (rc) return rc;
     // ---- loss (pipeline.py:506-511) and backward (pipeline.py:518)
     hipLaunchKernelGGL(loss_kernel, dim3(rblocks), dim3(256), 0, s, n_rays, C, w.o_rgb, w.o_dep, w.o_sem, target_rgb, target_depth, target_sem,
@@ -536,8 +545,8 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     // the rgb / semantic output gradients of a sample are its weight times its ray's loss gradient: the split backward forms them itself from (k_w, k_ray, g_rgb, g_sem)
     // — 12 bytes per sample and cached per-ray vectors instead of 128 bytes written here and read there; the fused backward (mode 2) reads the per-sample arrays
     const bool factored = f->bwd_mode != 2 && C > 0;
-    rc = mnf_composite_train_backward(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, C, max_kept, bk, w.k_w, w.k_tr, w.o_acc,
-                                      w.o_dep, w.g_rgb, nullptr, w.g_dep, w.g_sem, w.k_dsig, factored ? nullptr : w.k_drgb, factored ? nullptr : w.k_dsem, stream);
+    rc = composite_train_backward_impl(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, max_kept, C, max_kept, bk, w.k_w, w.k_tr, w.o_acc,
+                                       w.o_dep, w.g_rgb, nullptr, w.g_dep, w.g_sem, w.k_dsig, factored ? nullptr : w.k_drgb, factored ? nullptr : w.k_dsem, stream);
     if (rc) return rc;
     if (factored) set_factored_output_gradient(FactoredGrad{w.k_w, w.k_ray, w.g_rgb, w.g_sem});
     return backward(f, w.k_pos, max_kept, eff + 1, w.k_drgb, w.k_dsig, w.k_dsem, w.k_rgb, w.k_sigma, w.field_ws, w.field_ws_bytes, opts->loss_scale, g_base,
