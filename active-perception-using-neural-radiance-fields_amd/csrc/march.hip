@@ -559,21 +559,55 @@ extern "C" int64_t mnf_scan_workspace_bytes(int64_t n) { return n < 0 ? -1 : (ce
 
 // short inputs (the per-ray counts of a train batch): one workgroup, one launch instead of three (each small launch is ~5 us of the stream's time)
 constexpr int kScanSmall = 256 * 64;
+// Each of the four waves owns a contiguous quarter and walks it in runs of 64 consecutive values (one coalesced 512-byte load, one wave scan): a thread per `per`
+// consecutive values read at a 256-byte lane stride and took 24 us for the 8192 rays of a config-5 batch.
+__device__ __forceinline__ int64_t wave_inclusive_scan_i64(int64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+template <int kRuns>      // runs of 64 values per wave: 256 * kRuns >= n
 __global__ void __launch_bounds__(256) scan_small_kernel(const int64_t *__restrict__ in, int64_t n, int64_t *__restrict__ out, int64_t *__restrict__ total_out) {
     __shared__ int64_t s_wave[4];
-    const int per = (int)((n + 255) / 256);                      // consecutive values per thread (<= 64)
-    const int64_t base = (int64_t)threadIdx.x * per;
-    int64_t v = 0;
-    for (int k = 0; k < per; ++k) if (base + k < n) v += in[base + k];
-    int64_t total;
-    int64_t run = block_exclusive_scan_256(v, s_wave, total);
-    for (int k = 0; k < per; ++k) if (base + k < n) { const int64_t x = in[base + k]; out[base + k] = run; run += x; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t quarter = ((n + 255) / 256) * 64;              // a multiple of 64: runs never straddle two waves
+    const int64_t q0 = wave * quarter, q1 = q0 + quarter < n ? q0 + quarter : n;
+    // the quarter's values in registers first (every load in flight at once; a load per run in turn was 32 memory round trips at 8192 values)
+    int64_t x[kRuns];
+    int64_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < kRuns; ++r) {
+        const int64_t i = q0 + r * 64 + lane;
+        x[r] = i < q1 ? in[i] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < kRuns; ++r) sum += x[r];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0) s_wave[wave] = sum;
+    __syncthreads();
+    int64_t carry = 0, total = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) carry += s_wave[w]; total += s_wave[w]; }
+#pragma unroll
+    for (int r = 0; r < kRuns; ++r) {
+        if (q0 + r * 64 >= q1) break;                            // (wave-uniform)
+        const int64_t i = q0 + r * 64 + lane;
+        const int64_t incl = wave_inclusive_scan_i64(x[r], lane);
+        if (i < q1) out[i] = carry + incl - x[r];
+        carry += __shfl(incl, 63, 64);
+    }
     if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
 static int exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, int64_t *total, int64_t *tiles, hipStream_t s) {
     if (n <= kScanSmall && in != out) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(256), 0, s, in, n, out, total);
+        if (n <= 256 * 8) hipLaunchKernelGGL(scan_small_kernel<8>, dim3(1), dim3(256), 0, s, in, n, out, total);
+        else if (n <= 256 * 16) hipLaunchKernelGGL(scan_small_kernel<16>, dim3(1), dim3(256), 0, s, in, n, out, total);
+        else if (n <= 256 * 32) hipLaunchKernelGGL(scan_small_kernel<32>, dim3(1), dim3(256), 0, s, in, n, out, total);
+        else hipLaunchKernelGGL(scan_small_kernel<kScanSmall / 256>, dim3(1), dim3(256), 0, s, in, n, out, total);
         return launch_status("scan_small_kernel");
     }
     const int64_t n_tiles = ceil_div(n, kScanTile);

@@ -1450,16 +1450,25 @@ __device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_c
 __global__ void __launch_bounds__(256) count_nan3_kernel(const Adam3 a, int32_t *__restrict__ count) {
     int local = 0;
     const int64_t quads = ((a.n[0] + 3) >> 2) + ((a.n[1] + 3) >> 2) + ((a.n[2] + 3) >> 2);
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)blockDim.x * gridDim.x) {
-        int k; int64_t i0;
-        quad_of(a, q, k, i0);
-        const float *g = a.g[k] + i0;
-        if (i0 + 4 <= a.n[k] && aligned16(g)) {
-            const float4 x = *reinterpret_cast<const float4 *>(g);
-            local += !(fabsf(x.x) <= 3.4028234664e38f) + !(fabsf(x.y) <= 3.4028234664e38f) + !(fabsf(x.z) <= 3.4028234664e38f) + !(fabsf(x.w) <= 3.4028234664e38f);
-        } else {
-            for (int64_t i = i0; i < a.n[k] && i < i0 + 4; ++i) local += !(fabsf(a.g[k][i]) <= 3.4028234664e38f);
+    const int64_t stride = (int64_t)blockDim.x * gridDim.x;
+    // four quads per trip, their loads issued together (one 16-byte load in flight per thread read the 50 MB of gradients at 2.3 TB/s)
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < quads; q0 += 4 * stride) {
+        float4 x[4];
+        bool fast[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = q0 + u * stride;
+            int k = 0; int64_t i0 = 0;
+            const bool in = q < quads && quad_of(a, q, k, i0);
+            const float *g = a.g[k] + i0;
+            fast[u] = in && i0 + 4 <= a.n[k] && aligned16(g);
+            x[u] = fast[u] ? *reinterpret_cast<const float4 *>(g) : float4{0.f, 0.f, 0.f, 0.f};
+            if (in && !fast[u])
+                for (int64_t i = i0; i < a.n[k] && i < i0 + 4; ++i) local += !(fabsf(a.g[k][i]) <= 3.4028234664e38f);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            local += !(fabsf(x[u].x) <= 3.4028234664e38f) + !(fabsf(x[u].y) <= 3.4028234664e38f) + !(fabsf(x[u].z) <= 3.4028234664e38f) + !(fabsf(x[u].w) <= 3.4028234664e38f);
     }
     if (__ballot(local != 0) != 0ull && local) atomicAdd(count, local);
 }

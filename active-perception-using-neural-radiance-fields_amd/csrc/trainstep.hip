@@ -464,7 +464,7 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
                     pre->step == opts->render_step_size && pre->cone == opts->cone_angle && pre->alpha_thre == opts->alpha_thre &&
                     pre->res[0] == res_x && pre->res[1] == res_y && pre->res[2] == res_z && pre->max_marched == max_marched,
                     "train_step: opts->presampled was made for other rays, options, sample bound or another grid");
-        MNF_HIP(hipStreamWaitEvent(s, pre->ev_done, 0));
+        if (hipEventQuery(pre->ev_done) != hipSuccess) MNF_HIP(hipStreamWaitEvent(s, pre->ev_done, 0));      // (a wait on another queue costs the stream ~18 us even when the event is long done)
         const SampleWs sw = carve_sample((char *)pre->ws, n_rays, cap, max_marched);
         w.nearp = sw.nearp; w.farp = sw.farp; w.alpha_thre = sw.alpha_thre; w.counts = sw.counts; w.starts = sw.starts; w.totals = sw.totals;
         w.scratch_ts = sw.scratch_ts; w.scratch_te = sw.scratch_te; w.ts = sw.ts; w.te = sw.te; w.ray = sw.ray;
