@@ -1230,7 +1230,13 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     // enough sample chunks to fill the chip with waves (the loop is load-latency bound; 2 x 2 blocking leaves room for
     // ~3 waves per SIMD), but at least 16 tiles per wave so the final atomics stay negligible (sized on the upper bound `n`)
     const int64_t n_tiles = v.Np / 64;
-    int split = (int)(256 * 12 / n_groups);
+    // (12 waves per CU and 14 groups: 219 tile ranges; the deterministic mode's grouping of partial sums depends on this value and keeps it.  With float atomics
+    //  18 per CU — 329 ranges — is 20-40 us ahead at 1.0 M samples: 3.211 / 3.184 / 3.187 / 3.104 ms per step with 219 / 330 / 440 / 660, MNF_WGRAD_SPLIT)
+    int split = (int)(256 * (deterministic ? 12 : 18) / n_groups);
+    if (!deterministic) {
+        static const int split_env = diag_env("MNF_WGRAD_SPLIT") ? atoi(diag_env("MNF_WGRAD_SPLIT")) : 0;
+        if (split_env > 0) split = split_env;
+    }
     if (split > n_tiles / 16) split = (int)(n_tiles / 16);
     if (split < 1) split = 1;
     float *partials = nullptr;
