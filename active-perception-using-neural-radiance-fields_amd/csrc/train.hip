@@ -638,7 +638,10 @@ __device__ __forceinline__ float4 pack_item(const float v[4], uint32_t idx) {
 
 static_assert(kBinEntriesLog2 <= 12, "pack_item keeps 3 index bits per value");
 
-constexpr int kBinChunk = 2;                                 // sub-chunks of 256 samples per workgroup of pass A
+#ifndef MNF_BIN_CHUNK
+#define MNF_BIN_CHUNK 2
+#endif
+constexpr int kBinChunk = MNF_BIN_CHUNK;                     // sub-chunks of 256 samples per workgroup of pass A (experiment builds: -DMNF_BIN_CHUNK=1 / 4)
 constexpr int kBinStage = kBinChunk * 256 * 8;               // items staged in LDS per workgroup (64 KB)
 
 __global__ void __launch_bounds__(256) bin_items_kernel(const BinArgs args) {
