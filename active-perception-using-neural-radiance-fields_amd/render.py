@@ -418,7 +418,8 @@ def presample(radiance_field, estimator, rays: Rays, near_plane=0.1, far_plane=1
             train_step(field, est, opt, *batches[step], step=step, presampled=tok)
             tok = nxt
 
-    Same options as the step's (they are checked).  Draws the step's jitter seed from torch's CPU generator, as the step itself would have.  Pass
+    Same options as the step's (they are checked).  Call it on the stream the adopting `train_step` will run on (the token's buffers belong to torch's caching
+    allocator of that stream; `train_step_ensemble` takes care of its members' streams).  Draws the step's jitter seed from torch's CPU generator, as the step itself would have.  Pass
     `handle` to recycle a consumed `Presample`.  A token that does not fit its step any more (grid refreshed in between, other options) is ignored by
     `train_step`, which then marches itself with the token's seed: results never depend on whether the token was used."""
     if estimator.levels > 4:
