@@ -1127,6 +1127,8 @@ int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_
 int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_dev, const float *d_rgb, const float *d_density,
                   const float *d_sem, const float *rgb, const float *density, void *workspace, int64_t workspace_bytes, float loss_scale,
                   float *g_base, float *g_head, float *g_sem, bool zero_grads, bool positions_normalized, bool deterministic, hipStream_t s) {
+    FactoredGrad fg = {nullptr, nullptr, nullptr, nullptr};
+    const bool factored = take_factored_output_gradient(fg);      // first of all: taken (and cleared) on every path out of this call
     MNF_REQUIRE(f && f->params_loaded, "field_backward: parameters not loaded");
     MNF_REQUIRE(n >= 0 && loss_scale > 0.f, "field_backward: bad arguments");
     MNF_REQUIRE(g_base && g_head && g_sem, "field_backward: null gradient buffer");
@@ -1135,8 +1137,6 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         MNF_HIP(hipMemsetAsync(g_head, 0, (size_t)f->n_head * 4, s));
         MNF_HIP(hipMemsetAsync(g_sem, 0, (size_t)f->n_sem * 4, s));
     }
-    FactoredGrad fg = {nullptr, nullptr, nullptr, nullptr};
-    const bool factored = take_factored_output_gradient(fg);
     if (n == 0) return MNF_OK;
     MNF_REQUIRE(positions && d_density && rgb && density && (factored || (d_rgb && d_sem)), "field_backward: null pointer");
     int rc = ensure_train_state(f);
