@@ -461,3 +461,52 @@ def test_presampled_step_beyond_its_marched_bound_is_skipped_like_a_step_that_ma
         torch.cuda.synchronize()
         assert int(out2["skip"]) == 0 and int(out2["counts"][1]) > 3000 and int(out2["counts"][0]) == counts[0]
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+
+
+def test_feature_rows_are_bitwise_a_second_gather():
+    """The training forward reads every survivor's encoded features from the row the density pre-pass left (`FieldIO::rows_in`) instead of gathering 128 table
+    entries again: same bits as the two-gather form, which only the diag build can still run (MNF_NO_ROWS): child process (tests/diag_rows.py), fp16 and bf16."""
+    import os
+    import subprocess
+    import sys
+    from apnrf_amd import build as B
+    here = os.path.dirname(os.path.abspath(__file__))
+    assert os.path.exists(B.LIB_DIAG), "libmi355nerf_diag.so missing: run `python __graft_entry__.py build`"
+    env = dict(os.environ, MNF_LIB_PATH=B.LIB_DIAG)
+    r = subprocess.run([sys.executable, os.path.join(here, "diag_rows.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIAG_ROWS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_composite_backward_without_per_sample_rgb_sem_gradients():
+    """`mnf_composite_train_backward` with d_rgbs = d_sems = NULL (the caller forms weight x per-ray gradient itself, as the train step's backward-data kernel does):
+    d_sigmas is bit for bit what the full call writes, and the products the caller would form equal the arrays of the full call."""
+    import ctypes
+    from apnrf_amd import _lib as L
+    lib = L.load_library()
+    rng = np.random.default_rng(8)
+    R, C = 300, 29
+    cnts = rng.integers(0, 200, R)
+    cnts[::17] = 0
+    starts = np.concatenate([[0], np.cumsum(cnts)[:-1]])
+    N = int(cnts.sum())
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    ts = np.sort(rng.random(N).astype(np.float32)) * 3
+    te = ts + rng.uniform(1e-3, 2e-2, N).astype(np.float32)
+    sig, rgb, sem = rng.uniform(0, 30, N).astype(np.float32), rng.random((N, 3)).astype(np.float32), rng.normal(size=(N, C)).astype(np.float32)
+    d = dict(starts=cu(starts.astype(np.int64)), cnts=cu(cnts.astype(np.int64)), ts=cu(ts), te=cu(te), sig=cu(sig), rgb=cu(rgb), sem=cu(sem), bk=cu(np.array([0.2, 0.4, 0.6], np.float32)))
+    o_rgb, o_acc, o_dep, o_sem = torch.empty(R, 3, device=DEV), torch.empty(R, device=DEV), torch.empty(R, device=DEV), torch.empty(R, C, device=DEV)
+    w, tr = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    L.launch(lib.mnf_composite_train_forward, L.ptr(d["starts"]), L.ptr(d["cnts"]), R, L.ptr(d["ts"]), L.ptr(d["te"]), L.ptr(d["sig"]), L.ptr(d["rgb"]), L.ptr(d["sem"]), C, N,
+             L.ptr(d["bk"]), L.ptr(o_rgb), L.ptr(o_acc), L.ptr(o_dep), L.ptr(o_sem), L.ptr(w), L.ptr(tr), None)
+    g_rgb, g_dep, g_sem = cu(rng.normal(size=(R, 3)).astype(np.float32)), cu(rng.normal(size=R).astype(np.float32)), cu(rng.normal(size=(R, C)).astype(np.float32))
+    outs = []
+    for full in (True, False):
+        ds, dr, dm = torch.zeros(N, device=DEV), torch.zeros(N, 3, device=DEV), torch.zeros(N, C, device=DEV)
+        L.launch(lib.mnf_composite_train_backward, L.ptr(d["starts"]), L.ptr(d["cnts"]), R, L.ptr(d["ts"]), L.ptr(d["te"]), L.ptr(d["sig"]), L.ptr(d["rgb"]), L.ptr(d["sem"]), C, N,
+                 L.ptr(d["bk"]), L.ptr(w), L.ptr(tr), L.ptr(o_acc), L.ptr(o_dep), L.ptr(g_rgb), None, L.ptr(g_dep), L.ptr(g_sem), L.ptr(ds),
+                 L.ptr(dr) if full else None, L.ptr(dm) if full else None)
+        outs.append((ds, dr, dm))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][0].abs().max()) > 0
+    ray = torch.repeat_interleave(torch.arange(R, device=DEV), d["cnts"])
+    assert torch.equal(outs[0][1], w[:, None] * g_rgb[ray]) and torch.equal(outs[0][2], w[:, None] * g_sem[ray])
