@@ -510,3 +510,37 @@ def test_composite_backward_without_per_sample_rgb_sem_gradients():
     assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][0].abs().max()) > 0
     ray = torch.repeat_interleave(torch.arange(R, device=DEV), d["cnts"])
     assert torch.equal(outs[0][1], w[:, None] * g_rgb[ray]) and torch.equal(outs[0][2], w[:, None] * g_sem[ray])
+
+
+def test_optimizer_step_report_writes_counters_and_final_skip_flag_to_pinned_memory():
+    """`mnf_field_optimizer_step_report` (through `FusedAdam.step(report=...)`): the train step's four device counters and the FINAL skip flag — the non-finite count of
+    this very call included — land in pinned host memory without a copy on the stream; the update itself is the plain call's."""
+    from apnrf_amd.optim import FusedAdam
+    sc = H.make_scene(log2_hashmap_size=15)
+    res = []
+    for report in (False, True):
+        torch.manual_seed(3)
+        f = H.hip_field(sc).train()
+        opt = FusedAdam(f.parameters(), lr=1e-2, eps=1e-15).bind_field(f)
+        for p in f.parameters():
+            if p.numel():
+                p.grad = torch.randn_like(p) * 1e-3
+        counts = torch.tensor([123456, 7890, 321, 0], dtype=torch.int64, device=DEV)
+        skip = torch.zeros((), dtype=torch.int32, device=DEV)
+        host = torch.full((5,), -1, dtype=torch.int64).pin_memory()
+        opt.step(skip=skip, count_nonfinite=True, report=(counts, host) if report else None)
+        torch.cuda.synchronize()
+        assert opt.reported == report
+        if report:
+            assert host.tolist() == [123456, 7890, 321, 0, 0]
+        res.append([p.detach().clone() for p in f.parameters() if p.numel()])
+        # a non-finite gradient: the flag is raised by this call's own count, reported, and nothing moves
+        f.mlp_head.params.grad[5] = float("nan")
+        before = [p.detach().clone() for p in f.parameters() if p.numel()]
+        skip.zero_()
+        opt.step(skip=skip, count_nonfinite=True, report=(counts, host) if report else None)
+        torch.cuda.synchronize()
+        assert int(skip) >= 1 and all(torch.equal(a, b) for a, b in zip(before, [p.detach() for p in f.parameters() if p.numel()]))
+        if report:
+            assert host.tolist()[:4] == [123456, 7890, 321, 0] and host[4].item() == int(skip)
+    assert all(torch.equal(a, b) for a, b in zip(*res))
