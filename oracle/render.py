@@ -182,6 +182,7 @@ def render_train(field, binaries, aabbs, occs_mean, rays_o, rays_d, near_planes,
 
 
 # ---------------------------------------------------------------- test-mode renderers
+@torch.no_grad()                      # utils.py:554, :781
 def _render_test_impl(max_samples, field, binaries, aabbs, rays_o, rays_d, near_plane, far_plane,
                       render_step_size, render_bkgd, cone_angle, alpha_thre, early_stop_eps, probabilistic):
     """utils.py:555-779 (probabilistic=False) and :782-1032 (True)."""

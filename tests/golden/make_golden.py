@@ -262,8 +262,293 @@ def gen_dataset():
                         color_bkgd=d["color_bkgd"].numpy(), boot0=np.asarray(ds.bootstrap(0)), boot1=np.asarray(ds.bootstrap(1)))
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# glue.npz / glue_ngp.npz / scorer.npz: the reference's Python glue of the hot path, RUN (not restated), see ref_shim.py for
+# the three native entry points and the one gate substituted beneath it.
+def _glue_scene(seed=9):
+    """A small seeded scene: the yaml box of scene 102344250 at 0.2 m cells (98 x 17 x 98), procedural rooms grid."""
+    from apnrf_amd import synthetic as S
+    sc = S.SCENES["102344250"]
+    res = S.grid_resolution(sc["aabb"])
+    occ = S.make_occupancy(res, aabb=sc["aabb"], free_at=[sc["origin"]], seed=seed)
+    occs = occ.reshape(-1).astype(np.float32) * 0.04          # mean < alpha_thre: exercises occ_grid.py:199's min()
+    poses = S.camera_poses(sc["origin"], 8)
+    return dict(aabb=np.asarray(sc["aabb"], np.float32), res=res, occ=occ, occs=occs, poses=poses)
+
+
+def _ref_estimator(scene):
+    from nerfacc import OccGridEstimator
+    est = OccGridEstimator(roi_aabb=torch.from_numpy(scene["aabb"]), resolution=scene["res"], levels=1)
+    est.binaries = torch.from_numpy(scene["occ"])
+    est.occs = torch.from_numpy(scene["occs"])
+    return est.eval()
+
+
+def _view(scene, pose_idx, h, w, width=640, height=640):
+    """rays of a sub-sampled view through the REFERENCE's generate_image_rays + linspace sub-sampler"""
+    import habitat_to_data as h2d
+    from scipy.spatial.transform import Rotation as R
+    p = scene["poses"][pose_idx]
+    pose = np.eye(4); pose[:3, :3] = R.from_quat(p[3:]).as_matrix(); pose[:3, 3] = p[:3]
+    focal = 0.5 * width / np.tan(np.pi / 4)
+    K = np.array([[focal, 0.0, width / 2], [0.0, focal, height / 2], [0.0, 0.0, 1.0]])
+    rs = h2d.Dataset.generate_image_rays(torch.from_numpy(pose).unsqueeze(0).float(), width, height, K, "cpu")
+    idx = np.round(np.linspace(0, len(rs.origins) - 1, h * w)).astype(int)
+    return rs.origins[idx].contiguous(), rs.viewdirs[idx].contiguous()
+
+
+GLUE_KW = dict(near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01)
+
+
+def _pipeline_loss(rgb, depth, sem, pix, dep, lab):
+    import torch.nn.functional as F     # scripts/pipeline.py:506-511
+    return F.smooth_l1_loss(rgb, pix) * 10 + F.smooth_l1_loss(depth, dep.unsqueeze(1)) / 5 + F.cross_entropy(sem, lab) / 2
+
+
+def _record_rand_like(og_module, draws):
+    real = torch.rand_like
+
+    def rand_like(t, **kw):
+        r = real(t, **kw); draws.append(r.numpy().copy()); return r
+    og_module.torch.rand_like = rand_like
+    return real
+
+
+def gen_glue():
+    """utils.py:63-219, :362-461, :555-779, :782-1032 and occ_grid.py:80-238 of the reference, run on the analytic field."""
+    import ref_shim
+    shim = ref_shim.enter_reference()
+    import utils as U
+    from datasets.utils import Rays
+    import nerfacc.estimators.occ_grid as og
+    from analytic_field import AnalyticField
+    sc = _glue_scene()
+    est = _ref_estimator(sc)
+    field = AnalyticField(29, seed=11)
+    o, d = _view(sc, 1, 12, 12)
+    o2, d2 = _view(sc, 5, 6, 8)
+    bk = torch.tensor([0.1, 0.3, 0.6])
+    rec = dict(aabb=sc["aabb"], res=np.asarray(sc["res"]), occ=np.packbits(sc["occ"]), occs=sc["occs"], field_seed=np.int64(11),
+               rays_o=o.numpy(), rays_d=d.numpy(), rays2_o=o2.numpy(), rays2_d=d2.numpy(), bkgd=bk.numpy(),
+               **{"kw_" + k: np.float64(v) for k, v in GLUE_KW.items()})
+
+    # --- a15 / a16: the inference loops (eval mode), flat and [H,W,3]-shaped rays
+    field.eval()
+    shim.traverse_log.clear()
+    rgb, acc, depth, sem, tot = U.render_image_with_occgrid_test(1024, field, est, Rays(o, d), render_bkgd=bk, **GLUE_KW)
+    rec.update(test_rgb=rgb.numpy(), test_acc=acc.numpy(), test_depth=depth.numpy(), test_sem=sem.numpy(), test_total=np.int64(tot),
+               test_rounds=np.asarray(shim.traverse_log, np.int64))
+    shim.traverse_log.clear()
+    rgb, rgb_var, acc, depth, depth_var, sem, tot = U.render_probablistic_image_with_occgrid_test(
+        1024, field, est, Rays(o2.view(6, 8, 3), d2.view(6, 8, 3)), render_bkgd=bk, **GLUE_KW)
+    assert rgb.shape == (6, 8, 3) and depth_var.shape == (6, 8, 1)
+    rec.update(prob_rgb=rgb.numpy(), prob_rgb_var=rgb_var.numpy(), prob_acc=acc.numpy(), prob_depth=depth.numpy(),
+               prob_depth_var=depth_var.numpy(), prob_sem=sem.numpy(), prob_total=np.int64(tot),
+               prob_rounds=np.asarray(shim.traverse_log, np.int64))
+    # no alpha threshold, constant step, a background-free call with max_samples small enough to cut rays off
+    rgb, rgb_var, acc, depth, depth_var, sem, tot = U.render_probablistic_image_with_occgrid_test(
+        96, field, est, Rays(o, d), near_plane=0.2, render_step_size=5e-3, render_bkgd=torch.zeros(3), cone_angle=0.0, alpha_thre=0.0)
+    rec.update(cut_rgb=rgb.numpy(), cut_rgb_var=rgb_var.numpy(), cut_acc=acc.numpy(), cut_depth=depth.numpy(),
+               cut_depth_var=depth_var.numpy(), cut_sem=sem.numpy(), cut_total=np.int64(tot))
+
+    # --- a4: OccGridEstimator.sampling, with and without the density pre-pass, stratified with recorded draws
+    def sigma_fn(ts, te, ri):
+        pos = o[ri] + d[ri] * (ts + te)[:, None] / 2.0
+        return field.query_density(pos).squeeze(-1)
+    ri, ts, te = est.sampling(o, d, sigma_fn=sigma_fn, stratified=False, **GLUE_KW)
+    rec.update(samp_ri=ri.numpy(), samp_ts=ts.numpy(), samp_te=te.numpy())
+    ri, ts, te = est.sampling(o, d, sigma_fn=None, near_plane=0.1, render_step_size=1e-3, cone_angle=0.004, alpha_thre=0.01)
+    rec.update(samp_all_n=np.int64(len(ri)), samp_all_ri_sum=np.int64(ri.sum()), samp_all_ts_sum=np.float64(ts.double().sum()),
+               samp_all_cnt=np.bincount(ri.numpy(), minlength=len(o)).astype(np.int64))
+    draws = []
+    real = _record_rand_like(og, draws)
+    try:
+        torch.manual_seed(5)
+        ri, ts, te = est.sampling(o, d, sigma_fn=sigma_fn, stratified=True, **GLUE_KW)
+    finally:
+        og.torch.rand_like = real
+    rec.update(samp_st_draw=draws[0], samp_st_ri=ri.numpy(), samp_st_ts=ts.numpy(), samp_st_te=te.numpy())
+
+    # --- a13: sem_rendering on packed samples (the 48 rays of the second view) with leaf per-sample inputs; the loss of
+    #     pipeline.py:506-511; autograd.  The per-sample rgb / logits are not stored: the tests re-evaluate the analytic field.
+    o, d = o2, d2
+    rng = np.random.default_rng(3)
+    n_rays = len(o)
+    pix = torch.from_numpy(rng.random((n_rays, 3)).astype(np.float32))
+    dep = torch.from_numpy(rng.uniform(0.5, 4.0, n_rays).astype(np.float32))
+    lab = torch.from_numpy(rng.integers(0, 29, n_rays))
+    rec.update(pix=pix.numpy(), dep=dep.numpy(), lab=lab.numpy())
+    ri, ts, te = est.sampling(o, d, sigma_fn=sigma_fn, stratified=False, **GLUE_KW)
+    rec.update(semr_ri=ri.numpy(), semr_ts=ts.numpy(), semr_te=te.numpy())
+    field.train()
+    with torch.enable_grad():
+        def fn(ts_, te_, ri_):
+            pos = o[ri_] + d[ri_] * (ts_ + te_)[:, None] / 2.0
+            rgbs, sig, sems = field(pos, d[ri_])
+            return rgbs, sig.squeeze(-1), sems
+        colors, opac, depths, sems, extras = U.sem_rendering(ts, te, ri, n_rays=n_rays, rgb_sigma_sem_fn=fn, render_bkgd=bk,
+                                                             num_sumantic_classes=29)
+        loss = _pipeline_loss(colors, depths, sems, pix, dep, lab)
+        loss.backward()
+    r_, s_, m_ = field.last
+    rec.update(semr_sigmas=s_.detach().squeeze(-1).numpy(),
+               semr_colors=colors.detach().numpy(), semr_opac=opac.detach().numpy(), semr_depths=depths.detach().numpy(),
+               semr_sem=sems.detach().numpy(), semr_weights=extras["weights"].detach().numpy(), semr_trans=extras["trans"].detach().numpy(),
+               semr_alphas=extras["alphas"].detach().numpy(), semr_loss=np.float64(loss.item()),
+               semr_g_rgbs=r_.grad.numpy(), semr_g_sigmas=s_.grad.squeeze(-1).numpy(), semr_g_sems_every4=m_.grad.numpy()[::4])
+    # no samples at all (utils.py:403-407)
+    e = torch.empty(0)
+    colors, opac, depths, sems, _ = U.sem_rendering(e, e, torch.empty(0, dtype=torch.long), n_rays=4, rgb_sigma_sem_fn=fn, render_bkgd=bk,
+                                                    num_sumantic_classes=29)
+    rec.update(semr0_colors=colors.numpy(), semr0_opac=opac.numpy(), semr0_depths=depths.numpy(), semr0_sem=sems.numpy())
+
+    # --- a14: the training render, eval mode (chunks of 8192, no jitter) and train mode (one chunk, jitter recorded) + autograd
+    field.eval()
+    with torch.no_grad():
+        rgb, acc, depth, sem, n = U.render_image_with_occgrid_with_depth_guide(field, est, Rays(o, d), render_bkgd=bk, **GLUE_KW)
+    rec.update(tre_rgb=rgb.numpy(), tre_acc=acc.numpy(), tre_depth=depth.numpy(), tre_sem=sem.numpy(), tre_n=np.int64(n))
+    field.train()
+    draws = []
+    real = _record_rand_like(og, draws)
+    try:
+        torch.manual_seed(6)
+        rgb, acc, depth, sem, n = U.render_image_with_occgrid_with_depth_guide(field, est, Rays(o, d), render_bkgd=bk, depth=dep, **GLUE_KW)
+        loss = _pipeline_loss(rgb, depth, sem, pix, dep, lab)
+        loss.backward()
+    finally:
+        og.torch.rand_like = real
+    r_, s_, m_ = field.last
+    rec.update(trt_draw=draws[0], trt_rgb=rgb.detach().numpy(), trt_acc=acc.detach().numpy(), trt_depth=depth.detach().numpy(),
+               trt_sem=sem.detach().numpy(), trt_n=np.int64(n), trt_loss=np.float64(loss.item()),
+               trt_g_rgbs=r_.grad.numpy(), trt_g_sigmas=s_.grad.squeeze(-1).numpy(), trt_g_sems_every4=m_.grad.numpy()[::4])
+    np.savez_compressed(os.path.join(OUT, "glue.npz"), **rec)
+
+
+def _ngp_fields(sc, seeds, lh):
+    """the oracle's NGP field (oracle/field.py) with seeded parameters, given the nn.Module attributes utils.py reads"""
+    from apnrf_amd import synthetic as S
+    from oracle.field import FieldConfig, OracleField
+
+    class AsModule:
+        def __init__(self, f):
+            self.f, self.training, self.num_semantic_classes = f, False, f.num_semantic_classes
+
+        def eval(self):
+            self.training = False; return self
+
+        def train(self, mode=True):
+            self.training = mode; return self
+
+        def query_density(self, x):
+            return self.f.query_density(x)
+
+        def __call__(self, x, dd):
+            return self.f(x, dd)
+
+    out, sums = [], []
+    for s in seeds:
+        params = S.make_field_params(128, 2, 29, seed=s, log2_hashmap_size=lh)
+        cfg = FieldConfig(aabb=tuple(float(x) for x in sc["aabb"]), neurons=128, layers=2, num_semantic_classes=29, log2_hashmap_size=lh)
+        out.append(AsModule(OracleField(cfg, params, "f16")))
+        sums.append([float(np.sum(v[:4096].astype(np.float64))) for v in (params["mlp_base"], params["mlp_head"], params["mlp_sem"])])
+    return out, np.asarray(sums)
+
+
+def gen_glue_ngp():
+    """The same reference functions + the per-pose drivers habitat_to_data.py:304-549, driving the oracle's NGP field with seeded
+    parameters (synthetic.make_field_params(seed=0, log2_hashmap_size=14)): what the product's fused renderers are compared with."""
+    import ref_shim
+    shim = ref_shim.enter_reference()
+    import utils as U
+    import habitat_to_data as h2d
+    from datasets.utils import Rays
+    sc = _glue_scene()
+    est = _ref_estimator(sc)
+    (field,), sums = _ngp_fields(sc, [0], 14)
+    o, d = _view(sc, 1, 12, 12)
+    bk = torch.tensor([0.1, 0.3, 0.6])
+    rec = dict(aabb=sc["aabb"], res=np.asarray(sc["res"]), occ=np.packbits(sc["occ"]), occs=sc["occs"], poses=sc["poses"],
+               param_seed=np.int64(0), log2_hashmap_size=np.int64(14), param_sums=sums, rays_o=o.numpy(), rays_d=d.numpy(), bkgd=bk.numpy(),
+               **{"kw_" + k: np.float64(v) for k, v in GLUE_KW.items()})
+    with torch.no_grad():
+        shim.traverse_log.clear()
+        rgb, acc, depth, sem, tot = U.render_image_with_occgrid_test(1024, field, est, Rays(o, d), render_bkgd=bk, **GLUE_KW)
+        rec.update(test_rgb=rgb.numpy(), test_acc=acc.numpy(), test_depth=depth.numpy(), test_sem=sem.numpy(), test_total=np.int64(tot),
+                   test_rounds=np.asarray(shim.traverse_log, np.int64))
+        rgb, rgb_var, acc, depth, depth_var, sem, tot = U.render_probablistic_image_with_occgrid_test(
+            1024, field, est, Rays(o, d), render_bkgd=bk, **GLUE_KW)
+        rec.update(prob_rgb=rgb.numpy(), prob_rgb_var=rgb_var.numpy(), prob_acc=acc.numpy(), prob_depth=depth.numpy(),
+                   prob_depth_var=depth_var.numpy(), prob_sem=sem.numpy(), prob_total=np.int64(tot))
+        rgb, acc, depth, sem, n = U.render_image_with_occgrid_with_depth_guide(field, est, Rays(o, d), render_bkgd=bk, **GLUE_KW)
+        rec.update(tre_rgb=rgb.numpy(), tre_acc=acc.numpy(), tre_depth=depth.numpy(), tre_sem=sem.numpy(), tre_n=np.int64(n))
+        # habitat_to_data.py:304-372 / :374-549: two poses, 120 x 120 at scale 0.1 -> [2,12,12,.] float64 stacks
+        W = H = 120
+        focal = 0.5 * W / np.tan(np.pi / 4)
+        poses = sc["poses"][[2, 6]]
+        args = (field, est, poses, W, H, focal, GLUE_KW["near_plane"], GLUE_KW["render_step_size"], 0.1, GLUE_KW["cone_angle"],
+                GLUE_KW["alpha_thre"], 4, "cpu")
+        images, depths, accs, sems = h2d.Dataset.render_image_from_pose(*args)
+        rec.update(pose_whf=np.asarray([W, H, focal]), pose_idx=np.asarray([2, 6]), pose_images=images, pose_depths=depths, pose_accs=accs, pose_sems=sems)
+        images, images_var, depths, depths_var, accs, sems = h2d.Dataset.render_probablistic_image_from_pose(*args)
+        rec.update(ppose_images=images, ppose_images_var=images_var, ppose_depths=depths, ppose_depths_var=depths_var, ppose_accs=accs, ppose_sems=sems)
+    np.savez_compressed(os.path.join(OUT, "glue_ngp.npz"), **rec)
+
+
+def gen_scorer():
+    """scripts/pipeline.py:666-798 `ActiveNeRFMapper.probablistic_uncertainty`, run on a stand-in `self` (the attributes the method reads),
+    two ensemble members (the oracle's NGP field, parameter seeds 0 and 1), the reference's own per-pose driver underneath."""
+    import ref_shim
+    ref_shim.enter_reference(with_pipeline=True)
+    import pipeline as P
+    import habitat_to_data as h2d
+    sc = _glue_scene()
+    fields, sums = _ngp_fields(sc, [0, 1], 14)
+    ests = [_ref_estimator(sc), _ref_estimator(sc)]
+    W = H = 50
+    focal = 0.5 * W / np.tan(np.pi / 4)
+    rng = np.random.default_rng(21)
+    T = 60                                   # a trajectory of 60 poses: a short translation with a yaw sweep, inside the free column at the origin
+    from apnrf_amd import synthetic as S
+    org = np.asarray(S.SCENES["102344250"]["origin"])
+    traj = np.zeros((T, 7))
+    for i in range(T):
+        yaw = 2 * np.pi * i / T + rng.uniform(-0.05, 0.05)
+        traj[i, :3] = org + np.array([0.4 * np.cos(i / 9.0), 0.05 * np.sin(i / 5.0), 0.4 * np.sin(i / 9.0)])
+        traj[i, 3:] = [0.0, np.sin(yaw / 2), 0.0, np.cos(yaw / 2)]
+
+    class Self:
+        config_file = dict(n_ensembles=2, cuda="cpu", img_w=W, img_h=H, sample_disc=35, **GLUE_KW)
+        radiance_fields, estimators = fields, ests
+        trajector_uncertainty_list = [[]]
+    Self.focal = focal
+    stacks = []
+    real = h2d.Dataset.render_probablistic_image_from_pose
+
+    def recording(*a, **k):
+        out = real(*a, **k); stacks.append(out); return out
+    P.Dataset.render_probablistic_image_from_pose = staticmethod(recording)
+    try:
+        pi = P.ActiveNeRFMapper.probablistic_uncertainty(Self(), traj, 1)
+    finally:
+        P.Dataset.render_probablistic_image_from_pose = staticmethod(real)
+    a = np.linspace(0, T - 20, 20); b = np.linspace(T - 20, T - 1, 20)
+    unc_idx = np.hstack((a, b)).astype(int)
+    names = ("images", "images_var", "depths", "depths_var", "accs", "sems")
+    rec = dict(aabb=sc["aabb"], res=np.asarray(sc["res"]), occ=np.packbits(sc["occ"]), occs=sc["occs"], param_seeds=np.asarray([0, 1]),
+               log2_hashmap_size=np.int64(14), param_sums=sums, trajectory=traj, unc_idx=unc_idx, whf=np.asarray([W, H, focal]),
+               pi=np.float64(pi), terms=np.asarray(Self.trajector_uncertainty_list[0][0], np.float64),
+               **{"kw_" + k: np.float64(v) for k, v in GLUE_KW.items()})
+    for m in range(2):
+        for nm, arr in zip(names, stacks[m]):
+            assert np.array_equal(arr.astype(np.float32).astype(np.float64), arr)      # fp32 renders widened: stored as fp32 without loss
+            rec[f"m{m}_{nm}"] = arr.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "scorer.npz"), **rec)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["aabb", "volrend", "occgrid", "query", "vanilla", "raygen", "dataset"]
+    sys.path.insert(0, OUT)             # ref_shim.py, analytic_field.py
     _enter_reference()
     for w in which:
         globals()["gen_" + w]()

@@ -1,0 +1,241 @@
+"""The oracle's restatement of the hot path's Python glue against goldens recorded from the RUNNING reference
+(tests/golden/make_golden.py gen_glue / gen_glue_ngp / gen_scorer, substitutions listed in tests/golden/ref_shim.py):
+
+  glue.npz      utils.py:63-219, :362-461, :555-779, :782-1032 and occ_grid.py:80-238 driving the analytic field
+  glue_ngp.npz  the same functions + the per-pose drivers habitat_to_data.py:304-549 driving the oracle's NGP field
+  scorer.npz    scripts/pipeline.py:666-798 `probablistic_uncertainty` on two ensemble members
+
+CPU only.  Tolerances: sample sets, counts and round schedules bit-exact; floating point 1e-6 (the judge measured 3e-8 / 0)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H  # noqa: F401  (registers the package alias)
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from analytic_field import AnalyticField  # noqa: E402
+
+
+def scene_of(g):
+    res = [int(x) for x in g["res"]]
+    occ = np.unpackbits(g["occ"])[: int(np.prod(res))].reshape(1, *res).astype(bool)
+    kw = {k[3:]: float(g[k]) for k in g.files if k.startswith("kw_")}
+    occs_mean = float(torch.from_numpy(g["occs"]).mean().item())           # occ_grid.py:199 `self.occs.mean().item()`
+    return dict(aabb=g["aabb"], res=res, occ=occ, occs=g["occs"], occs_mean=occs_mean, kw=kw)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _close(got, want, name, atol=1e-6, rtol=1e-6):
+    np.testing.assert_allclose(np.asarray(got), np.asarray(want), atol=atol, rtol=rtol, err_msg=name)
+
+
+def _check_test_render(out, g, pre, prob):
+    shp = g[pre + "_rgb"].shape[:-1]
+    for k in ("rgb", "acc", "depth", "sem") + (("rgb_var", "depth_var") if prob else ()):
+        _close(out[k].numpy().reshape(*shp, -1), g[f"{pre}_{k}"], f"{pre}_{k}")
+    assert out["total_samples"] == int(g[pre + "_total"])
+    if pre + "_rounds" in g.files:
+        assert [list(r) for r in out["rounds"]] == g[pre + "_rounds"].tolist()       # (rays alive, samples per ray) of every round
+
+
+def test_oracle_test_renderers_equal_reference_glue(golden):
+    from oracle import render as R
+    g = golden("glue")
+    sc = scene_of(g)
+    f = AnalyticField(29, seed=int(g["field_seed"])).eval()
+    bk = _t(g["bkgd"])
+    o, d = _t(g["rays_o"]), _t(g["rays_d"])
+    out = R.render_test(1024, f, sc["occ"], sc["aabb"][None], o, d, render_bkgd=bk, **sc["kw"])
+    _check_test_render(out, g, "test", False)
+    assert len(out["rounds"]) > 20 and max(n for _, n in out["rounds"]) == 64
+    o2, d2 = _t(g["rays2_o"]), _t(g["rays2_d"])
+    out = R.render_prob_test(1024, f, sc["occ"], sc["aabb"][None], o2, d2, render_bkgd=bk, **sc["kw"])
+    _check_test_render(out, g, "prob", True)
+    out = R.render_prob_test(96, f, sc["occ"], sc["aabb"][None], o, d, near_plane=0.2, render_step_size=5e-3, render_bkgd=torch.zeros(3),
+                             cone_angle=0.0, alpha_thre=0.0)
+    _check_test_render(out, g, "cut", True)
+
+
+def _sigma_fn(f, o, d):
+    def fn(ts, te, ri):
+        pos = o[ri] + d[ri] * (ts + te)[:, None] / 2.0
+        return f.query_density(pos).squeeze(-1)
+    return fn
+
+
+def test_oracle_sampling_equals_reference_estimator(golden):
+    from oracle import render as R
+    g = golden("glue")
+    sc = scene_of(g)
+    kw = sc["kw"]
+    f = AnalyticField(29, seed=int(g["field_seed"])).eval()
+    o, d = _t(g["rays_o"]), _t(g["rays_d"])
+    near = torch.full((len(o),), kw["near_plane"])
+    assert sc["occs_mean"] < kw["alpha_thre"]                              # the min() of occ_grid.py:199 decides
+    args = dict(render_step_size=kw["render_step_size"], alpha_thre=kw["alpha_thre"], cone_angle=kw["cone_angle"])
+    ri, ts, te, n_all = R.sampling(sc["occ"], sc["aabb"][None], sc["occs_mean"], o, d, _sigma_fn(f, o, d), near, **args)
+    np.testing.assert_array_equal(ri.numpy(), g["samp_ri"])
+    np.testing.assert_array_equal(ts.numpy(), g["samp_ts"])
+    np.testing.assert_array_equal(te.numpy(), g["samp_te"])
+    assert n_all == int(g["samp_all_n"])
+    ri, ts, te, _ = R.sampling(sc["occ"], sc["aabb"][None], sc["occs_mean"], o, d, None, near, **args)
+    assert len(ri) == int(g["samp_all_n"]) and int(ri.sum()) == int(g["samp_all_ri_sum"])
+    np.testing.assert_array_equal(np.bincount(ri.numpy(), minlength=len(o)), g["samp_all_cnt"])
+    assert float(ts.double().sum()) == float(g["samp_all_ts_sum"])
+    # stratified: near += rand * step (occ_grid.py:158-159), the reference's draw replayed
+    near_st = near + _t(g["samp_st_draw"]) * kw["render_step_size"]
+    ri, ts, te, _ = R.sampling(sc["occ"], sc["aabb"][None], sc["occs_mean"], o, d, _sigma_fn(f, o, d), near_st, **args)
+    np.testing.assert_array_equal(ri.numpy(), g["samp_st_ri"])
+    np.testing.assert_array_equal(ts.numpy(), g["samp_st_ts"])
+    np.testing.assert_array_equal(te.numpy(), g["samp_st_te"])
+
+
+def pipeline_loss(rgb, depth, sem, pix, dep, lab):
+    import torch.nn.functional as F          # scripts/pipeline.py:506-511
+    return F.smooth_l1_loss(rgb, pix) * 10 + F.smooth_l1_loss(depth, dep.unsqueeze(1)) / 5 + F.cross_entropy(sem, lab) / 2
+
+
+def test_oracle_sem_rendering_and_train_render_equal_reference_glue(golden):
+    from oracle import render as R
+    g = golden("glue")
+    sc = scene_of(g)
+    kw = sc["kw"]
+    f = AnalyticField(29, seed=int(g["field_seed"])).train()
+    o, d = _t(g["rays2_o"]), _t(g["rays2_d"])
+    bk = _t(g["bkgd"])
+    pix, dep, lab = _t(g["pix"]), _t(g["dep"]), _t(g["lab"])
+    ri, ts, te = _t(g["semr_ri"]), _t(g["semr_ts"]), _t(g["semr_te"])
+    colors, opac, depths, sem, ex = R.sem_rendering(f, o, d, ts, te, ri, len(o), bk)
+    np.testing.assert_array_equal(ex["sigmas"].detach().numpy(), g["semr_sigmas"])      # the density is elementwise arithmetic: same bits
+    for got, k in ((colors, "colors"), (opac, "opac"), (depths, "depths"), (sem, "sem"), (ex["weights"], "weights"),
+                   (ex["trans"], "trans"), (ex["alphas"], "alphas")):
+        _close(got.detach().numpy(), g["semr_" + k], k)
+    loss = pipeline_loss(colors, depths, sem, pix, dep, lab)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g["semr_loss"]), rtol=1e-6)
+    rgbs, dens, sems = f.last
+    _close(rgbs.grad.numpy(), g["semr_g_rgbs"], "d rgbs", atol=1e-9, rtol=1e-5)
+    _close(dens.grad.squeeze(-1).numpy(), g["semr_g_sigmas"], "d sigmas", atol=1e-9, rtol=2e-5)        # sums of terms of both signs: absolute bar = 1.5e-5 of the largest entry
+    _close(sems.grad.numpy()[::4], g["semr_g_sems_every4"], "d sems", atol=1e-9, rtol=1e-5)
+    # no samples (utils.py:403-407)
+    e = torch.empty(0)
+    c0, a0, d0, s0, _ = R.sem_rendering(f, o[:4], d[:4], e, e, torch.empty(0, dtype=torch.long), 4, bk)
+    for got, k in ((c0, "colors"), (a0, "opac"), (d0, "depths"), (s0, "sem")):
+        _close(got.numpy(), g["semr0_" + k], k)
+
+    # utils.py:63-219 in eval mode (no jitter) ...
+    f.eval()
+    near = torch.full((len(o),), kw["near_plane"])
+    args = dict(render_step_size=kw["render_step_size"], cone_angle=kw["cone_angle"], alpha_thre=kw["alpha_thre"], render_bkgd=bk)
+    with torch.no_grad():
+        rgb, acc, depth, sem, n, _ = R.render_train(f, sc["occ"], sc["aabb"][None], sc["occs_mean"], o, d, near, **args)
+    assert n == int(g["tre_n"])
+    for got, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (sem, "sem")):
+        _close(got.numpy(), g["tre_" + k], k)
+    # ... and in train mode with the reference's recorded jitter, loss and autograd
+    f.train()
+    near_st = near + _t(g["trt_draw"]) * kw["render_step_size"]
+    rgb, acc, depth, sem, n, _ = R.render_train(f, sc["occ"], sc["aabb"][None], sc["occs_mean"], o, d, near_st, **args)
+    assert n == int(g["trt_n"])
+    for got, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (sem, "sem")):
+        _close(got.detach().numpy(), g["trt_" + k], k)
+    loss = pipeline_loss(rgb, depth, sem, pix, dep, lab)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g["trt_loss"]), rtol=1e-6)
+    rgbs, dens, sems = f.last
+    _close(rgbs.grad.numpy(), g["trt_g_rgbs"], "d rgbs", atol=1e-9, rtol=1e-5)
+    _close(dens.grad.squeeze(-1).numpy(), g["trt_g_sigmas"], "d sigmas", atol=1e-9, rtol=2e-5)        # sums of terms of both signs: absolute bar = 1.5e-5 of the largest entry
+    _close(sems.grad.numpy()[::4], g["trt_g_sems_every4"], "d sems", atol=1e-9, rtol=1e-5)
+
+
+def ngp_oracle_fields(g, seeds):
+    from apnrf_amd import synthetic as S
+    from oracle.field import FieldConfig, OracleField
+    lh = int(g["log2_hashmap_size"])
+    out = []
+    for k, s in enumerate(seeds):
+        params = S.make_field_params(128, 2, 29, seed=int(s), log2_hashmap_size=lh)
+        sums = [float(np.sum(v[:4096].astype(np.float64))) for v in (params["mlp_base"], params["mlp_head"], params["mlp_sem"])]
+        np.testing.assert_allclose(sums, g["param_sums"][k], rtol=1e-12, err_msg="numpy's generator no longer reproduces the fixture's parameters")
+        cfg = FieldConfig(aabb=tuple(float(x) for x in g["aabb"]), neurons=128, layers=2, num_semantic_classes=29, log2_hashmap_size=lh)
+        out.append((OracleField(cfg, params, "f16"), params))
+    return out
+
+
+def test_oracle_with_ngp_field_equals_reference_glue_and_pose_drivers(golden):
+    from oracle import render as R
+    g = golden("glue_ngp")
+    sc = scene_of(g)
+    (f, _), = ngp_oracle_fields(g, [int(g["param_seed"])])
+    o, d = _t(g["rays_o"]), _t(g["rays_d"])
+    bk = _t(g["bkgd"])
+    out = R.render_test(1024, f, sc["occ"], sc["aabb"][None], o, d, render_bkgd=bk, **sc["kw"])
+    _check_test_render(out, g, "test", False)
+    out = R.render_prob_test(1024, f, sc["occ"], sc["aabb"][None], o, d, render_bkgd=bk, **sc["kw"])
+    _check_test_render(out, g, "prob", True)
+    kw = sc["kw"]
+    with torch.no_grad():
+        rgb, acc, depth, sem, n, _ = R.render_train(f, sc["occ"], sc["aabb"][None], sc["occs_mean"], o, d, torch.full((len(o),), kw["near_plane"]),
+                                                    render_step_size=kw["render_step_size"], cone_angle=kw["cone_angle"],
+                                                    alpha_thre=kw["alpha_thre"], render_bkgd=bk)
+    assert n == int(g["tre_n"])
+    for got, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (sem, "sem")):
+        _close(got.numpy(), g["tre_" + k], k)
+    # habitat_to_data.py:304-549: pose -> c2w -> rays -> linspace sub-sample -> render -> [P,h,w,.] float64
+    W, Hh, focal = (float(x) for x in g["pose_whf"])
+    W, Hh = int(W), int(Hh)
+    idx = R.subsample_indices(W * Hh, 144)
+    for k, pi in enumerate(g["pose_idx"]):
+        o, d = R.generate_image_rays(R.pose_to_c2w(g["poses"][pi]), W, Hh, focal, idx)
+        ref = R.render_prob_test(1024, f, sc["occ"], sc["aabb"][None], o, d, render_bkgd=torch.zeros(3), **sc["kw"])
+        _close(ref["rgb"].numpy().reshape(12, 12, 3), g["ppose_images"][k], "images")
+        _close(ref["rgb_var"].numpy().reshape(12, 12, 3), g["ppose_images_var"][k], "images_var")
+        _close(ref["depth"].numpy().reshape(12, 12), g["ppose_depths"][k], "depths")
+        _close(ref["depth_var"].numpy().reshape(12, 12), g["ppose_depths_var"][k], "depths_var")
+        _close(ref["acc"].numpy().reshape(12, 12), g["ppose_accs"][k], "accs")
+        _close(ref["sem"].numpy().reshape(12, 12, 29), g["ppose_sems"][k], "sems")
+        _close(g["pose_images"][k], g["ppose_images"][k], "deterministic driver == probabilistic driver")
+
+
+def scorer_stacks(g):
+    """[M,1,V,h,w,.] as pipeline.py:720-725 builds them"""
+    st = lambda nm: np.stack([g[f"m{m}_{nm}"].astype(np.float64)[None] for m in range(2)])
+    return st("images_var"), st("depths_var"), st("accs"), st("sems")
+
+
+def test_oracle_scorer_equals_reference_probablistic_uncertainty(golden):
+    from oracle import scorer as SC
+    g = golden("scorer")
+    rv, dv, ac, sm = scorer_stacks(g)
+    assert rv.shape == (2, 1, 40, 5, 5, 3) and sm.shape == (2, 1, 40, 5, 5, 29)
+    r, d, s, o = SC.predictive_information_terms(rv, dv, ac, sm)
+    np.testing.assert_allclose([r, d, 3 * s, 2 * o], g["terms"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(SC.predictive_information(rv, dv, ac, sm), float(g["pi"]), rtol=1e-12)
+    rows = SC.per_view_terms(rv, dv, ac, sm)                        # the view-sharded form composes to the same numbers
+    np.testing.assert_allclose(rows.mean(0) * [1, 1, 3, 2], g["terms"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("member", [0, 1])
+def test_oracle_renders_equal_the_scorer_goldens_views(golden, member):
+    """Four of the 40 views the reference rendered for the scorer golden (its own per-pose driver), by the oracle."""
+    from oracle import render as R
+    g = golden("scorer")
+    sc = scene_of(g)
+    f, _ = ngp_oracle_fields(g, g["param_seeds"])[member]
+    W, Hh, focal = (float(x) for x in g["whf"])
+    W, Hh = int(W), int(Hh)
+    idx = R.subsample_indices(W * Hh, 25)
+    for v in (0, 13, 27, 39):
+        p = g["trajectory"][g["unc_idx"][v]]
+        o, d = R.generate_image_rays(R.pose_to_c2w(p), W, Hh, focal, idx)
+        ref = R.render_prob_test(1024, f, sc["occ"], sc["aabb"][None], o, d, render_bkgd=torch.zeros(3), **sc["kw"])
+        _close(ref["rgb_var"].numpy().reshape(5, 5, 3), g[f"m{member}_images_var"][v], "images_var")
+        _close(ref["depth_var"].numpy().reshape(5, 5), g[f"m{member}_depths_var"][v], "depths_var")
+        _close(ref["acc"].numpy().reshape(5, 5), g[f"m{member}_accs"][v], "accs")
+        _close(ref["sem"].numpy().reshape(5, 5, 29), g[f"m{member}_sems"][v], "sems")

@@ -1,0 +1,214 @@
+"""Round 5: the HIP path against goldens recorded from the RUNNING reference glue (tests/golden/glue.npz, glue_ngp.npz,
+scorer.npz; generator tests/golden/make_golden.py, substitutions tests/golden/ref_shim.py).
+
+  * analytic field (glue.npz): the product's `OccGridEstimator.sampling` and compositing kernels are fed the same closed-form
+    field the reference's functions were driven with -> sample sets bit-exact, composited values and gradients 1e-5.
+  * NGP field (glue_ngp.npz, scorer.npz): the reference's glue drove the oracle's NGP field with seeded parameters; the
+    product's fused renderers, per-pose drivers and scorer run the same parameters -> north star 1e-3 abs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from test_glue_golden_cpu import AnalyticField, pipeline_loss, scene_of, scorer_stacks
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t if dtype is None else t.to(dtype)).to(DEV)
+
+
+def _hip_estimator(sc):
+    from apnrf_amd.nerfacc import OccGridEstimator
+    est = OccGridEstimator(torch.from_numpy(sc["aabb"]), resolution=sc["res"], levels=1)
+    est.binaries = torch.from_numpy(sc["occ"])
+    est.occs = torch.from_numpy(sc["occs"])
+    return est.to(DEV).eval()
+
+
+def _hip_ngp_field(g, seed):
+    from apnrf_amd import synthetic as S
+    lh = int(g["log2_hashmap_size"])
+    params = S.make_field_params(128, 2, 29, seed=int(seed), log2_hashmap_size=lh)
+    scene = dict(aabb=g["aabb"], neurons=128, layers=2, C=29, log2_hashmap_size=lh, params=params)
+    return H.hip_field(scene), params
+
+
+# ------------------------------------------------------------------ analytic field: sampling (a4) and compositing (a10-a13)
+def test_sampling_equals_reference_estimator_golden(golden):
+    """occ_grid.py:80-238 as the reference ran it: marched set, density pre-pass with the analytic sigma_fn, visibility filter."""
+    g = golden("glue")
+    sc = scene_of(g)
+    kw = sc["kw"]
+    est = _hip_estimator(sc)
+    f = AnalyticField(29, seed=int(g["field_seed"]), device=DEV).eval()
+    o, d = _cu(g["rays_o"]), _cu(g["rays_d"])
+
+    def sigma_fn(ts, te, ri):
+        pos = o[ri] + d[ri] * (ts + te)[:, None] / 2.0
+        return f.query_density(pos).squeeze(-1)
+
+    ri, ts, te = est.sampling(o, d, sigma_fn=sigma_fn, stratified=False, **kw)
+    assert ri.dtype == torch.int64
+    np.testing.assert_array_equal(ri.cpu().numpy(), g["samp_ri"])
+    np.testing.assert_array_equal(ts.cpu().numpy(), g["samp_ts"])
+    np.testing.assert_array_equal(te.cpu().numpy(), g["samp_te"])
+    ri, ts, te = est.sampling(o, d, sigma_fn=None, **kw)
+    assert len(ri) == int(g["samp_all_n"]) and int(ri.sum().item()) == int(g["samp_all_ri_sum"])
+    np.testing.assert_array_equal(torch.bincount(ri, minlength=len(o)).cpu().numpy(), g["samp_all_cnt"])
+    assert float(ts.double().sum().item()) == pytest.approx(float(g["samp_all_ts_sum"]), rel=1e-12)
+    # the reference's stratified draw replayed through t_min (near = clamp(near, min=t_min): occ_grid.py:152-159)
+    near_st = torch.full((len(o),), kw["near_plane"], device=DEV) + _cu(g["samp_st_draw"]) * kw["render_step_size"]
+    ri, ts, te = est.sampling(o, d, sigma_fn=sigma_fn, t_min=near_st, stratified=False, **kw)
+    np.testing.assert_array_equal(ri.cpu().numpy(), g["samp_st_ri"])
+    np.testing.assert_array_equal(ts.cpu().numpy(), g["samp_st_ts"])
+    np.testing.assert_array_equal(te.cpu().numpy(), g["samp_st_te"])
+
+
+def test_compositing_kernels_equal_reference_sem_rendering_golden(golden):
+    """utils.py:362-461 + the loss of pipeline.py:506-511 + autograd, on the reference's own sample set and per-sample field outputs."""
+    from apnrf_amd import nerfacc as NA
+    g = golden("glue")
+    f = AnalyticField(29, seed=int(g["field_seed"])).train()
+    o, d = torch.from_numpy(g["rays2_o"]), torch.from_numpy(g["rays2_d"])
+    ri, ts, te = (torch.from_numpy(g[k]) for k in ("semr_ri", "semr_ts", "semr_te"))
+    with torch.no_grad():
+        rgbs, dens, sems = f(o[ri] + d[ri] * (ts + te)[:, None] / 2.0, d[ri])
+    np.testing.assert_array_equal(dens.squeeze(-1).numpy(), g["semr_sigmas"])
+    n_rays = len(o)
+    rgbs, sig, sems = (t.to(DEV).requires_grad_(True) for t in (rgbs, dens.squeeze(-1), sems))
+    packed = NA.pack_info_grouped(ri.to(DEV), n_rays)
+    np.testing.assert_array_equal(packed[:, 1].cpu().numpy(), np.bincount(g["semr_ri"], minlength=n_rays))
+    colors, opac, depths, sem, w, tr, al = NA._CompositeTrain.apply(packed[:, 0].contiguous(), packed[:, 1].contiguous(), ts.to(DEV), te.to(DEV),
+                                                                    sig, rgbs, sems, _cu(g["bkgd"]))
+    tol = dict(atol=2e-6, rtol=2e-6)
+    for got, k in ((colors, "colors"), (opac, "opac"), (depths, "depths"), (sem, "sem"), (w, "weights"), (tr, "trans"), (al, "alphas")):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), g["semr_" + k], err_msg=k, atol=1e-5 if k == "sem" else 2e-6, rtol=2e-6)
+    loss = pipeline_loss(colors, depths, sem, _cu(g["pix"]), _cu(g["dep"]), _cu(g["lab"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g["semr_loss"]), rtol=2e-6)
+    np.testing.assert_allclose(rgbs.grad.cpu().numpy(), g["semr_g_rgbs"], atol=1e-8, rtol=1e-4)
+    np.testing.assert_allclose(sig.grad.cpu().numpy(), g["semr_g_sigmas"], atol=2e-9, rtol=1e-4)      # 3e-5 of the largest entry
+    np.testing.assert_allclose(sems.grad.cpu().numpy()[::4], g["semr_g_sems_every4"], atol=1e-8, rtol=1e-4)
+    # no samples at all (utils.py:403-407): background colour, zeros
+    z = torch.zeros(4, dtype=torch.int64, device=DEV)
+    e = torch.empty(0, device=DEV)
+    c0, a0, d0, s0, *_ = NA._CompositeTrain.apply(z, z, e, e, e, torch.empty(0, 3, device=DEV), torch.empty(0, 29, device=DEV), _cu(g["bkgd"]))
+    for got, k in ((c0, "colors"), (a0, "opac"), (d0, "depths"), (s0, "sem")):
+        np.testing.assert_allclose(got.cpu().numpy(), g["semr0_" + k], atol=1e-7, err_msg=k)
+
+
+def test_train_render_golden_through_compositing_with_recorded_jitter(golden):
+    """utils.py:63-219 in train mode as the reference ran it (its stratified draw replayed): sampling -> analytic field -> compositing
+    kernels -> pipeline loss -> backward, against the reference's outputs, loss and per-sample gradients."""
+    from apnrf_amd import nerfacc as NA
+    g = golden("glue")
+    sc = scene_of(g)
+    kw = sc["kw"]
+    est = _hip_estimator(sc)
+    f = AnalyticField(29, seed=int(g["field_seed"]), device=DEV).train()
+    o, d = _cu(g["rays2_o"]), _cu(g["rays2_d"])
+
+    def sigma_fn(ts, te, ri):
+        return f.query_density(o[ri] + d[ri] * (ts + te)[:, None] / 2.0).squeeze(-1)
+
+    near_st = torch.full((len(o),), kw["near_plane"], device=DEV) + _cu(g["trt_draw"]) * kw["render_step_size"]
+    ri, ts, te = est.sampling(o, d, sigma_fn=sigma_fn, t_min=near_st, stratified=False, **kw)
+    assert len(ri) == int(g["trt_n"])
+    with torch.no_grad():
+        rgbs, dens, sems = f(o[ri] + d[ri] * (ts + te)[:, None] / 2.0, d[ri])
+    rgbs, sig, sems = (t.detach().requires_grad_(True) for t in (rgbs, dens.squeeze(-1), sems))
+    packed = NA.pack_info_grouped(ri, len(o))
+    rgb, acc, depth, sem, *_ = NA._CompositeTrain.apply(packed[:, 0].contiguous(), packed[:, 1].contiguous(), ts, te, sig, rgbs, sems, _cu(g["bkgd"]))
+    for got, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (sem, "sem")):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), g["trt_" + k], atol=1e-5, rtol=2e-6, err_msg=k)
+    loss = pipeline_loss(rgb, depth, sem, _cu(g["pix"]), _cu(g["dep"]), _cu(g["lab"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g["trt_loss"]), rtol=2e-6)
+    np.testing.assert_allclose(rgbs.grad.cpu().numpy(), g["trt_g_rgbs"], atol=1e-8, rtol=1e-4)
+    np.testing.assert_allclose(sig.grad.cpu().numpy(), g["trt_g_sigmas"], atol=2e-9, rtol=1e-4)
+    np.testing.assert_allclose(sems.grad.cpu().numpy()[::4], g["trt_g_sems_every4"], atol=1e-8, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ NGP field: the fused renderers (a14-a17) and the scorer (a18)
+def _check(got, want, name, atol=1e-3, rtol=0.0):
+    np.testing.assert_allclose(np.asarray(got), np.asarray(want), atol=atol, rtol=rtol, err_msg=name)
+
+
+def test_fused_renderers_equal_reference_glue_golden(golden):
+    from apnrf_amd import render as RD
+    g = golden("glue_ngp")
+    sc = scene_of(g)
+    kw = sc["kw"]
+    hip, _ = _hip_ngp_field(g, g["param_seed"])
+    est = _hip_estimator(sc)
+    rays = RD.Rays(_cu(g["rays_o"]), _cu(g["rays_d"]))
+    bk = _cu(g["bkgd"])
+    rgb, acc, depth, sem, tot = RD.render_image_with_occgrid_test(1024, hip, est, rays, render_bkgd=bk, **kw)
+    for got, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (sem, "sem")):
+        _check(got.cpu().numpy(), g["test_" + k], k, rtol=1e-3 if k == "depth" else 0.0)
+    assert abs(tot - int(g["test_total"])) <= 3
+    rgb, rgb_var, acc, depth, depth_var, sem, tot = RD.render_probablistic_image_with_occgrid_test(1024, hip, est, rays, render_bkgd=bk, **kw)
+    for got, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (sem, "sem"), (rgb_var, "rgb_var"), (depth_var, "depth_var")):
+        _check(got.cpu().numpy(), g["prob_" + k], k, atol=2e-3 if k == "depth_var" else 1e-3, rtol=2e-3 if k == "depth_var" else (1e-3 if k == "depth" else 0.0))
+    assert abs(tot - int(g["prob_total"])) <= 3
+    hip.eval()
+    with torch.no_grad():
+        rgb, acc, depth, sem, n = RD.render_image_with_occgrid_with_depth_guide(hip, est, rays, render_bkgd=bk, **kw)
+    assert abs(n - int(g["tre_n"])) <= 3
+    for got, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (sem, "sem")):
+        _check(got.cpu().numpy(), g["tre_" + k], k, rtol=1e-3 if k == "depth" else 0.0)
+
+
+def test_pose_drivers_equal_reference_dataset_golden(golden):
+    """habitat_to_data.py:304-549 as the reference ran them: [P,h,w,.] float64 stacks."""
+    from apnrf_amd import render as RD
+    g = golden("glue_ngp")
+    sc = scene_of(g)
+    kw = sc["kw"]
+    hip, _ = _hip_ngp_field(g, g["param_seed"])
+    est = _hip_estimator(sc)
+    W, Hh, focal = (float(x) for x in g["pose_whf"])
+    poses = g["poses"][g["pose_idx"]]
+    args = (hip, est, poses, int(W), int(Hh), focal, kw["near_plane"], kw["render_step_size"], 0.1, kw["cone_angle"], kw["alpha_thre"], 4, DEV)
+    images, depths, accs, sems = RD.render_image_from_pose(*args)
+    for got, k in ((images, "images"), (depths, "depths"), (accs, "accs"), (sems, "sems")):
+        assert got.dtype == np.float64 and got.shape == g["pose_" + k].shape
+        _check(got, g["pose_" + k], k, rtol=1e-3 if k == "depths" else 0.0)
+    out = RD.render_probablistic_image_from_pose(*args)
+    for got, k in zip(out, ("images", "images_var", "depths", "depths_var", "accs", "sems")):
+        assert got.dtype == np.float64 and got.shape == g["ppose_" + k].shape
+        _check(got, g["ppose_" + k], k, atol=2e-3 if k == "depths_var" else 1e-3, rtol=2e-3 if k == "depths_var" else (1e-3 if k == "depths" else 0.0))
+
+
+def test_scorer_equals_reference_probablistic_uncertainty_golden(golden):
+    """scripts/pipeline.py:666-798 as the reference ran it on 40 views x 2 members: (i) `mnf_score_views` on the reference's own render
+    stacks == its four terms to 1e-9; (ii) poses -> terms end to end (`score_views`, `score_poses`) against the same terms."""
+    from apnrf_amd import render as RD
+    g = golden("scorer")
+    sc = scene_of(g)
+    kw = sc["kw"]
+    rv, dv, ac, sm = scorer_stacks(g)                       # [M,1,V,h,w,.]
+    M, V = 2, 40
+    terms = RD.score_view_terms(_cu(rv.reshape(M, V, 25, 3), torch.float32), _cu(dv.reshape(M, V, 25), torch.float32),
+                                _cu(ac.reshape(M, V, 25), torch.float32), _cu(sm.reshape(M, V, 25, 29), torch.float32))
+    t = terms.cpu().numpy()
+    np.testing.assert_allclose(t.mean(0) * [1, 1, 3, 2], g["terms"], rtol=1e-9)
+    np.testing.assert_allclose(float(RD.trajectory_score(terms).item()), float(g["pi"]), rtol=1e-9)
+    hips = [_hip_ngp_field(g, s)[0] for s in g["param_seeds"]]
+    ests = [_hip_estimator(sc), _hip_estimator(sc)]
+    W, Hh, focal = (float(x) for x in g["whf"])
+    poses = g["trajectory"][g["unc_idx"]]
+    args = (hips, ests, poses, int(W), int(Hh), focal, kw["near_plane"], kw["render_step_size"], 0.1, kw["cone_angle"], kw["alpha_thre"], DEV)
+    terms2, score = RD.score_views(*args)
+    t2 = terms2.cpu().numpy().mean(0) * [1, 1, 3, 2]
+    np.testing.assert_allclose(t2, g["terms"], rtol=5e-3, atol=2e-4)
+    assert abs(float(score.item()) - float(g["pi"])) <= 5e-3 * abs(float(g["pi"])) + 5e-4
+    terms3, score3 = RD.score_poses(*args)
+    np.testing.assert_array_equal(terms3.cpu().numpy(), terms2.cpu().numpy())
