@@ -116,11 +116,11 @@ def _timed(fn, warm, iters):
     return float(np.median(ts))
 
 
-def _oracle_field(scene, requires_grad=False):
+def _oracle_field(scene, requires_grad=False, accum="whole"):
     from oracle.field import FieldConfig, OracleField
     cfg = FieldConfig(aabb=tuple(float(x) for x in scene["aabb"]), neurons=scene["neurons"], layers=scene["layers"],
                       num_semantic_classes=scene["C"], log2_hashmap_size=scene["log2_hashmap_size"])
-    return OracleField(cfg, scene["params"], "f16", requires_grad)
+    return OracleField(cfg, scene["params"], "f16", requires_grad, accum=accum)
 
 
 def _thread_sweep(fn, unit_count, set_threads, budget_s=25.0):
@@ -220,18 +220,28 @@ def cpu_baselines(scene, scene_score, poses, score_pose, width, height, focal, g
     got = RD.render_views(gpu_field, gpu_est, o.to(dev), d.to(dev), S_ * S_, 1024, render_bkgd=bk, **SC.RENDER_KW)
     r = ref["r"]
     errs = {k: (got[k].cpu() - r[k]).abs().reshape(S_ * S_, -1).max(dim=1).values.numpy() for k in ("rgb", "acc", "depth", "sem")}
-    # rgb / acc / depth: 1e-3 absolute (north star).  The composited class logits are unbounded (up to ~55 on this scene): their error is
-    # measured against max(1, largest |logit| of the ray) — 1e-3 absolute for logits up to 1, relative beyond (the fp16 arithmetic itself
-    # moves these logits by ~1e-2 relative against an fp32 field: tools/debug_parity.py)
-    sem_mag = np.maximum(1.0, r["sem"].abs().max(dim=1).values.numpy())
+    # rgb / acc / depth: 1e-3 absolute (north star).  The composited class logits are un-normalised sums of raw logits (up to ~55 on this scene):
+    # their bar is max(1e-3, 3e-4 x largest |logit| of the ray) = three times the NOISE FLOOR measured right here — the same model through the
+    # oracle a second time with every layer's fp32 products added in another order (oracle/field.py accum="k16_reversed"): what two faithful
+    # fp16-operand / fp32-accumulate implementations differ by (tests/test_oracle_noise_floor_cpu.py: ~1e-4 of the logit at every scale).
+    r2 = R.render_test(1024, _oracle_field(scene, accum="k16_reversed"), scene["occ"], scene["aabb"][None], o, d, render_bkgd=bk, **SC.RENDER_KW)
+    nf = {k: (r2[k] - r[k]).abs().reshape(S_ * S_, -1).max(dim=1).values.numpy() for k in ("rgb", "acc", "depth", "sem")}
+    mag = r["sem"].abs().max(dim=1).values.numpy()
+    sem_scale = np.maximum(1.0, 0.3 * mag)
     raw_sem = errs["sem"].copy()
-    errs["sem"] = errs["sem"] / sem_mag
+    errs["sem"] = errs["sem"] / sem_scale
     worst = np.max(np.stack(list(errs.values())), axis=0)
     tie = worst > 1e-3
     mse = float(((got["rgb"].cpu() - r["rgb"]) ** 2).mean())
     parity = {"rays": S_ * S_, "max_abs": {k: float(v[~tie].max()) for k, v in errs.items()}, "tolerance": 1e-3,
-              "sem_error_is": "abs error / max(1, largest |composited logit| of the ray)", "sem_max_abs_unscaled": float(raw_sem.max()),
-              "sem_rays_above_1e-3_unscaled": int((raw_sem > 1e-3).sum()), "sem_largest_logit": float(sem_mag.max()),
+              "sem_error_is": "abs error / max(1, 0.3 x largest |composited logit| of the ray): the bar is max(1e-3, 3e-4 x |logit|)",
+              "sem_max_abs_unscaled": float(raw_sem.max()), "sem_max_rel_to_logit": float((raw_sem / np.maximum(1.0, mag)).max()),
+              "sem_rays_above_1e-3_unscaled": int((raw_sem > 1e-3).sum()), "sem_largest_logit": float(mag.max()),
+              "noise_floor": {"what": "oracle vs the same oracle with permuted fp32 accumulation order (same fp16 operands), same rays",
+                              "sem_abs": float(nf["sem"].max()), "sem_rel_to_logit": float((nf["sem"] / np.maximum(1.0, mag)).max()),
+                              "sem_rays_above_1e-3": int((nf["sem"] > 1e-3).sum()), "rgb_abs": float(nf["rgb"].max()), "acc_abs": float(nf["acc"].max()),
+                              "depth_abs": float(nf["depth"].max()), "total_samples": int(r2["total_samples"])},
+              "noise_floor_abs": float(nf["sem"].max()),
               "tie_rays": int(tie.sum()), "tie_rays_max_abs": float(worst[tie].max()) if tie.any() else 0.0, "tie_budget": "<= 2 rays up to 5e-2",
               "psnr_db": float(10 * np.log10(1.0 / max(mse, 1e-20))), "total_samples_gpu": int(got["total"][0]), "total_samples_oracle": int(r["total_samples"]),
               "what": "HIP render vs oracle render of the SAME trained scene and rays (stand-alone call: the round schedule of a 576-ray call)"}

@@ -148,13 +148,19 @@ class OracleField:
     """forward / query_density with the ngp.py call surface, torch CPU fp32."""
 
     def __init__(self, cfg: FieldConfig, params: Dict[str, np.ndarray], precision: str = "f16", requires_grad: bool = False,
-                 blend: str = "f32"):
+                 blend: str = "f32", accum: str = "whole"):
         """blend: precision of the 8-corner interpolation of a hash level.  "f32" (default): fp32 weight x fp16 entry summed in fp32 (one rounding
         when the feature enters the network).  "f16": tiny-cuda-nn's published kernel with T = __half (grid.h `kernel_grid`): the weight is cast to
         half and `result = fma((T)weight, value, result)` runs in half precision, corners in index order.  Which of the two the reference's
         un-pinned tinycudann computes cannot be checked here (parity unpinned); the product's mirror is mnf_field_config.blend_fp16."""
         self.cfg = cfg
         self.blend = blend
+        # accum: the ORDER in which a layer's fp32 products are added up.  "whole": one torch matmul per layer (the parity reference).
+        # "k16_reversed": the contraction cut into the 16-wide k blocks a matrix-core instruction consumes, block sums added last block
+        # first.  Both are correct fp32 accumulations of the same fp16 operands; they differ by fp32 rounding, which the fp16 rounding of
+        # the next layer's input turns into occasional one-ulp (2^-11 relative) flips.  Used only to MEASURE that noise floor
+        # (tests/test_oracle_noise_floor_cpu.py, bench_parity.noise_floor): what two faithful implementations may differ by.
+        self.accum = accum
         self.precision = precision
         self.num_semantic_classes = cfg.num_semantic_classes
         self.aabb = torch.tensor(cfg.aabb, dtype=torch.float32)
@@ -245,11 +251,21 @@ class OracleField:
         ]
         return torch.stack(o, -1)
 
+    def _mm(self, h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        if self.accum == "whole":
+            return h @ w.t()
+        assert self.accum == "k16_reversed", self.accum
+        out = None
+        for k0 in reversed(range(0, h.shape[1], 16)):
+            part = h[:, k0:k0 + 16] @ w[:, k0:k0 + 16].t()
+            out = part if out is None else out + part
+        return out
+
     def _mlp(self, h: torch.Tensor, ws: List[torch.Tensor]) -> torch.Tensor:
         h = _q(h, self.precision)
         for w in ws[:-1]:
-            h = _q(torch.relu(h @ w.t()), self.precision)
-        out = h @ ws[-1].t()
+            h = _q(torch.relu(self._mm(h, w)), self.precision)
+        out = self._mm(h, ws[-1])
         # "tcnn": the network hands its outputs over in fp16 (ngp.py:181-200, :210-220 widen them with `.to(x)`)
         return _q(out, "f16") if self.precision == "tcnn" else out
 
