@@ -2,7 +2,7 @@
 memory and streams; tensors cross the boundary as raw device pointers."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uint64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 import torch
 
@@ -15,15 +15,23 @@ class MnfError(RuntimeError):
     """Raised for any non-zero return code of the C ABI (mirrors TORCH_CHECK -> RuntimeError)."""
 
 
-class FieldConfig(ctypes.Structure):
-    _fields_ = [("aabb", c_float * 6), ("neurons", c_int32), ("layers", c_int32),
+class _Sized(ctypes.Structure):
+    """include/mi355nerf.h MNF_INIT: zero-filled (ctypes does that) with `struct_size` = sizeof(the struct)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = ctypes.sizeof(self)
+
+
+class FieldConfig(_Sized):
+    _fields_ = [("struct_size", c_uint32), ("aabb", c_float * 6), ("neurons", c_int32), ("layers", c_int32),
                 ("num_semantic_classes", c_int32), ("n_levels", c_int32), ("n_features", c_int32),
                 ("log2_hashmap_size", c_int32), ("base_resolution", c_int32), ("max_resolution", c_int32),
                 ("output_fp16", c_int32), ("mfma_bf16", c_int32), ("blend_fp16", c_int32)]
 
 
-class TrainOpts(ctypes.Structure):
-    _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float), ("cone_angle", c_float),
+class TrainOpts(_Sized):
+    _fields_ = [("struct_size", c_uint32), ("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float), ("cone_angle", c_float),
                 ("alpha_thre", c_float), ("early_stop_eps", c_float), ("render_bkgd", c_float * 3), ("loss_scale", c_float),
                 ("stratified", c_int32), ("seed", c_uint64), ("render_bkgd_dev", c_void_p), ("deterministic", c_int32), ("n_levels", c_int32),
                 ("presampled", c_void_p)]
@@ -34,8 +42,8 @@ class VanillaConfig(ctypes.Structure):
                 ("net_width_condition", c_int32)]
 
 
-class RenderOpts(ctypes.Structure):
-    _fields_ = [("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float),
+class RenderOpts(_Sized):
+    _fields_ = [("struct_size", c_uint32), ("near_plane", c_float), ("far_plane", c_float), ("render_step_size", c_float),
                 ("cone_angle", c_float), ("alpha_thre", c_float), ("early_stop_eps", c_float),
                 ("render_bkgd", c_float * 3), ("max_samples", c_int32), ("probabilistic", c_int32),
                 ("rays_per_view", c_int32), ("sync_every", c_int32), ("view_order", c_void_p), ("bitgrid", c_void_p), ("n_levels", c_int32)]

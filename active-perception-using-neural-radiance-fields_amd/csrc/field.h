@@ -38,7 +38,7 @@ struct mnf_field_s {
     bool params_loaded;
     std::vector<int32_t> frag_src_host;   // host copy of the gather table (train.hip inverts it: parameter -> fragment slot)
     void *train_state;        // lazily built by train.hip (transposed fragments, weight-gradient job table)
-    int bwd_mode = 0;         // mnf_field_set_backward_mode: 0 auto (fused backward where supported), 1 split kernels (dgrad + wgrad), 2 fused required
+    int bwd_mode = 0;         // mnf_field_set_backward_mode: 0 / 1 the split kernels (dgrad + wgrad; default), 2 the fused backward (opt-in)
 };
 inline bool field_rows_supported(const mnf_field_s *f) { return f->cfg.neurons == 128 && !f->cfg.blend_fp16; }
 

@@ -819,6 +819,8 @@ extern "C" void *mnf_field_table_mirror(mnf_field_t f, int64_t *first_param_host
 
 extern "C" int mnf_field_create(const mnf_field_config *cfg, mnf_field_t *out) {
     MNF_REQUIRE(cfg && out, "field_create: null argument");
+    MNF_REQUIRE(cfg->struct_size == sizeof(mnf_field_config), "field_create: cfg->struct_size is %u, this library's mnf_field_config has %zu bytes (MNF_INIT)",
+                cfg->struct_size, sizeof(mnf_field_config));
     MNF_REQUIRE(cfg->neurons == 64 || cfg->neurons == 128, "field_create: neurons must be 64 or 128 (got %d)", cfg->neurons);
     MNF_REQUIRE(cfg->layers >= 1 && cfg->layers <= 4, "field_create: layers must be 1..4 (got %d)", cfg->layers);
     MNF_REQUIRE(cfg->num_semantic_classes >= 1 && cfg->num_semantic_classes <= 32,

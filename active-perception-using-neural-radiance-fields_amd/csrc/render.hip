@@ -483,6 +483,8 @@ int job_begin(RenderJob &j, mnf_field_t f, const uint8_t *binaries, int32_t res_
               float *sem, float *rgb_var, float *depth_var, int64_t *total_samples, void *workspace, int64_t workspace_bytes, hipStream_t s,
               JobRes *res) {
     MNF_REQUIRE(f && opts && aabb_host, "render_test: null argument");
+    MNF_REQUIRE(opts->struct_size == sizeof(mnf_render_opts), "render_test: opts->struct_size is %u, this library's mnf_render_opts has %zu bytes (MNF_INIT)",
+                opts->struct_size, sizeof(mnf_render_opts));
     MNF_REQUIRE(f->params_loaded, "render_test: field parameters not loaded");
     MNF_REQUIRE(n_rays > 0, "render_test: a job needs rays");
     MNF_REQUIRE(opts->rays_per_view > 0 && n_rays % opts->rays_per_view == 0,
@@ -691,6 +693,8 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
 extern "C" int mnf_render_jobs(const mnf_render_job *jobs_host, int32_t n_jobs, int32_t res_x, int32_t res_y, int32_t res_z,
                                const float *aabb_host, const mnf_render_opts *opts, mnf_stream_t stream) {
     MNF_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= 64 && opts, "render_jobs: bad arguments");
+    MNF_REQUIRE(opts->struct_size == sizeof(mnf_render_opts), "render_jobs: opts->struct_size is %u, this library's mnf_render_opts has %zu bytes (MNF_INIT)",
+                opts->struct_size, sizeof(mnf_render_opts));
     JobPool *pp = job_pool();
     if (!pp) return MNF_ERR_HIP;
     JobPool &pool = *pp;

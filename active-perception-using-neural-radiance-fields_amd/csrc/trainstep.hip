@@ -407,6 +407,8 @@ extern "C" int mnf_train_presample(mnf_presample_t p, const uint8_t *binaries, c
                                    int32_t res_z, const float *aabb_host, const float *rays_o, const float *rays_d, int32_t n_rays,
                                    const mnf_train_opts *opts, int64_t max_marched, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
     MNF_REQUIRE(p && binaries && occs && aabb_host && rays_o && rays_d && opts && workspace, "train_presample: null pointer");
+    MNF_REQUIRE(opts->struct_size == sizeof(mnf_train_opts), "train_presample: opts->struct_size is %u, this library's mnf_train_opts has %zu bytes (MNF_INIT)",
+                opts->struct_size, sizeof(mnf_train_opts));
     MNF_REQUIRE(n_rays > 0 && max_marched > 0 && opts->render_step_size > 0.f, "train_presample: bad sizes");
     const int n_levels = opts->n_levels > 1 ? opts->n_levels : 1;
     MNF_REQUIRE(n_levels <= 4, "train_presample: at most 4 occupancy levels");
@@ -441,6 +443,8 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
                               float *g_base, float *g_head, float *g_sem, float *losses, int64_t *counts_dev, int32_t *skip_dev, int64_t max_marched,
                               int64_t max_kept, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
     MNF_REQUIRE(f && f->params_loaded && opts && aabb_host && counts_dev && skip_dev, "train_step: bad handle or options");
+    MNF_REQUIRE(opts->struct_size == sizeof(mnf_train_opts), "train_step: opts->struct_size is %u, this library's mnf_train_opts has %zu bytes (MNF_INIT)",
+                opts->struct_size, sizeof(mnf_train_opts));
     MNF_REQUIRE(binaries && occs && rays_o && rays_d && target_rgb && target_depth && target_sem && g_base && g_head && g_sem && losses && workspace,
                 "train_step: null pointer");
     MNF_REQUIRE(n_rays > 0 && max_marched > 0 && max_kept > 0 && opts->render_step_size > 0.f, "train_step: bad sizes");
@@ -579,6 +583,8 @@ extern "C" int mnf_score_poses(const mnf_field_t *fields_host, const uint8_t *co
                                int32_t n_views, int32_t width, int32_t height, float focal, const int64_t *pix_idx, int64_t n_pix,
                                const mnf_render_opts *opts, double *terms, void *workspace, int64_t workspace_bytes, mnf_stream_t stream) {
     MNF_REQUIRE(fields_host && binaries_host && aabb_host && c2w && opts && terms && workspace && pix_idx, "score_poses: null pointer");
+    MNF_REQUIRE(opts->struct_size == sizeof(mnf_render_opts), "score_poses: opts->struct_size is %u, this library's mnf_render_opts has %zu bytes (MNF_INIT)",
+                opts->struct_size, sizeof(mnf_render_opts));
     MNF_REQUIRE(n_members >= 1 && n_members <= 16 && n_views >= 1 && n_pix >= 1, "score_poses: bad sizes");
     const int C = fields_host[0]->cfg.num_semantic_classes;
     for (int m = 1; m < n_members; ++m) MNF_REQUIRE(fields_host[m]->cfg.num_semantic_classes == C, "score_poses: members disagree on the class count");

@@ -23,24 +23,37 @@ from . import nerfacc as NA
 
 Rays = collections.namedtuple("Rays", ("origins", "viewdirs"))
 
-_WORKSPACES = {}
+_WORKSPACES = collections.OrderedDict()
+MAX_CACHED_WORKSPACES = 12      # (device, slot, stream) entries kept; the least recently used one goes first
 
 
 def _workspace(key, nbytes: int) -> torch.Tensor:
     """Cached scratch buffer; `key` is a device or (device, slot) — concurrent render jobs of one call use one slot each.  The buffer belongs to the
     (device, slot) AND the stream the caller enqueues on: two members of an ensemble trained or rendered side by side on two streams must not share
-    scratch (round 4: they did, silently, through the per-device cache)."""
+    scratch (round 4: they did, silently, through the per-device cache).
+    Cost: one buffer per (device, slot, stream) in use, sized for that key's largest call so far — hundreds of MB for a train step (feature rows, bin lists).
+    At most MAX_CACHED_WORKSPACES entries are kept (least recently used evicted: a caller that makes streams per phase or per epoch no longer accumulates
+    buffers); `release_workspaces(stream)` drops a stream's buffers at once.  Eviction is safe while kernels still use a buffer: it was allocated
+    under the stream it is keyed by, so torch's caching allocator hands its memory only to later work of that same stream."""
     device = key[0] if isinstance(key, tuple) else key
     key = (key, torch.cuda.current_stream(device).cuda_stream) if torch.device(device).type == "cuda" else key
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
         _WORKSPACES[key] = ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _WORKSPACES.move_to_end(key)
+    while len(_WORKSPACES) > MAX_CACHED_WORKSPACES:
+        _WORKSPACES.popitem(last=False)
     return ws
 
 
-def release_workspaces():
-    """Drop the cached render workspaces (they only ever grow: one per device, sized for the largest call so far)."""
-    _WORKSPACES.clear()
+def release_workspaces(stream=None):
+    """Drop the cached workspaces: all of them, or those keyed by `stream` (a torch.cuda.Stream or a raw handle)."""
+    if stream is None:
+        _WORKSPACES.clear()
+        return
+    h = getattr(stream, "cuda_stream", stream)
+    for k in [k for k in _WORKSPACES if isinstance(k, tuple) and len(k) == 2 and k[1] == h]:
+        del _WORKSPACES[k]
 
 
 def _grid_levels(estimator, max_levels=4):
@@ -383,19 +396,33 @@ class Presample:
         h = ctypes.c_void_p()
         L.check(L.load_library().mnf_presample_create(ctypes.byref(h)))
         self.handle = h
-        weakref.finalize(self, L.load_library().mnf_presample_destroy, h)
-        self.keep = None
+        self._box = [None]           # what the march reads and wrote; shared with the finalizer (which must not reference `self`)
+        # ONE finalizer does both things in order (a separate __del__ could run after the handle was destroyed at interpreter exit):
+        # a token dropped without a step first makes the stream wait for its march — its buffers go back to the allocator only behind it — then the handle goes.
+        self._fin = weakref.finalize(self, Presample._drop, L.load_library(), h, self._box)
 
-    def wait(self, device=None):
-        """torch's current stream waits for the march (no-op if none was launched)."""
-        L.check(L.load_library().mnf_presample_wait(self.handle, L.stream(device)))
-
-    def __del__(self):
+    @staticmethod
+    def _drop(lib, h, box):
         try:
-            if self.keep is not None:        # dropped without a step: its buffers go back to the allocator only behind the march
-                self.wait(self.keep[0].device)
+            if box[0] is not None:
+                lib.mnf_presample_wait(h, L.stream(box[0][0].device))
         except Exception:
             pass
+        box[0] = None
+        lib.mnf_presample_destroy(h)
+
+    @property
+    def keep(self):
+        return self._box[0]
+
+    @keep.setter
+    def keep(self, v):
+        self._box[0] = v
+
+    def wait(self, device=None):
+        """torch's current stream waits for the march (no-op if none was launched or the handle is gone)."""
+        if self._fin.alive:
+            L.check(L.load_library().mnf_presample_wait(self.handle, L.stream(device)))
 
 
 def _grid_version(estimator):
@@ -642,8 +669,11 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     from .optim import FusedAdam, count_nan_gradients
     radiance_field.train()
     estimator.train()
-    if presampled is not None and presampled.keep is not None:
-        presampled.wait(rays.origins.device)       # the occupancy refresh below must not rewrite the grid under a march still in flight
+    if presampled is not None and presampled.keep is not None and step % 16 == 0:
+        # only a step that refreshes the grid (update_every_n_steps: step % 16 == 0) needs the march finished before it starts: the refresh must not rewrite the
+        # grid under it.  Every other step leaves the wait to mnf_train_step, which skips it when hipEventQuery says the march is done (a cross-queue wait costs
+        # the stream ~18 us even then; ADVICE r04: waiting here unconditionally made that shortcut dead).
+        presampled.wait(rays.origins.device)
     device_guard = isinstance(optimizer, FusedAdam)
     if not sync and not (fused and device_guard):
         raise ValueError("train_step(sync=False) needs fused=True and optim.FusedAdam (the skip decision is taken on the device)")

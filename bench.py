@@ -31,6 +31,10 @@ What one invocation measures (ONE JSON line, rank 0):
                         terms (per-rank compute and gather times reported apart); with N > 1 rank 0 re-computes all views alone
                         and the gathered terms must be bit-identical.  `score256_shard8`: 32 views on this GPU = one rank's
                         share of an 8-GPU run (predicts strong scaling without a node)
+  train_dropin          scripts/pipeline.py:472-532 UNCHANGED on the drop-in surface (autograd route, torch losses, per-parameter isnan,
+                        torch.optim.Adam) at the reference yaml's 2000 rays, beside the fused step's numbers
+  render_from_pose      Dataset.render_image_from_pose (one 640x640 pose, pipeline.py:960-974) and render_probablistic_image_from_pose
+                        (40 poses x 2 members at scale 0.1, pipeline.py:697-711) with their float64 host stacks
   cpu_baseline          the oracle (CPU port of the same path) on this box's host cores: BASELINE.md §4 protocol (3 warm-ups + 20
                         iterations, threads swept over {1, 8, 32, all}, best reported), shapes (i) BL-1 and (ii) headline sample,
                         one 4096-ray scoring view, one 2000-ray train step
@@ -683,6 +687,59 @@ def main():
             res["speedup_presampled"] = res["one_stream"]["ms_per_iteration"] / res["stream_per_member_next_batch_presampled"]["ms_per_iteration"]
             return res
 
+        def dropin_leg(R_, steps):
+            """The UNCHANGED caller: scripts/pipeline.py:472-532 typed against the drop-in names only — `render_image_with_occgrid_with_depth_guide` (autograd), torch losses,
+            `loss.backward()`, the per-parameter `torch.isnan` loop with its host round trips, `torch.optim.Adam.step()` and the reference's scheduler — on the same scene,
+            start state and batches as `train_refyaml`.  What NOT editing pipeline.py costs against `render.train_step` (one fused C call + FusedAdam)."""
+            import torch.nn.functional as F
+            from apnrf_amd.nerfacc import OccGridEstimator
+            from apnrf_amd import nerfacc as NA
+            tf = SC.hip_field(scene280, dev)
+            tf.load_state_dict(tfield0.state_dict())
+            te = OccGridEstimator(torch.from_numpy(scene280["aabb"]), resolution=scene280["res"], levels=1).to(dev)
+            te.occs.copy_(test0.occs); te.binaries = test0.binaries.clone()
+            tf.train(); te.train()
+            optimizer = torch.optim.Adam(tf.parameters(), lr=2e-4, eps=1e-15, weight_decay=0.0)                      # pipeline.py:173-178
+            scheduler = torch.optim.lr_scheduler.ChainedScheduler([torch.optim.lr_scheduler.CyclicLR(
+                optimizer, base_lr=1e-4, max_lr=2e-4, step_size_up=250, mode="exp_range", gamma=1.0, cycle_momentum=False)])   # pipeline.py:183-193's form
+            occ_eval_fn = NA.FieldDensityOcc(tf, 1e-3)                                                               # pipeline.py:376-378
+            batches = make_batches(R_)
+            bkd = torch.rand(3, generator=torch.Generator().manual_seed(7)).to(dev)
+            stats = {"n": [], "jumped": 0}
+
+            def step(i):
+                rays_, pixels, dep_, sem_ = batches[i % 8]
+                te.update_every_n_steps(step=1000 + i, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
+                rgb, acc, depth, semantic, n_rendering_samples = RD.render_image_with_occgrid_with_depth_guide(
+                    tf, te, rays_, near_plane=0.1, render_step_size=1e-3, render_bkgd=bkd, cone_angle=0.004, alpha_thre=0.01, depth=dep_)
+                if n_rendering_samples == 0:
+                    return None
+                loss_rgb = F.smooth_l1_loss(rgb, pixels)
+                loss_dep = F.smooth_l1_loss(depth, dep_.unsqueeze(1))
+                loss_sem = F.cross_entropy(semantic, sem_)
+                loss = loss_rgb * 10 + loss_dep / 5 + loss_sem / 2
+                host_losses = (loss_rgb.detach().cpu().item(), loss_dep.detach().cpu().item() / 50, loss_sem.detach().cpu().item() / 2)   # pipeline.py:513-515
+                optimizer.zero_grad()
+                loss.backward()
+                flag = False
+                for name, param in tf.named_parameters():
+                    if param.grad is not None and torch.sum(torch.isnan(param.grad)) > 0:
+                        flag = True
+                        break
+                if flag:
+                    optimizer.zero_grad()
+                    stats["jumped"] += 1
+                    return None
+                optimizer.step()
+                scheduler.step()
+                stats["n"].append(n_rendering_samples)
+                return host_losses
+            dt_d = timed(step, steps, max(args.warmup, 4), False)
+            return {"ms_per_step": 1e3 * dt_d / steps, "steps": steps, "rays_per_step": R_, "rendering_samples_per_step": float(np.mean(stats["n"][-steps:])),
+                    "steps_jumped": stats["jumped"], "host_round_trips_per_step": "sample count (inside sampling) + n_rendering_samples + 3 losses + one per parameter vector",
+                    "what": "pipeline.py:472-532 unchanged on the drop-in surface: autograd route (same kernels call by call), torch smooth_l1 / cross_entropy, loss.backward(), "
+                            "per-parameter isnan round trips, torch.optim.Adam + CyclicLR"}
+
         tsteps = max(args.steps, 10)
         dtypes = [d for d in args.train_dtypes.split(",") if d in ("f16", "bf16")]
         presample_note = ("next_batch_presampled: the same steps with the batch fetched one iteration early and its march (occ_grid.py:181-208: reads rays and grid, not the model) "
@@ -716,6 +773,12 @@ def main():
         dy = train_leg("f16", 2000, False, max(tsteps, 40), False, dynamic_target=1 << 18)
         dy["workload"] = ("the reference's own schedule (scripts/pipeline.py:494-504, config_102344250.yaml:3-4): num_rays starts at 1024 and is recomputed after "
                           "every iteration to hold 262 144 samples, capped at 2000; asynchronous steps, the count used is the latest that has arrived on the host")
+        log("train: the drop-in surface (autograd route + torch.optim.Adam)")
+        dropin = dropin_leg(2000, max(tsteps, 20))
+        dropin["fused_async_ms_per_step"] = ry["ms_per_step"]
+        dropin["fused_host_synchronous_ms_per_step"] = ry["host_synchronous_ms_per_step"]
+        dropin["cost_of_not_editing_pipeline_py"] = dropin["ms_per_step"] / ry["host_synchronous_ms_per_step"]
+        line["train_dropin"] = dropin
         line["train"] = train
         line["train_refyaml"] = ry
         line["train_dynamic"] = dy
@@ -802,6 +865,26 @@ def main():
                                        "bit_identical_to_full_pass_rows": bool(torch.equal(t8, terms[lo:hi])),
                                        "note": "views 0..31 of the same pass on one GPU = the per-rank work of --gpus 8; predicted 8-GPU pass = this + one 8 KB all-gather"}
         sc["process_samples"] = int(score_samples.item())
+        if world == 1:
+            # The drop-in surface scripts/pipeline.py calls today, float64 host stacks and D2H copies included:
+            #   pipeline.py:960-974   Dataset.render_image_from_pose(field, est, traj, img_w, img_h, focal, near, step, 1, cone, alpha, 1, device): full 640x640 views
+            #   pipeline.py:697-711   Dataset.render_probablistic_image_from_pose(member, est, trajectory[unc_idx] (40 poses), ..., scale 0.1, ..., 4, device), once per member
+            from apnrf_amd.dataset import Dataset
+            p1 = poses256[:1]
+            p40 = poses256[:40]
+            a_full = (f0, e0, p1, 640, 640, 320.0, 0.1, 1e-3, 1, 0.004, 0.01, 1, dev)
+            a_40 = lambda f_, e_: (f_, e_, p40, 640, 640, 320.0, 0.1, 1e-3, 0.1, 0.004, 0.01, 4, dev)
+            dt_full = timed(lambda i: Dataset.render_image_from_pose(*a_full), 3, 1, False)
+            dt_40 = timed(lambda i: [Dataset.render_probablistic_image_from_pose(*a_40(f_, e_)) for f_, e_ in ((f0, e0), (f1, e1))], 3, 1, False)
+            dt_40s = timed(lambda i: RD.score_views([f0, f1], [e0, e1], p40, 640, 640, 320.0, 0.1, 1e-3, 0.1, 0.004, 0.01, dev, group=False)[1].item(), 3, 1, False)
+            line["render_from_pose"] = {
+                "full_view_640x640": {"ms_per_call": 1e3 * dt_full / 3, "rays_per_s": 640 * 640 * 3 / dt_full, "poses": 1,
+                                      "what": "Dataset.render_image_from_pose as pipeline.py:960-974 calls it (scale 1): -> numpy float64 [1,640,640,.] stacks"},
+                "uncertainty_40_poses_x2_members": {"ms_per_trajectory": 1e3 * dt_40 / 3, "rays_per_s": 2 * 40 * 4096 * 3 / dt_40, "poses": 40, "members": 2,
+                                                    "what": "Dataset.render_probablistic_image_from_pose as pipeline.py:697-711 calls it (scale 0.1, once per ensemble "
+                                                            "member): -> six numpy float64 [40,64,64,.] stacks per member, the scorer's numpy then runs on the host"},
+                "same_40_poses_on_device_scorer_ms": 1e3 * dt_40s / 3,
+                "note": "the second entry against the third is what the host stacks cost a trajectory score: the renders are the same kernels"}
         if not want("render800") and not want("train"):
             line.update({"metric": "candidate-view scoring rays/s", "value": sc["rays_per_s"], "ms_per_step": sc["ms_per_pass"], "scaling": "strong"})
             line["config"]["workload"] = sc["workload"]

@@ -21,6 +21,7 @@
 #define MI355NERF_H
 
 #include <stdint.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -234,7 +235,14 @@ int mnf_gather_pixels(const uint8_t *images, const void *depths, int32_t depth_i
 
 /* ---------------------------------------------------------------- radiance field (tinycudann replacement) */
 
+/* Option structs that the library takes BY POINTER start with `struct_size`: set it to sizeof(the struct) (MNF_INIT below zero-fills and sets it).
+ * The library refuses any other value (MNF_ERR_INVALID), so a caller compiled against an older header — whose struct is shorter than what this
+ * library reads — is stopped at the boundary instead of having the tail of its struct read from whatever follows it.  Every field added after a
+ * struct's first release reads 0 / NULL as "the previous behaviour". */
+#define MNF_INIT(var) do { memset(&(var), 0, sizeof(var)); (var).struct_size = (uint32_t)sizeof(var); } while (0)
+
 typedef struct {
+    uint32_t struct_size;          /* sizeof(mnf_field_config) */
     float aabb[6];                 /* ngp.py:91 */
     int32_t neurons;               /* ngp.py:77  (64 or 128) */
     int32_t layers;                /* ngp.py:78  == tcnn n_hidden_layers of the base MLP (>=1) */
@@ -390,6 +398,7 @@ int mnf_field_forward_train_samples(mnf_field_t f, const float *rays_o, const fl
  * to and retries with larger bounds after bits 1 / 4.
  * Stratified near planes: near + U[0,1) * render_step_size per ray from Philox4x32-10 (counter (ray, 0, 7, 0), key = seed). */
 typedef struct {
+    uint32_t struct_size;     /* sizeof(mnf_train_opts) */
     float near_plane, far_plane, render_step_size, cone_angle, alpha_thre, early_stop_eps;   /* utils.py:63-76 / occ_grid.py:80-96 */
     float render_bkgd[3];
     float loss_scale;         /* fp16 activation-gradient scale of the backward (tcnn: 128) */
@@ -435,6 +444,7 @@ int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint32_t *bitgr
 /* ---------------------------------------------------------------- fused test-mode renderers */
 
 typedef struct {
+    uint32_t struct_size;    /* sizeof(mnf_render_opts), see MNF_INIT */
     float near_plane;        /* utils.py:563 */
     float far_plane;         /* utils.py:564 */
     float render_step_size;  /* utils.py:565 */

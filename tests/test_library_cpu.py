@@ -99,3 +99,26 @@ def test_vanilla_field_state_dict_matches_reference(golden):
         f(torch.zeros(4, 3), torch.zeros(4, 3))                     # no CPU fallback
     dflt = VanillaNeRFRadianceField()                                # reference defaults: depth 8, width 256, skip 4
     assert dflt.mlp.base.hidden_layers[5].in_features == 256 + 63 and dflt.mlp.rgb_layer.hidden_layers[0].in_features == 256 + 27
+
+
+def test_option_structs_carry_their_size_and_stale_callers_are_refused():
+    """include/mi355nerf.h MNF_INIT: by-pointer structs start with `struct_size`; a caller built against an older (shorter) header, or one that
+    did not initialise the struct, is refused at the boundary before anything is read from the struct's tail.  No GPU needed:
+    the check comes first."""
+    lib = apnrf_amd.load_library()
+    for cls in (L.FieldConfig, L.TrainOpts, L.RenderOpts):
+        s = cls()
+        assert s.struct_size == ctypes.sizeof(cls) and cls._fields_[0][0] == "struct_size"
+    cfg = L.FieldConfig()
+    cfg.neurons, cfg.layers, cfg.num_semantic_classes, cfg.n_levels, cfg.n_features, cfg.log2_hashmap_size = 128, 2, 29, 16, 4, 12
+    cfg.base_resolution, cfg.max_resolution = 16, 4096
+    h = ctypes.c_void_p()
+    for bad in (0, ctypes.sizeof(L.FieldConfig) - 4):
+        cfg.struct_size = bad
+        assert lib.mnf_field_create(ctypes.byref(cfg), ctypes.byref(h)) == -1          # MNF_ERR_INVALID
+        assert b"struct_size" in lib.mnf_last_error()
+    header = open(os.path.join(REPO, "include", "mi355nerf.h")).read()
+    for name in ("mnf_field_config", "mnf_train_opts", "mnf_render_opts"):            # every struct the library takes by pointer declares it first
+        body = header[:header.index("} " + name + ";")]
+        body = body[body.rindex("typedef struct {"):]
+        assert body.split("\n")[1].strip().startswith("uint32_t struct_size;"), name
