@@ -33,7 +33,9 @@ SOURCES = {
     "occupancy.hip": ["-ffp-contract=off"],
     "vanilla.hip": [],
     "trainstep.hip": ["-ffp-contract=off"],
+    "viewq.hip": ["-fno-slp-vectorize"],
     "field.hip@bf16": ["-DMNF_BF16", "-fno-slp-vectorize"],
+    "viewq.hip@bf16": ["-DMNF_BF16", "-fno-slp-vectorize"],
     "train.hip@bf16": ["-DMNF_BF16"],
 }
 # translation units that read diagnostic knobs (csrc/common.h: diag_env): recompiled with -DMNF_DIAG for the diag library

@@ -17,6 +17,7 @@
 
 #include "field.h"
 #include "march_dev.h"
+#include "viewq.h"
 
 namespace mnf {
 
@@ -40,7 +41,22 @@ struct RenderWs {
     int32_t *tile_hdr;   // per 64-column tile: stride (= the view's budget this round) | view << 8
     void *enc;           // hash features of the round's columns in MLP fragment order (two-launch field path)
     int64_t col_cap;
+    // view-queue renderer (csrc/viewq.hip; small views only): per-view arrival counters, and this job's share of the call's queue structures
+    int32_t *done;
+    char *vq;            // [job table | control words | queue slots | column scratch] (the table and the scratch are used from job 0's workspace)
+    int64_t vq_slots_cap;
 };
+
+constexpr int kVQMaxJobs = 64;           // mnf_render_jobs' own limit
+constexpr int kVQMaxRounds = 1026;       // queue slots per (view, slice): rounds a view can have with max_samples / min_samples <= 1025 (the reference: 1024 / 4 or 1024 / 1)
+static inline int64_t vq_units(int64_t n_rays, int32_t rays_per_view) { return (n_rays / rays_per_view) * ((rays_per_view + kVQSlice - 1) / kVQSlice); }
+static inline size_t vq_off_ctrl() { return ((size_t)kVQMaxJobs * sizeof(VQJob) + 255) & ~(size_t)255; }
+static inline size_t vq_off_slots() { return vq_off_ctrl() + (((size_t)kVQCtrlWords * 4 + 255) & ~(size_t)255); }
+static inline size_t vq_off_scratch(int64_t units) { return vq_off_slots() + (((size_t)units * kVQMaxRounds * 4 + 255) & ~(size_t)255); }
+static inline int64_t vq_bytes(int64_t n_rays, int32_t rays_per_view) {
+    if (rays_per_view > kVQMaxRaysPerView) return 0;
+    return (int64_t)vq_off_scratch(vq_units(n_rays, rays_per_view)) + vq_scratch_bytes();
+}
 
 static bool split_field() {
     static const bool on = diag_env("MNF_FIELD_SPLIT") != nullptr;
@@ -92,6 +108,9 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     if (split_field()) { p = take((col_cap / 64 + 1) * 8192); if (ws) ws->enc = p; }   // two-launch path: 128 B per column
     else if (ws) ws->enc = nullptr;
     if (ws) ws->col_cap = col_cap;
+    p = take(n_views * 4); if (ws) ws->done = (int32_t *)p;
+    const int64_t vqb = vq_bytes(n_rays, rays_per_view);
+    p = take(vqb ? vqb : 16); if (ws) { ws->vq = vqb ? p : nullptr; ws->vq_slots_cap = vq_units(n_rays, rays_per_view) * kVQMaxRounds; }
     return (int64_t)off;
 }
 
@@ -322,6 +341,25 @@ __global__ void __launch_bounds__(kRayThreads) finalize_kernel(int64_t n_rays, f
     out.rgb[3 * r + 1] = out.rgb[3 * r + 1] + b1 * (1.0f - op);
     out.rgb[3 * r + 2] = out.rgb[3 * r + 2] + b2 * (1.0f - op);
     out.depth[r] = out.depth[r] / fmaxf(op, 1.1920928955078125e-07f);   // torch.finfo(float32).eps
+}
+
+// ------------------------------------------------------------------ view-queue renderer, host-side kernels (csrc/viewq.hip holds the renderer itself)
+__global__ void vq_set_job_kernel(VQJob *dst, VQJob job) { *dst = job; }
+
+// round 0 of every view: budget for n_alive = rays_per_view (utils.py:667-672), one item per (view, slice) in the job's queue
+__global__ void __launch_bounds__(256) vq_init_kernel(const VQJob *jobs, int32_t job, int32_t spv, int32_t ns0) {
+    const VQJob j = jobs[job];
+    const int units = j.n_views * spv;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u == 0) {
+        j.ctrl[kVQHead] = 0; j.ctrl[kVQTail] = units; j.ctrl[kVQViewsLeft] = j.n_views; j.ctrl[kVQJobDone] = j.n_views == 0; j.ctrl[kVQError] = 0;
+    }
+    if (u >= units) return;
+    j.slots[u] = (uint32_t)(u + 1);
+    if (u % spv == 0) {
+        const int v = u / spv;
+        j.n_samples[v] = ns0; j.iter_samples[v] = ns0; j.alive_count[v] = 0; j.done[v] = 0;
+    }
 }
 
 // ------------------------------------------------------------------ scorer (pipeline.py:727-781), one block per view
@@ -668,6 +706,98 @@ int run_jobs(std::vector<RenderJob> &jobs) {
     return MNF_OK;
 }
 
+// Small views: the whole loop as one persistent launch (csrc/viewq.hip).  Eligible when every job renders views of at most kVQMaxRaysPerView rays through ONE
+// occupancy level whose bits fit the LDS beside the field's weights, and the jobs' fields share shape and operand type (an ensemble's members do).
+bool viewq_eligible(const std::vector<RenderJob> &jobs) {
+    if (round_log() || split_field() || diag_env("MNF_COMPOSITE_GENERAL") || diag_env("MNF_MIN_SAMPLES") || diag_env("MNF_NO_VIEWQ")) return false;
+    if (jobs.empty() || (int)jobs.size() > kVQMaxJobs) return false;
+    const RenderJob &a = jobs[0];
+    if (a.opts.rays_per_view > kVQMaxRaysPerView || a.boxes.n != 1 || !a.lds_grid || a.n_words > kVQGridWords || !a.ws.vq) return false;
+    if (ceil_div(a.opts.max_samples, a.min_samples) + 1 > kVQMaxRounds) return false;
+    const mnf_field_config &c = a.f->cfg;
+    if (c.blend_fp16) return false;
+    if (!(c.mfma_bf16 ? bf16::viewq_supported(c.neurons, c.layers) : f16::viewq_supported(c.neurons, c.layers))) return false;
+    for (const RenderJob &j : jobs) {
+        const mnf_field_config &d = j.f->cfg;
+        if (d.neurons != c.neurons || d.layers != c.layers || (d.mfma_bf16 != 0) != (c.mfma_bf16 != 0) || d.blend_fp16) return false;
+        if (!j.ws.vq || j.boxes.n != 1 || !j.lds_grid || j.n_words != a.n_words) return false;
+    }
+    return true;
+}
+
+int run_viewq(std::vector<RenderJob> &jobs) {
+    RenderJob &a = jobs[0];
+    hipStream_t s = a.s;                       // everything on the first job's stream (the caller's): nothing here runs side by side
+    for (auto &j : jobs)
+        if (j.s != s) { MNF_HIP(hipEventRecord(j.res->ev_join, j.s)); MNF_HIP(hipStreamWaitEvent(s, j.res->ev_join, 0)); }   // the job's init ran on its own stream
+    const int32_t rpv = a.opts.rays_per_view;
+    const int32_t spv = (rpv + kVQSlice - 1) / kVQSlice;
+    VQJob *table = reinterpret_cast<VQJob *>(a.ws.vq);
+    int64_t total_units = 0;
+    const int ns0 = 1 > a.min_samples ? 1 : a.min_samples;                     // n_alive = rays_per_view: max(min(1, 64), min_samples)
+    for (size_t k = 0; k < jobs.size(); ++k) {
+        RenderJob &j = jobs[k];
+        VQJob d = {};
+        d.table = j.f->d_table; d.frags = j.f->d_frags;
+        d.levels = reinterpret_cast<const LevelMeta *>(reinterpret_cast<const char *>(j.f->d_frags) + (size_t)j.f->shape.blocks_total * 1024);
+        for (int i = 0; i < 6; ++i) d.aabb[i] = j.f->cfg.aabb[i];
+        d.C = j.C; d.out_fp16 = j.f->cfg.output_fp16 ? 1 : 0;
+        d.bitgrid = j.ws.bitgrid; d.rays_o = j.rays_o; d.rays_d = j.rays_d;
+        d.alive = j.ws.alive; d.hit = j.ws.hit; d.near_plane = j.ws.near_plane; d.t_min = j.ws.t_min; d.t_max = j.ws.t_max;
+        d.alive_count = j.ws.alive_count; d.n_samples = j.ws.n_samples; d.iter_samples = j.ws.iter_samples; d.done = j.ws.done;
+        d.rgb = j.out.rgb; d.acc = j.out.acc; d.depth = j.out.depth; d.sem = j.out.sem; d.rgb_var = j.out.rgb_var; d.depth_var = j.out.depth_var;
+        d.totals = reinterpret_cast<unsigned long long *>(j.out.total_samples);
+        d.slots = reinterpret_cast<uint32_t *>(j.ws.vq + vq_off_slots());
+        d.n_views = j.n_views;
+        const int64_t units = (int64_t)j.n_views * spv;
+        const int64_t rounds = ceil_div(j.opts.max_samples, j.min_samples) + 1;
+        d.slots_cap = (int32_t)(units * rounds);
+        d.ctrl = reinterpret_cast<int32_t *>(j.ws.vq + vq_off_ctrl());
+        MNF_HIP(hipMemsetAsync(d.slots, 0, (size_t)d.slots_cap * 4, s));
+        hipLaunchKernelGGL(vq_set_job_kernel, dim3(1), dim3(1), 0, s, table + k, d);
+        hipLaunchKernelGGL(vq_init_kernel, dim3((int)ceil_div(units > 0 ? units : 1, 256)), dim3(256), 0, s, table, (int32_t)k, spv, ns0);
+        total_units += units;
+    }
+    int rc = launch_status("vq_init_kernel");
+    if (rc) return rc;
+    VQArgs q = {};
+    q.jobs = table; q.n_jobs = (int32_t)jobs.size(); q.rays_per_view = rpv; q.spv = spv;
+    q.max_samples = a.opts.max_samples; q.min_samples = a.min_samples; q.probabilistic = a.opts.probabilistic;
+    q.far_plane = a.opts.far_plane; q.step_size = a.opts.render_step_size; q.cone_angle = a.opts.cone_angle;
+    q.alpha_thre = a.opts.alpha_thre; q.opc_thre = 1.0f - a.opts.early_stop_eps;
+    q.res = a.grid; q.n_words = a.n_words;
+    for (int i = 0; i < 6; ++i) q.occ_aabb[i] = a.ab[i];
+    q.view_order = a.opts.view_order;
+    char *scratch = a.ws.vq + vq_off_scratch(vq_units(a.n_rays, rpv));
+    const int64_t cols = (int64_t)kVQMaxGrid * kVQWaves * kVQWaveCols;
+    q.col_ray = reinterpret_cast<int32_t *>(scratch); q.col_ts = reinterpret_cast<float *>(scratch + cols * 4); q.col_te = reinterpret_cast<float *>(scratch + cols * 8);
+    q.error = reinterpret_cast<int32_t *>(a.ws.vq + vq_off_ctrl()) + kVQError;
+    const int grid = (int)(total_units < kVQMaxGrid ? total_units : kVQMaxGrid);
+    const mnf_field_config &c = a.f->cfg;
+    {
+        ProfScope ps("viewq_render", s);
+        rc = c.mfma_bf16 ? bf16::launch_viewq_impl(q, c.neurons, c.layers, grid, s) : f16::launch_viewq_impl(q, c.neurons, c.layers, grid, s);
+    }
+    if (rc) return rc;
+    for (auto &j : jobs) {
+        hipLaunchKernelGGL(finalize_kernel, dim3((int)ceil_div(j.n_rays, kRayThreads)), dim3(kRayThreads), 0, s, j.n_rays,
+                           j.opts.render_bkgd[0], j.opts.render_bkgd[1], j.opts.render_bkgd[2], j.out);
+    }
+    rc = launch_status("finalize_kernel");
+    if (rc) return rc;
+    // the kernel's own verdict (a queue that starved for seconds, a queue overflow): read once, behind everything
+    MNF_HIP(hipMemcpyAsync(a.res->flags, q.error, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MNF_HIP(hipEventRecord(a.res->ev_flags, s));
+    for (auto &j : jobs)
+        if (j.s != s) MNF_HIP(hipStreamWaitEvent(j.s, a.res->ev_flags, 0));        // (the side streams are joined by the caller: keep them behind this call's work)
+    MNF_HIP(hipEventSynchronize(a.res->ev_flags));
+    if (a.res->flags[0]) {
+        set_error("render: the view-queue kernel gave up (code %d: 1 = a queue starved for 4 s, 2 = a queue overflowed)", a.res->flags[0]);
+        return MNF_ERR_HIP;
+    }
+    return MNF_OK;
+}
+
 }  // namespace
 }  // namespace mnf
 
@@ -687,7 +817,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     rc = job_begin(jobs[0], f, binaries, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, rgb, acc, depth, sem, rgb_var, depth_var,
                    total_samples, workspace, workspace_bytes, as_stream(stream), &pool.res[0]);
     if (rc) return rc;
-    return run_jobs(jobs);
+    return viewq_eligible(jobs) ? run_viewq(jobs) : run_jobs(jobs);
 }
 
 extern "C" int mnf_render_jobs(const mnf_render_job *jobs_host, int32_t n_jobs, int32_t res_x, int32_t res_y, int32_t res_z,
@@ -717,7 +847,7 @@ extern "C" int mnf_render_jobs(const mnf_render_job *jobs_host, int32_t n_jobs, 
         if (rc) return rc;
     }
     if (jobs.empty()) return MNF_OK;
-    rc = run_jobs(jobs);
+    rc = viewq_eligible(jobs) ? run_viewq(jobs) : run_jobs(jobs);
     // join: the caller's stream continues after every job (also on an error path, so that no side stream is left racing the caller)
     for (auto &j : jobs)
         if (j.s != s0) { (void)hipEventRecord(j.res->ev_join, j.s); (void)hipStreamWaitEvent(s0, j.res->ev_join, 0); }

@@ -101,6 +101,28 @@ def spawn_ranks(args):
     return subprocess.call(cmd)
 
 
+TRAIN_SOURCES = ("train.hip", "trainstep.hip", "composite_train.hip", "field.hip", "field_dev.h", "field.h", "common.h", "march.hip", "march_dev.h")
+
+
+def train_traffic(rays):
+    """HBM bytes of one train step from the committed counter passes (profiles/r05_pmc_train.json: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_ATOMIC_sum,
+    tools/r05_pmc_train.sh) — quoted only for the kernel sources they were measured on (md5) and the shape they were measured at.  -> (bytes or None, note)"""
+    pj = os.path.join(REPO, "profiles", "r05_pmc_train.json")
+    if not os.path.exists(pj):
+        return None, "no PMC profile of the train step is committed"
+    pm = json.load(open(pj))
+    h = hashlib.md5()
+    for f in TRAIN_SOURCES:
+        with open(os.path.join(REPO, "active-perception-using-neural-radiance-fields_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    if pm.get("train_sources_md5") != h.hexdigest()[:12]:
+        return None, "profiles/r05_pmc_train.json was measured on a different build of the train kernels: not quoted"
+    if int(pm.get("rays_per_step", 0)) != int(rays):
+        return None, f"profiles/r05_pmc_train.json was measured at {pm.get('rays_per_step')} rays per step: not quoted for {rays}"
+    return pm["per_step"]["hbm_bytes"], ("rocprofv3 --pmc passes of these kernel sources (profiles/r05_pmc_train.json: FETCH_SIZE corrected x2 for the 16-byte-per-lane streaming kernels "
+                                        "+ WRITE_SIZE, per train step at %s surviving samples; copied from the profile, not measured in this run)" % pm.get("surviving_samples_per_step"))
+
+
 def field_source_id():
     """Hash of the sources of the dominant kernel: PMC traffic measured on another build is not quoted for this one."""
     h = hashlib.md5()
@@ -228,6 +250,7 @@ def cpu_baselines(scene, scene_score, poses, score_pose, width, height, focal, g
     # their bar is max(1e-3, 3e-4 x largest |logit| of the ray) = three times the NOISE FLOOR measured right here — the same model through the
     # oracle a second time with every layer's fp32 products added in another order (oracle/field.py accum="k16_reversed"): what two faithful
     # fp16-operand / fp32-accumulate implementations differ by (tests/test_oracle_noise_floor_cpu.py: ~1e-4 of the logit at every scale).
+    set_threads(int(th))       # (the sweep leaves its LAST thread count set: the oracle crawls with 64+ torch threads — one 576-ray pass took 20 minutes)
     r2 = R.render_test(1024, _oracle_field(scene, accum="k16_reversed"), scene["occ"], scene["aabb"][None], o, d, render_bkgd=bk, **SC.RENDER_KW)
     nf = {k: (r2[k] - r[k]).abs().reshape(S_ * S_, -1).max(dim=1).values.numpy() for k in ("rgb", "acc", "depth", "sem")}
     mag = r["sem"].abs().max(dim=1).values.numpy()
@@ -609,8 +632,10 @@ def main():
             g_tab = tf.mlp_base.params.grad[n_mlp:].view(-1, 4)
             res["table_entries_touched_fraction"] = float((g_tab != 0).any(dim=1).float().mean())
             algo = TRAIN_BYTES_KEPT * kept + TRAIN_BYTES_MARCHED * marched
+            traffic, traffic_note = train_traffic(R_) if dtype == "f16" else (None, "the counter passes were taken with fp16 operands")
             res["roofline"] = {"bound": "hbm", "achieved": algo / (dt_t / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": algo / (dt_t / steps) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": algo,
+                               "frac": algo / (dt_t / steps) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                               "traffic_over_algorithmic": (traffic / algo) if traffic else None, "algorithmic_bytes_per_step": algo,
                                "definition": "(4.1 KB x surviving samples + 1 KB x pre-pass samples) / un-instrumented step time (SURVEY 8d)"}
             if with_kernels and not args.no_kernel_timing:
                 outs.clear()
@@ -885,6 +910,7 @@ def main():
                                                             "member): -> six numpy float64 [40,64,64,.] stacks per member, the scorer's numpy then runs on the host"},
                 "same_40_poses_on_device_scorer_ms": 1e3 * dt_40s / 3,
                 "note": "the second entry against the third is what the host stacks cost a trajectory score: the renders are the same kernels"}
+            line["render_from_pose"]["source"] = "render.render_image_from_pose / render_probablistic_image_from_pose: pose -> rays -> render -> .cpu().numpy() float64 stacks"
         if not want("render800") and not want("train"):
             line.update({"metric": "candidate-view scoring rays/s", "value": sc["rays_per_s"], "ms_per_step": sc["ms_per_pass"], "scaling": "strong"})
             line["config"]["workload"] = sc["workload"]
