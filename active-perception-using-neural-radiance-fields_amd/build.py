@@ -39,7 +39,7 @@ SOURCES = {
     "train.hip@bf16": ["-DMNF_BF16"],
 }
 # translation units that read diagnostic knobs (csrc/common.h: diag_env): recompiled with -DMNF_DIAG for the diag library
-DIAG_UNITS = ("render.hip", "field.hip", "train.hip", "field.hip@bf16", "train.hip@bf16", "trainstep.hip")
+DIAG_UNITS = ("render.hip", "field.hip", "train.hip", "field.hip@bf16", "train.hip@bf16", "trainstep.hip", "viewq.hip", "viewq.hip@bf16")
 
 
 def _deps_mtime():
