@@ -33,13 +33,11 @@ SOURCES = {
     "occupancy.hip": ["-ffp-contract=off"],
     "vanilla.hip": [],
     "trainstep.hip": ["-ffp-contract=off"],
-    "viewq.hip": ["-fno-slp-vectorize"],
     "field.hip@bf16": ["-DMNF_BF16", "-fno-slp-vectorize"],
-    "viewq.hip@bf16": ["-DMNF_BF16", "-fno-slp-vectorize"],
     "train.hip@bf16": ["-DMNF_BF16"],
 }
 # translation units that read diagnostic knobs (csrc/common.h: diag_env): recompiled with -DMNF_DIAG for the diag library
-DIAG_UNITS = ("render.hip", "field.hip", "train.hip", "field.hip@bf16", "train.hip@bf16", "trainstep.hip", "viewq.hip", "viewq.hip@bf16")
+DIAG_UNITS = ("render.hip", "field.hip", "train.hip", "field.hip@bf16", "train.hip@bf16", "trainstep.hip")
 
 
 def _deps_mtime():

@@ -2,10 +2,8 @@
 //
 // Semantics follow the reference kernel perception/nerfacc/nerfacc/cuda/csrc/grid.cu:68-282 with
 // its helpers include/utils_grid.cuh:10-142; results are bit-identical to oracle/nerfacc_grid.c
-// (no FMA contraction: every t value is a chain of separately rounded fp32 operations.  march.hip /
-// render.hip are built with -ffp-contract=off; every function below ALSO switches contraction off for
-// its own body, so that the same marcher can be inlined into translation units that contract — the
-// view-queue renderer csrc/viewq.hip, which holds the MLP kernels' arithmetic as well).  The traversal is written once, parameterised by a `Sink` that receives each
+// (both must be built with -ffp-contract=off: every t value is a chain of separately rounded
+// fp32 operations).  The traversal is written once, parameterised by a `Sink` that receives each
 // emitted sample (t_last, t_next, continuous), so the same code serves the count pass, the fill
 // pass and the fused per-round marcher of the test-mode renderer.
 #pragma once
@@ -23,7 +21,6 @@ __device__ __forceinline__ int clampi(int f, int a, int b) { return max(a, min(f
 // utils_grid.cuh:10-55
 __device__ __forceinline__ bool ray_aabb(const F3 o, const F3 inv, float ray_tmin, float ray_tmax,
                                          const float *__restrict__ aabb, float &tmin, float &tmax) {
-#pragma clang fp contract(off)
     float tmin_t, tmax_t;
     if (inv.x >= 0) { tmin = (aabb[0] - o.x) * inv.x; tmax = (aabb[3] - o.x) * inv.x; }
     else            { tmin = (aabb[3] - o.x) * inv.x; tmax = (aabb[0] - o.x) * inv.x; }
@@ -44,7 +41,6 @@ __device__ __forceinline__ bool ray_aabb(const F3 o, const F3 inv, float ray_tmi
 }
 
 __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min, float dt_max) {
-#pragma clang fp contract(off)
     return clampf(t * cone_angle, dt_min, dt_max);  // grid.cu:23-28
 }
 
@@ -52,7 +48,6 @@ __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min
 // The extra `!(nt > t_last)` exit only triggers where the reference would spin forever
 // (dt below half an ulp of t_last, or NaN) — it protects the GPU from a hang.
 __device__ __forceinline__ void skip_to(float &t_last, float dt, float target) {
-#pragma clang fp contract(off)
     const float hd = dt * 0.5f;
 #if defined(MNF_SAMPLER_EXP) && MNF_SAMPLER_EXP == 4
     t_last = target - hd; return;          /* timing experiment: no empty-space stepping (results invalid) */
@@ -107,7 +102,6 @@ __device__ __forceinline__ void march_segment(const F3 org, const F3 dir, const 
                                               const Occ occupied,
                                               float step_size, float cone_angle, int32_t limit,
                                               MarchState &st, Sink &sink) {
-#pragma clang fp contract(off)
     const float eps = 1e-6f;
     if (!st.continuous) {
         if (step_size <= 0.0f) {
@@ -215,7 +209,6 @@ template <class Sink, class GridOf>
 __device__ __forceinline__ void march_levels(const F3 org, const F3 dir, const F3 inv, float near_plane, float far_plane, const LevelBoxes &boxes,
                                              const I3 res, const GridOf grid_of, float step_size, float cone_angle, int32_t limit,
                                              MarchState &st, Sink &sink) {
-#pragma clang fp contract(off)
     const int L = boxes.n;
     float tv[8]; int ti[8]; bool lhit[4];
     for (int l = 0; l < L; ++l) {

@@ -17,7 +17,6 @@
 
 #include "field.h"
 #include "march_dev.h"
-#include "viewq.h"
 
 namespace mnf {
 
@@ -41,29 +40,7 @@ struct RenderWs {
     int32_t *tile_hdr;   // per 64-column tile: stride (= the view's budget this round) | view << 8
     void *enc;           // hash features of the round's columns in MLP fragment order (two-launch field path)
     int64_t col_cap;
-    // view-queue renderer (csrc/viewq.hip; small views only): per-view round state, the views' lists of alive rays, and this job's share of the call's queue structures
-    int32_t *done, *n_items, *rpi, *lcnt, *list, *next, *segcnt;
-    int32_t seg_stride;
-    char *vq;            // [job table | control words | ring | column scratch] (the table and the scratch are used from job 0's workspace)
-    int64_t vq_ring;     // ring slots (a power of two)
 };
-
-constexpr int kVQMaxJobs = 64;           // mnf_render_jobs' own limit
-// ring slots of a job: every item that can be pending at one time (a view's round has at most rays_per_view / 64 + 1 items when its rays fill whole waves, fewer and smaller
-// ones later: n_alive * budget <= max(R, 4 n_alive)), twice over, as a power of two
-static inline int64_t vq_ring_slots(int64_t n_rays, int32_t rays_per_view) {
-    const int64_t n_views = n_rays / rays_per_view;
-    int64_t need = 2 * (n_rays / 16 + 2 * n_views) + 64, p2 = 64;
-    while (p2 < need) p2 <<= 1;
-    return p2;
-}
-static inline size_t vq_off_ctrl() { return ((size_t)kVQMaxJobs * sizeof(VQJob) + 255) & ~(size_t)255; }
-static inline size_t vq_off_ring() { return vq_off_ctrl() + (((size_t)kVQCtrlWords * 4 + 255) & ~(size_t)255); }
-static inline size_t vq_off_scratch(int64_t ring_slots) { return vq_off_ring() + (((size_t)ring_slots * 8 + 255) & ~(size_t)255); }
-static inline int64_t vq_bytes(int64_t n_rays, int32_t rays_per_view) {
-    if (rays_per_view > kVQMaxRaysPerView) return 0;
-    return (int64_t)vq_off_scratch(vq_ring_slots(n_rays, rays_per_view)) + vq_scratch_bytes();
-}
 
 static bool split_field() {
     static const bool on = diag_env("MNF_FIELD_SPLIT") != nullptr;
@@ -115,16 +92,6 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     if (split_field()) { p = take((col_cap / 64 + 1) * 8192); if (ws) ws->enc = p; }   // two-launch path: 128 B per column
     else if (ws) ws->enc = nullptr;
     if (ws) ws->col_cap = col_cap;
-    const int64_t vqb = vq_bytes(n_rays, rays_per_view);
-    p = take(n_views * 4); if (ws) ws->done = (int32_t *)p;
-    p = take(n_views * 4); if (ws) ws->n_items = (int32_t *)p;
-    p = take(n_views * 4); if (ws) ws->rpi = (int32_t *)p;
-    p = take(n_views * 4); if (ws) ws->lcnt = (int32_t *)p;
-    const int64_t lstride = rays_per_view + 64, sstride = rays_per_view / 16 + 2;
-    p = take(vqb ? n_views * lstride * 4 : 16); if (ws) ws->list = (int32_t *)p;
-    p = take(vqb ? n_views * lstride * 4 : 16); if (ws) ws->next = (int32_t *)p;
-    p = take(vqb ? n_views * sstride * 4 : 16); if (ws) { ws->segcnt = (int32_t *)p; ws->seg_stride = (int32_t)sstride; }
-    p = take(vqb ? vqb : 16); if (ws) { ws->vq = vqb ? p : nullptr; ws->vq_ring = vqb ? vq_ring_slots(n_rays, rays_per_view) : 0; }
     return (int64_t)off;
 }
 
@@ -355,33 +322,6 @@ __global__ void __launch_bounds__(kRayThreads) finalize_kernel(int64_t n_rays, f
     out.rgb[3 * r + 1] = out.rgb[3 * r + 1] + b1 * (1.0f - op);
     out.rgb[3 * r + 2] = out.rgb[3 * r + 2] + b2 * (1.0f - op);
     out.depth[r] = out.depth[r] / fmaxf(op, 1.1920928955078125e-07f);   // torch.finfo(float32).eps
-}
-
-// ------------------------------------------------------------------ view-queue renderer, host-side kernels (csrc/viewq.hip holds the renderer itself)
-__global__ void vq_set_job_kernel(VQJob *dst, VQJob job) { *dst = job; }
-
-// round 0 of every view: every ray in the view's first list (in the caller's march order), the budget for n_alive = rays_per_view (utils.py:667-672), the round's items in the queue
-__global__ void __launch_bounds__(256) vq_init_kernel(const VQJob *jobs, int32_t job, int32_t rays_per_view, int32_t ns0, const int32_t *view_order, int32_t waves_per_view) {
-    const VQJob j = jobs[job];
-    const int rpi0 = vq_rays_per_item(ns0, rays_per_view, waves_per_view);
-    const int ipv = (rays_per_view + rpi0 - 1) / rpi0;             // items of a view's first round
-    const int64_t n_rays = (int64_t)j.n_views * rays_per_view;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
-        j.ctrl[kVQHead] = 0; j.ctrl[kVQTail] = j.n_views * ipv; j.ctrl[kVQViewsLeft] = j.n_views; j.ctrl[kVQJobDone] = j.n_views == 0; j.ctrl[kVQError] = 0;
-    }
-    if (i < n_rays) {
-        const int v = (int)(i / rays_per_view), k = (int)(i - (int64_t)v * rays_per_view);
-        j.list[(int64_t)v * (rays_per_view + 64) + k] = v * rays_per_view + (view_order ? view_order[k] : k);
-    }
-    if (i < (int64_t)j.n_views * ipv) {
-        const int v = (int)(i / ipv), k = (int)(i - (int64_t)v * ipv);
-        j.ring[i & j.ring_mask] = ((unsigned long long)(i + 1) << 32) | ((unsigned)v << kVQItemBits) | (unsigned)k;
-    }
-    if (i < j.n_views) {
-        j.n_samples[i] = ns0; j.iter_samples[i] = ns0; j.done[i] = 0; j.n_items[i] = ipv; j.rpi[i] = rpi0;
-        j.cnt[i] = rays_per_view; j.alive_sink[i] = 0;
-    }
 }
 
 // ------------------------------------------------------------------ scorer (pipeline.py:727-781), one block per view
@@ -728,155 +668,6 @@ int run_jobs(std::vector<RenderJob> &jobs) {
     return MNF_OK;
 }
 
-// Small views: the whole loop as one persistent launch (csrc/viewq.hip).  Eligible when every job renders views of at most kVQMaxRaysPerView rays through ONE
-// occupancy level whose bits fit the LDS beside the field's weights, the jobs' fields share shape and operand type (an ensemble's members do), and the call
-// has at most kVQMaxGroups distinct (weights, occupancy grid) pairs.
-static int vq_groups(const std::vector<RenderJob> &jobs, std::vector<int> *order, std::vector<int> *group_end) {
-    std::vector<std::pair<const void *, const void *>> keys;
-    std::vector<int> grp(jobs.size());
-    for (size_t k = 0; k < jobs.size(); ++k) {
-        const std::pair<const void *, const void *> key(jobs[k].f->d_frags, jobs[k].ws.bitgrid);
-        size_t g = 0;
-        while (g < keys.size() && keys[g] != key) ++g;
-        if (g == keys.size()) keys.push_back(key);
-        grp[k] = (int)g;
-    }
-    if (order) {
-        order->clear(); group_end->clear();
-        for (size_t g = 0; g < keys.size(); ++g) {
-            for (size_t k = 0; k < jobs.size(); ++k) if (grp[k] == (int)g) order->push_back((int)k);
-            group_end->push_back((int)order->size());
-        }
-    }
-    return (int)keys.size();
-}
-
-bool viewq_eligible(const std::vector<RenderJob> &jobs) {
-    if (round_log() || split_field() || diag_env("MNF_COMPOSITE_GENERAL") || diag_env("MNF_MIN_SAMPLES") || diag_env("MNF_NO_VIEWQ")) return false;
-    if (jobs.empty() || (int)jobs.size() > kVQMaxJobs) return false;
-    const RenderJob &a = jobs[0];
-    if (a.opts.rays_per_view > kVQMaxRaysPerView || a.boxes.n != 1 || !a.lds_grid || a.n_words > kVQGridWords || !a.ws.vq) return false;
-    const mnf_field_config &c = a.f->cfg;
-    if (c.blend_fp16) return false;
-    if (!(c.mfma_bf16 ? bf16::viewq_supported(c.neurons, c.layers) : f16::viewq_supported(c.neurons, c.layers))) return false;
-    for (const RenderJob &j : jobs) {
-        const mnf_field_config &d = j.f->cfg;
-        if (d.neurons != c.neurons || d.layers != c.layers || (d.mfma_bf16 != 0) != (c.mfma_bf16 != 0) || d.blend_fp16) return false;
-        if (!j.ws.vq || j.boxes.n != 1 || !j.lds_grid || j.n_words != a.n_words) return false;
-    }
-    return vq_groups(jobs, nullptr, nullptr) <= kVQMaxGroups;
-}
-
-int run_viewq(std::vector<RenderJob> &jobs) {
-    RenderJob &a = jobs[0];
-    hipStream_t s = a.s;                       // everything on the first job's stream (the caller's): nothing here runs side by side
-    for (auto &j : jobs)
-        if (j.s != s) { MNF_HIP(hipEventRecord(j.res->ev_join, j.s)); MNF_HIP(hipStreamWaitEvent(s, j.res->ev_join, 0)); }   // the job's init ran on its own stream
-    const int32_t rpv = a.opts.rays_per_view;
-    VQJob *table = reinterpret_cast<VQJob *>(a.ws.vq);
-    const int ns0 = 1 > a.min_samples ? 1 : a.min_samples;                     // n_alive = rays_per_view: max(min(1, 64), min_samples)
-    std::vector<int> order, group_end;
-    const int n_groups = vq_groups(jobs, &order, &group_end);
-    std::vector<int64_t> group_rays(n_groups, 0);
-    int64_t total_rays = 0, total_views = 0;
-    for (auto &j : jobs) { total_rays += j.n_rays; total_views += j.n_views; }
-    // workgroups: one per 8 single-tile items of the first round (128 rays at a budget of 4), at most one per CU
-    int grid = (int)ceil_div(total_rays, (int64_t)kVQWaves * (64 / ns0));
-    if (grid > kVQMaxGrid) grid = kVQMaxGrid;
-    if (grid < n_groups) grid = n_groups;
-    int waves_per_view = (int)((int64_t)grid * kVQWaves / (total_views > 0 ? total_views : 1));
-    if (waves_per_view < 1) waves_per_view = 1;
-    total_rays = 0;
-    for (size_t k = 0; k < order.size(); ++k) {          // the job table holds the jobs group by group
-        RenderJob &j = jobs[order[k]];
-        VQJob d = {};
-        d.table = j.f->d_table; d.frags = j.f->d_frags;
-        d.levels = reinterpret_cast<const LevelMeta *>(reinterpret_cast<const char *>(j.f->d_frags) + (size_t)j.f->shape.blocks_total * 1024);
-        for (int i = 0; i < 6; ++i) d.aabb[i] = j.f->cfg.aabb[i];
-        d.C = j.C; d.out_fp16 = j.f->cfg.output_fp16 ? 1 : 0;
-        d.bitgrid = j.ws.bitgrid; d.rays_o = j.rays_o; d.rays_d = j.rays_d;
-        d.alive = j.ws.alive; d.hit = j.ws.hit; d.near_plane = j.ws.near_plane; d.t_min = j.ws.t_min; d.t_max = j.ws.t_max;
-        d.n_samples = j.ws.n_samples; d.iter_samples = j.ws.iter_samples; d.done = j.ws.done; d.n_items = j.ws.n_items; d.rpi = j.ws.rpi;
-        d.cnt = j.ws.lcnt; d.list = j.ws.list; d.next = j.ws.next; d.segcnt = j.ws.segcnt; d.seg_stride = j.ws.seg_stride; d.alive_sink = j.ws.alive_count;
-        d.rgb = j.out.rgb; d.acc = j.out.acc; d.depth = j.out.depth; d.sem = j.out.sem; d.rgb_var = j.out.rgb_var; d.depth_var = j.out.depth_var;
-        d.totals = reinterpret_cast<unsigned long long *>(j.out.total_samples);
-        d.ring = reinterpret_cast<unsigned long long *>(j.ws.vq + vq_off_ring());
-        d.ring_mask = (int32_t)(j.ws.vq_ring - 1);
-        d.n_views = j.n_views;
-        d.ctrl = reinterpret_cast<int32_t *>(j.ws.vq + vq_off_ctrl());
-        MNF_HIP(hipMemsetAsync(d.ring, 0, (size_t)j.ws.vq_ring * 8, s));
-        hipLaunchKernelGGL(vq_set_job_kernel, dim3(1), dim3(1), 0, s, table + k, d);
-        hipLaunchKernelGGL(vq_init_kernel, dim3((int)ceil_div(j.n_rays, 256)), dim3(256), 0, s, table, (int32_t)k, rpv, ns0, j.opts.view_order, waves_per_view);
-        int g = 0;
-        while ((int)k >= group_end[g]) ++g;
-        group_rays[g] += j.n_rays; total_rays += j.n_rays;
-    }
-    int rc = launch_status("vq_init_kernel");
-    if (rc) return rc;
-    VQArgs q = {};
-    q.jobs = table; q.n_jobs = (int32_t)order.size(); q.n_groups = n_groups; q.rays_per_view = rpv; q.waves_per_view = waves_per_view;
-    q.max_samples = a.opts.max_samples; q.min_samples = a.min_samples; q.probabilistic = a.opts.probabilistic;
-    q.far_plane = a.opts.far_plane; q.step_size = a.opts.render_step_size; q.cone_angle = a.opts.cone_angle;
-    q.alpha_thre = a.opts.alpha_thre; q.opc_thre = 1.0f - a.opts.early_stop_eps;
-    q.res = a.grid; q.n_words = a.n_words;
-    for (int i = 0; i < 6; ++i) q.occ_aabb[i] = a.ab[i];
-    // the workgroups are shared out to the groups by their rays (at least one each)
-    int given = 0;
-    for (int g = 0; g < n_groups; ++g) {
-        int share = (int)((int64_t)grid * group_rays[g] / (total_rays > 0 ? total_rays : 1));
-        if (share < 1) share = 1;
-        if (g == n_groups - 1 && given + share < grid) share = grid - given;
-        given += share;
-        q.group_job_end[g] = group_end[g]; q.group_wg_end[g] = given;
-    }
-    grid = given;
-    char *scratch = a.ws.vq + vq_off_scratch(a.ws.vq_ring);
-    const int64_t cols = (int64_t)kVQMaxGrid * kVQWaves * kVQWaveCols;
-    if (grid > kVQMaxGrid) { set_error("render: view-queue grid accounting error"); return MNF_ERR_INVALID; }
-    q.col_ray = reinterpret_cast<int32_t *>(scratch); q.col_ts = reinterpret_cast<float *>(scratch + cols * 4); q.col_te = reinterpret_cast<float *>(scratch + cols * 8);
-    q.error = reinterpret_cast<int32_t *>(a.ws.vq + vq_off_ctrl()) + kVQError;
-    const mnf_field_config &c = a.f->cfg;
-    static unsigned long long *d_stats = nullptr;
-    const bool want_stats = diag_env("MNF_VQ_STATS") != nullptr;
-    if (want_stats) {
-        if (!d_stats) MNF_HIP(hipMalloc((void **)&d_stats, 16 * 8));
-        MNF_HIP(hipMemsetAsync(d_stats, 0, 16 * 8, s));
-        q.stats = d_stats;
-    }
-    {
-        ProfScope ps("viewq_render", s);
-        rc = c.mfma_bf16 ? bf16::launch_viewq_impl(q, c.neurons, c.layers, grid, s) : f16::launch_viewq_impl(q, c.neurons, c.layers, grid, s);
-    }
-    if (rc) return rc;
-    for (auto &j : jobs) {
-        hipLaunchKernelGGL(finalize_kernel, dim3((int)ceil_div(j.n_rays, kRayThreads)), dim3(kRayThreads), 0, s, j.n_rays,
-                           j.opts.render_bkgd[0], j.opts.render_bkgd[1], j.opts.render_bkgd[2], j.out);
-    }
-    rc = launch_status("finalize_kernel");
-    if (rc) return rc;
-    // the kernel's own verdict (a queue that starved for seconds): read once, behind everything
-    MNF_HIP(hipMemcpyAsync(a.res->flags, q.error, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    MNF_HIP(hipEventRecord(a.res->ev_flags, s));
-    for (auto &j : jobs)
-        if (j.s != s) MNF_HIP(hipStreamWaitEvent(j.s, a.res->ev_flags, 0));        // (the side streams are joined by the caller: keep them behind this call's work)
-    MNF_HIP(hipEventSynchronize(a.res->ev_flags));
-    if (a.res->flags[0]) {
-        set_error("render: the view-queue kernel gave up (a queue starved for 4 s)");
-        return MNF_ERR_HIP;
-    }
-    if (want_stats) {
-        unsigned long long h[16];
-        MNF_HIP(hipMemcpy(h, d_stats, sizeof(h), hipMemcpyDeviceToHost));
-        const double tot = (double)(h[0] + h[2] + h[3] + h[4]);
-        fprintf(stderr, "[mnf viewq] grid %d, %llu waves, %llu items (%llu finishers), %llu tiles | wave cycles: pop %.1f %%, march %.1f %%, tiles %.1f %%, survivors + publish %.1f %%, "
-                        "compaction + push %.1f %% | per item: pop %.0f, march %.0f, tiles %.0f (%.0f per tile), publish %.0f; per finisher %.0f cycles\n",
-                grid, h[8], h[5], h[7], h[6], 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * (h[2] - h[1]) / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot,
-                (double)h[0] / (h[5] ? h[5] : 1), (double)h[1] / (h[5] ? h[5] : 1), (double)(h[2] - h[1]) / (h[5] ? h[5] : 1), (double)(h[2] - h[1]) / (h[6] ? h[6] : 1),
-                (double)h[3] / (h[5] ? h[5] : 1), (double)h[4] / (h[7] ? h[7] : 1));
-    }
-    return MNF_OK;
-}
-
 }  // namespace
 }  // namespace mnf
 
@@ -896,7 +687,7 @@ extern "C" int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t r
     rc = job_begin(jobs[0], f, binaries, res_x, res_y, res_z, aabb_host, rays_o, rays_d, n_rays, opts, rgb, acc, depth, sem, rgb_var, depth_var,
                    total_samples, workspace, workspace_bytes, as_stream(stream), &pool.res[0]);
     if (rc) return rc;
-    return viewq_eligible(jobs) ? run_viewq(jobs) : run_jobs(jobs);
+    return run_jobs(jobs);
 }
 
 extern "C" int mnf_render_jobs(const mnf_render_job *jobs_host, int32_t n_jobs, int32_t res_x, int32_t res_y, int32_t res_z,
@@ -926,7 +717,7 @@ extern "C" int mnf_render_jobs(const mnf_render_job *jobs_host, int32_t n_jobs, 
         if (rc) return rc;
     }
     if (jobs.empty()) return MNF_OK;
-    rc = viewq_eligible(jobs) ? run_viewq(jobs) : run_jobs(jobs);
+    rc = run_jobs(jobs);
     // join: the caller's stream continues after every job (also on an error path, so that no side stream is left racing the caller)
     for (auto &j : jobs)
         if (j.s != s0) { (void)hipEventRecord(j.res->ev_join, j.s); (void)hipStreamWaitEvent(s0, j.res->ev_join, 0); }
