@@ -130,7 +130,6 @@ SIGNATURES = {
     "mnf_vanilla_density": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_vanilla_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "mnf_field_train_workspace_bytes": (c_int64, [c_void_p, c_int64]),
-    "mnf_field_set_backward_mode": (c_int32, [c_void_p, c_int32]),
     "mnf_field_forward_train": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_field_backward": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -38,7 +38,6 @@ struct mnf_field_s {
     bool params_loaded;
     std::vector<int32_t> frag_src_host;   // host copy of the gather table (train.hip inverts it: parameter -> fragment slot)
     void *train_state;        // lazily built by train.hip (transposed fragments, weight-gradient job table)
-    int bwd_mode = 0;         // mnf_field_set_backward_mode: 0 / 1 the split kernels (dgrad + wgrad; default), 2 the fused backward (opt-in)
 };
 inline bool field_rows_supported(const mnf_field_s *f) { return f->cfg.neurons == 128 && !f->cfg.blend_fp16; }
 
@@ -108,10 +107,7 @@ struct TrainBuf {
     uint8_t *masks;   // [tiles][64 lanes][mask_bytes]: a record per lane (field_dev.h TrainLayout)
     int64_t Np;
     int32_t rows;
-    void *xenc;       // fused backward (csrc/fused_bwd.h): instead of `act` / `masks`, [tiles][kEncBlocks][64] x 16 B — the tile's hash features
-                      // (blocks ks * 2 + ct, ks < 4) and its SH fragment (blocks 8 + ct) in B-fragment order; NULL selects the full dump
 };
-constexpr int kEncBlocks = 10;
 
 // dispatchers on the handle's operand type (defined once, in the fp16 translation units)
 void free_train_state(mnf_field_t f);

@@ -223,10 +223,8 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     using T = TrainLayout<W, NH>;
     // ENC: 0 the kernel encodes; 1 the features come from encode_kernel's scratch in fragment order (two-launch diagnostic path); 2 they come from the rows the
     // density pre-pass left (FieldIO::rows_in / rows_src: one 128-byte line per sample instead of 128 gathers); 3 the kernel encodes AND leaves those rows (rows_out)
-    // SAVEK: 0 inference; 1 training with the full activation dump (split backward: dgrad + wgrad kernels); 2 training for the fused backward
-    // (csrc/fused_bwd.h): only the encoded inputs leave the kernel — the hash features and the SH fragment, in B-fragment order, 160 B per sample
+    // SAVEK: 0 inference; 1 training with the activation dump the backward kernels (dgrad + wgrad) read
     constexpr bool SAVE = SAVEK == 1;
-    constexpr bool SAVE_X = SAVEK == 2;
     constexpr int kBlocks = DENSITY_ONLY ? L::o_h_in : L::blocks;
     __shared__ half8 s_w[kBlocks * 64];
     __shared__ half_t s_stage[SAVE ? kWavesPerBlock * kStageHalves : 1];   // training: per-wave transpose tile of the activation dump
@@ -424,13 +422,6 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) save_pair<false>(from_constant(&la.train), tile, T::rX + 16 * ks, lane, stage, bfeat[0][ks], bfeat[1][ks]);
         }
-        half8 *xdump = SAVE_X ? reinterpret_cast<half8 *>(la.train.xenc) + tile * (kEncBlocks * 64) + lane : nullptr;
-        if (SAVE_X) {      // lane-linear 16-byte stores, no transpose: block (ks * 2 + ct) of the tile
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) xdump[(ks * 2 + ct) * 64] = bfeat[ct][ks];
-        }
 
         // ---- base MLP ----
         half8 hb[CT][L::KSW];
@@ -501,7 +492,6 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             save_pair<false>(from_constant(&la.train), tile, T::rS, lane, stage, hin[0][0], hin[1][0]);
             save_pair<true>(from_constant(&la.train), tile, T::rG, lane, stage, hin[0][1], hin[1][1]);
         }
-        if (SAVE_X) { xdump[8 * 64] = hin[0][0]; xdump[9 * 64] = hin[1][0]; }     // the SH fragment (blocks 8, 9)
         half8 h1[CT][L::KSh], h2[CT][L::KSh];
         f32x16 out_rgb[CT], out_sem[CT];
         auto save_hidden = [&](const half8 (&a)[CT][L::KSh], int row0, int mblk) {
@@ -678,7 +668,7 @@ static std::vector<int32_t> build_frag_table(const mnf_field_config &cfg) {
 template <int W, int NH>
 static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, int grid, hipStream_t stream, const TrainBuf *train) {
     KernelArgs a;
-    a.train = train ? *train : TrainBuf{nullptr, nullptr, 0, 0, nullptr};
+    a.train = train ? *train : TrainBuf{nullptr, nullptr, 0, 0};
     a.table = reinterpret_cast<const tab4 *>(f->d_table);
     a.frags = reinterpret_cast<const half8 *>(f->d_frags);
     std::memcpy(a.aabb, f->cfg.aabb, sizeof(a.aabb));
@@ -704,14 +694,9 @@ static int launch_variant(mnf_field_t f, const FieldIO &io, bool density_only, i
     const bool rows_ok = W == 128 && !b16 && !io.enc;
     if ((io.rows_in || io.rows_out) && !rows_ok) { set_error("field: feature rows are built for neurons = 128 with the fp32 blend"); return MNF_ERR_UNSUPPORTED; }
     if (train && io.rows_in && io.mode == 1) {
-        if constexpr (W == 128) {
-            if (train->xenc) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 2, 2, false>), dim3(grid), dim3(kThreads), 0, stream, a);
-            else hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 1, 2, false>), dim3(grid), dim3(kThreads), 0, stream, a);
-        }
+        if constexpr (W == 128) hipLaunchKernelGGL((field_kernel<W, NH, 1, false, 1, 2, false>), dim3(grid), dim3(kThreads), 0, stream, a);
     } else if (density_only && io.mode == 3 && io.rows_out) {
         if constexpr (W == 128) hipLaunchKernelGGL((field_kernel<W, NH, 3, true, 0, 3, false>), dim3(grid), dim3(kThreads), 0, stream, a);
-    } else if (train && train->xenc) {
-        if (io.mode == 1) MNF_LAUNCH_S(1, false, 2); else MNF_LAUNCH_S(0, false, 2);
     } else if (train) {
         if (io.mode == 1) MNF_LAUNCH_S(1, false, 1); else MNF_LAUNCH_S(0, false, 1);
     } else if (io.enc) {

@@ -383,8 +383,6 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradJob *__res
     g[jb.param_off + (int64_t)(jb.n0 + row) * jb.stride + col] = sum * inv_scale;   // every weight belongs to exactly one tile
 }
 
-#include "fused_bwd.h"
-
 // ------------------------------------------------------------------ hash-grid gradient scatter
 // Deterministic mode (mnf_train_opts.deterministic): the table gradient is accumulated in 64-bit fixed point (value * 2^56, integer
 // atomics: associative, so the result does not depend on the order in which the adds arrive), then converted to fp32 once.  The
@@ -1045,18 +1043,8 @@ struct WsView {
     half_t *act; uint8_t *masks; float *dX, *xn, *repl;
     float4 *bin_items;     // item lists of the binned scatter (levels kBinLevel0Default .. 15): part of the caller's workspace since round 4 (ADVICE r03:
     size_t bin_items_n;    // they were ~720 B per sample of raw hipMalloc per train state, invisible to the caller's allocator and grown mid-step)
-    half8 *enc;            // fused backward: the forward's encoded inputs ([tiles][kEncBlocks][64] x 16 B) instead of act / masks
     int64_t Np, bytes;
 };
-
-// The fused backward (fused_bwd.h) serves neurons = 128 with one or two hidden layers (the reference's yaml: 128 x 2) in the float-atomic mode;
-// deterministic accumulation and the other shapes keep the split kernels (dgrad + wgrad with the activation dump).
-// It is OPT-IN (mnf_field_set_backward_mode(f, 2)): measured on MI355X (round 4, profiles/r04_fused_backward.txt) it is bit-compatible with the split
-// kernels up to summation order but slower — one wave per SIMD with 512 registers (176 of them weight-gradient accumulators) leaves every LDS /
-// memory round trip of its nine phases exposed (68 % of wave cycles parked on s_waitcnt / s_barrier).
-static bool use_fused_backward(mnf_field_t f, bool deterministic) {
-    return !deterministic && f->cfg.neurons == 128 && f->cfg.layers <= 2 && f->bwd_mode == 2;
-}
 
 // the binned scatter's plan for an upper bound of n samples: levels [first, 16) (all hashed, one size, whole bins), lists per level, items per list
 constexpr int kBinLevel0Default = 12;      // measured: round 3 (tools/r03_bins_step.sh, profiles/r03_bins_step_*.txt) the step time was flat from 10 to 12, worse below and above (11 then);
@@ -1085,7 +1073,6 @@ static WsView carve_train(const TrainTables &tt, const mnf_field_s *f, void *bas
     v.dX = (float *)take((size_t)v.Np * 64 * 4);
     v.xn = (float *)take((size_t)v.Np * 3 * 4);
     v.repl = (float *)take((size_t)kReplicas * kReplMaxEntries * 4 * sizeof(float));   // private copies of the coarsest levels' gradient (scatter)
-    v.enc = (half8 *)take((size_t)(v.Np / 64) * kEncBlocks * 64 * sizeof(half8));
     {
         int first; uint32_t nb, cap;
         bin_plan(f, n, kBinLevel0Default, first, nb, cap);
@@ -1120,7 +1107,7 @@ int forward_train_impl(mnf_field_t f, const FieldIO &io, void *workspace, int64_
         set_error("field_forward_train: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)v.bytes);
         return MNF_ERR_WORKSPACE;
     }
-    TrainBuf tb = {v.act, v.masks, v.Np, ts->tt.rows, use_fused_backward(f, deterministic) ? v.enc : nullptr};
+    TrainBuf tb = {v.act, v.masks, v.Np, ts->tt.rows};
     return launch_field_impl(f, io, false, stream, &tb);
 }
 
@@ -1163,9 +1150,6 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     const int64_t n_frag = (int64_t)ts->tt.fragT.size();
     hipLaunchKernelGGL(gather_fragsT_kernel, dim3((unsigned)ceil_div(n_frag > 16 * kMaxBins ? n_frag : (int64_t)16 * kMaxBins, 256)), dim3(256), 0, s, ts->d_fragT_src,
                        reinterpret_cast<const half_t *>(f->d_frags), ts->d_fragT, n_frag, ts->d_bin_cursors, 16 * kMaxBins);
-    const bool fused = use_fused_backward(f, deterministic);
-    if (f->bwd_mode == 2 && !fused) { set_error("field_backward: the fused backward serves neurons = 128, layers <= 2, non-deterministic mode only"); return MNF_ERR_UNSUPPORTED; }
-    if (factored && fused) { set_error("field_backward: the fused backward reads per-sample output gradients"); return MNF_ERR_UNSUPPORTED; }
     BwdArgs a;
     a.fg = fg;
     a.fragsT = reinterpret_cast<const half8 *>(ts->d_fragT);
@@ -1178,9 +1162,8 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     // (and the weight gradients, which read every range) is left behind the last dgrad.  One range = the old schedule (deterministic mode: its grouping
     // of partial sums must not change).
     static const int chunks_env = diag_env("MNF_BWD_CHUNKS") ? atoi(diag_env("MNF_BWD_CHUNKS")) : 0;
-    // measured (profiles/r04_bwd_chunks.txt): 5.77 / 5.52 / 5.60 ms per step with 1 / 2 / 4 ranges.  The fused backward takes every register of a CU: no scatter
-    // workgroup runs beside it, and a second range only costs a second flush of its weight gradients (4.33 / 4.26 ms with 1 / 2 ranges when its kernel ran 2 x 0.78 ms).
-    int n_chunks = (!deterministic && !fused && n >= ((int64_t)1 << 18)) ? 2 : 1;
+    // measured (profiles/r04_bwd_chunks.txt): 5.77 / 5.52 / 5.60 ms per step with 1 / 2 / 4 ranges.
+    int n_chunks = (!deterministic && n >= ((int64_t)1 << 18)) ? 2 : 1;
     if (chunks_env >= 1 && chunks_env <= 4 && !deterministic) n_chunks = chunks_env;
     if (!positions_normalized) {   // (the train step's forward hands over normalised positions already: FieldIO::xn_out)
         const float *ab = f->cfg.aabb;
@@ -1194,26 +1177,10 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
     if (wgs < grid) grid = (int)wgs;
     const int W = f->cfg.neurons, NH = f->cfg.layers;
     bool ok = false;
-    if (fused) {      // forward recompute + backward-data + weight gradients in one launch (fused_bwd.h); the scatter below is unchanged
-        FusedBwdArgs fa;
-        fa.frags = reinterpret_cast<const half8 *>(f->d_frags); fa.fragsT = a.fragsT; fa.enc = v.enc; fa.jobs = ts->d_jobs;
-        fa.d_rgb = d_rgb; fa.d_sigma = d_density; fa.d_sem = d_sem; fa.rgb = rgb; fa.sigma = density; fa.dX = v.dX;
-        fa.g0 = g_base; fa.g1 = g_head; fa.g2 = g_sem; fa.n = n; fa.Np = v.Np; fa.n_dev = n_dev; fa.C = f->cfg.num_semantic_classes;
-        fa.out_fp16 = f->cfg.output_fp16 ? 1 : 0; fa.loss_scale = loss_scale;
-        const int fgrid = (int)(chunk_tiles_max < 256 ? chunk_tiles_max : 256);
-        ProfScope ps("fused_backward", s);
-        for (int c = 0; c < n_chunks; ++c) {      // range by range like dgrad below: the scatter of a range runs beside the next range's launch
-            fa.chunk = c; fa.n_chunks = n_chunks;
-            if (NH == 1) hipLaunchKernelGGL((fused_bwd_kernel<1>), dim3(fgrid), dim3(kFusedThreads), 0, s, fa);
-            else hipLaunchKernelGGL((fused_bwd_kernel<2>), dim3(fgrid), dim3(kFusedThreads), 0, s, fa);
-            MNF_HIP(hipEventRecord(ts->ev_chunk[c], s));
-        }
-        ok = true;
-    }
-    const int prof_dgrad = fused ? -1 : prof_start("dgrad", s);
-    for (int c = 0; c < n_chunks && !fused; ++c) {
+    const int prof_dgrad = prof_start("dgrad", s);
+    for (int c = 0; c < n_chunks; ++c) {
         a.chunk = c; a.n_chunks = n_chunks;
-#define MNF_CASE(w, nh) if (!fused && W == w && NH == nh) { launch_dgrad<w, nh>(a, grid, s); ok = true; }
+#define MNF_CASE(w, nh) if (W == w && NH == nh) { launch_dgrad<w, nh>(a, grid, s); ok = true; }
 #ifdef MNF_DEV_ONLY_128x2
         MNF_CASE(128, 2)
 #else
@@ -1254,7 +1221,7 @@ int backward_impl(mnf_field_t f, const float *positions, int64_t n, const int64_
         partials = ts->d_partials;
     }
     static const bool no_wgrad = diag_env("MNF_NO_WGRAD") != nullptr;    // timing experiments: the scatter alone on the chip
-    if (!no_wgrad && !fused) {
+    if (!no_wgrad) {
         ProfScope ps("wgrad", s);
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(ceil_div(n_groups, 4) * split)), dim3(256), 0, s, ts->d_jobs, ts->d_groups, n_groups,
                            split, v.act, n, n_dev, ts->tt.rows, 1.0f / loss_scale, g_base, g_head, g_sem, partials);
@@ -1570,13 +1537,6 @@ int backward(mnf_field_t f, const float *positions, int64_t n, const int64_t *n_
 
 using namespace mnf;
 
-extern "C" int mnf_field_set_backward_mode(mnf_field_t f, int32_t mode) {
-    MNF_REQUIRE(f && mode >= 0 && mode <= 2, "field_set_backward_mode: mode must be 0 (auto), 1 (split kernels) or 2 (fused)");
-    MNF_REQUIRE(mode != 2 || (f->cfg.neurons == 128 && f->cfg.layers <= 2), "field_set_backward_mode: the fused backward serves neurons = 128, layers <= 2");
-    f->bwd_mode = mode;
-    return MNF_OK;
-}
-
 extern "C" int64_t mnf_field_train_workspace_bytes(mnf_field_t f, int64_t n) {
     if (!f) return -1;
     return f->cfg.mfma_bf16 ? bf16::train_workspace_bytes_impl(f, n) : f16::train_workspace_bytes_impl(f, n);
@@ -1699,11 +1659,3 @@ extern "C" int mnf_count_nan(const float *values, int64_t n, int32_t *count, mnf
     return launch_status("count_nan_kernel");
 }
 #endif  // MNF_BF16
-
-#if defined(MNF_FUSED_STAMPS) && !defined(MNF_BF16)
-// experiment builds only (tools/exp_fused_stamps.py): the phase stamps fused_bwd_kernel's workgroup 0 left in its last launch
-extern "C" int mnf_exp_fused_stamps(unsigned long long *out, int n) {
-    const size_t bytes = (size_t)n * sizeof(unsigned long long);
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mnf::f16::g_fused_stamps), bytes < sizeof(mnf::f16::g_fused_stamps) ? bytes : sizeof(mnf::f16::g_fused_stamps)) == hipSuccess ? 0 : -1;
-}
-#endif

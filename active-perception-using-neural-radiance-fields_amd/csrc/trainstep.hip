@@ -548,7 +548,7 @@ extern "C" int mnf_train_step(mnf_field_t f, const uint8_t *binaries, const uint
     if (rc) return rc;
     // the rgb / semantic output gradients of a sample are its weight times its ray's loss gradient: the split backward forms them itself from (k_w, k_ray, g_rgb, g_sem)
     // — 12 bytes per sample and cached per-ray vectors instead of 128 bytes written here and read there; the fused backward (mode 2) reads the per-sample arrays
-    const bool factored = f->bwd_mode != 2 && C > 0;
+    const bool factored = C > 0;
     rc = composite_train_backward_impl(w.kept_starts, w.kept_cnts, n_rays, w.k_ts, w.k_te, w.k_sigma, w.k_rgb, w.k_sem, max_kept, C, max_kept, bk, w.k_w, w.k_tr, w.o_acc,
                                        w.o_dep, w.g_rgb, nullptr, w.g_dep, w.g_sem, w.k_dsig, factored ? nullptr : w.k_drgb, factored ? nullptr : w.k_dsem, stream);
     if (rc) return rc;

@@ -201,13 +201,6 @@ class NGPRadianceField(torch.nn.Module):
             self._loaded_versions = versions
         return self._handle
 
-    def set_backward_mode(self, mode: int):
-        """`mnf_field_set_backward_mode`: 0 / 1 the split kernels (dgrad + wgrad over the saved activations, tcnn's decomposition: the
-        default), 2 the fused backward (recompute + backward-data + weight gradients in one kernel, no activation dump; neurons = 128,
-        layers <= 2).  Applies to the following forward / backward pairs and train steps of this field."""
-        L.check(L.load_library().mnf_field_set_backward_mode(self._ensure_handle(), int(mode)))
-        return self
-
     def _refresh_after_optimizer(self):
         """Called by `optim.FusedAdam` (bound with `bind_field`) after it updated the parameters: its kernel has already written the
         rounded hash-table values into the handle's fp16 table, so only the MLP weight fragments are re-derived (no conversion pass

@@ -349,13 +349,9 @@ int mnf_vanilla_backward(mnf_vanilla_t v, const float *d_rgb, const float *d_sig
  * that keeps activations and the backward to the flat parameter vectors.  Compositing, the loss and the optimizer
  * stay with the caller exactly as in the reference (perception/models/utils.py:362-461, pipeline.py:506-535). */
 
-/* How the backward behind the train forward is computed (tiny-cuda-nn fuses its backward-data pass and runs the weight gradients as GEMMs over
- * saved activations, ngp.py:123-169 / pipeline.py:518).  0 (default) and 1: the split kernels — a fused backward-data kernel (dgrad) and weight-gradient
- * GEMMs (wgrad) over the 2.4 KB per sample of 16-bit activations the train forward saves, tcnn's own decomposition; 2: the fused backward — forward
- * recompute, backward-data and weight gradients of a 64-sample tile in ONE kernel, the forward leaves 160 B per sample and no activation dump
- * (neurons = 128, layers <= 2, non-deterministic accumulation only: MNF_ERR_UNSUPPORTED otherwise).  Same gradients up to summation order; mode 2 is
- * the slower of the two on MI355X so far.  Set it before a forward / backward pair, not between the two. */
-int mnf_field_set_backward_mode(mnf_field_t f, int32_t mode);
+/* The backward behind the train forward is tiny-cuda-nn's own decomposition (ngp.py:123-169 / pipeline.py:518): a fused backward-data kernel (dgrad) and
+ * weight-gradient GEMMs (wgrad) over the 2.4 KB per sample of 16-bit activations the train forward saves.  (A single-kernel form without the dump was built in
+ * round 4 and measured slower: tools/experiments/fused_backward.patch, DESIGN.md "negative results".) */
 /* bytes of workspace the train forward/backward pair needs for n samples (activations, masks, feature gradients) */
 int64_t mnf_field_train_workspace_bytes(mnf_field_t f, int64_t n);
 /* NGPRadianceField.forward with activations saved into `workspace` for the following backward */

@@ -21,7 +21,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 lr = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0          # 0: the parameters (hence the sample counts) stay put across the timed steps
 shapes = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [8192, 2000]
 modes = [bool(int(x)) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [True, False]
-bwd_mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0        # mnf_field_set_backward_mode: 0 auto (fused where supported), 1 split kernels, 2 fused
+bwd_mode = 0                                                     # (argv[6] was the backward mode of round 4's fused-backward experiment: tools/experiments/fused_backward.patch)
 presample = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False   # march batch k+1 beside step k (render.presample)
 dev = "cuda:0"
 scene = SC.make_scene("102344280", n_poses=40)
@@ -32,8 +32,6 @@ if dtype == "bf16":
     f2.load_state_dict(field.state_dict())
     field = f2
 field.train(); est.train()
-from apnrf_amd import _lib as L
-L.check(L.load_library().mnf_field_set_backward_mode(field._ensure_handle(), bwd_mode))
 proc = SI._procedural_estimator(scene, dev)
 c2w = np.stack([RD.pose_to_c2w(p) for p in scene["poses"][:8]]).astype(np.float32)
 K6 = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
