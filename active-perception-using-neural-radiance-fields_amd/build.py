@@ -87,7 +87,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print("[mi355nerf] compiling", ", ".join(SOURCES), "(+ diag units)", file=sys.stderr)
     hdr_m = _headers_mtime()
     jobs = [(k, e, False, force, hdr_m) for k, e in SOURCES.items()] + [(k, SOURCES[k], True, force, hdr_m) for k in DIAG_UNITS]
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+    with ThreadPoolExecutor(max_workers=min(20, os.cpu_count() or 4)) as ex:
         objs = list(ex.map(_compile, jobs))
     rel = objs[:len(SOURCES)]
     diag_of = dict(zip(DIAG_UNITS, objs[len(SOURCES):]))

@@ -50,7 +50,7 @@ def gather_rows(local: torch.Tensor, rows_per_rank: int, total_rows: int, group=
         block = local.new_zeros((rows_per_rank, D))
         block[:local.shape[0]] = local
     out = local.new_empty((world * rows_per_rank, D))
-    dist.all_gather_into_tensor(out, block.contiguous(), group=group)
+    RD.all_gather_blocks(out, block.contiguous(), group)
     return out[:total_rows]
 
 

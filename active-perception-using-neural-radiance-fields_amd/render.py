@@ -953,8 +953,20 @@ def gather_view_terms(terms_local: torch.Tensor, n_views: int, group=None) -> to
         return terms_local[:n_views]
     world = dist.get_world_size(group)
     gathered = torch.empty(world * terms_local.shape[0], 4, dtype=terms_local.dtype, device=terms_local.device)
-    dist.all_gather_into_tensor(gathered, terms_local.contiguous(), group=group)
+    all_gather_blocks(gathered, terms_local.contiguous(), group)
     return gathered[:n_views]
+
+
+def all_gather_blocks(out: torch.Tensor, block: torch.Tensor, group=None) -> None:
+    """`dist.all_gather_into_tensor(out, block)`: RCCL for device tensors; under the `gloo` backend (CPU test rigs, two processes sharing one GPU) device tensors
+    are staged through the host, which is the only form gloo offers for them."""
+    import torch.distributed as dist
+    if block.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, block.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, block, group=group)
 
 
 def trajectory_score(terms: torch.Tensor) -> torch.Tensor:

@@ -191,3 +191,36 @@ def train_standin(scene, device, steps=2000, max_rays=8192, target_samples=1 << 
     if keep_optimizer:
         info["optimizer_state"] = opt.state_dict()
     return field.eval(), est.eval(), info
+
+
+def shared_standin(scene, device, steps=2000, seed=9, keep_optimizer=False, group=None, cache_dir=None, log=None):
+    """`train_standin` for every rank of a job with ONE training: rank 0 trains (or loads its cache) and says whether the cache file exists now; the other ranks
+    load that file, or — when it could not be written (read-only home, full disk) — build empty modules and receive weights and occupancy grid by
+    `distributed.broadcast_model`.  Every rank reaches the same collectives whatever happened to the file.  -> (field, estimator, info); info of ranks that
+    received the model by broadcast carries `received_by_broadcast=True` and no optimizer state."""
+    import torch.distributed as dist
+    from . import distributed as DD
+    distributed = group is not False and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if distributed else 0
+    field = est = None
+    info = {}
+    flag_dev = device if (distributed and dist.get_backend(group) == "nccl") else "cpu"
+    saved = torch.zeros(1, device=flag_dev)
+    if rank == 0:
+        field, est, info = train_standin(scene, device, steps=steps, seed=seed, keep_optimizer=keep_optimizer, cache_dir=cache_dir)
+        if log:
+            log(f"stand-in {scene.get('name')} seed {seed}: " + str({k: v for k, v in info.items() if k != "optimizer_state"}))
+        saved.fill_(1.0 if info.get("saved", info.get("cached")) else 0.0)
+    if distributed:
+        dist.broadcast(saved, src=0, group=group)
+        if rank != 0:
+            if saved.item() > 0:
+                field, est, info = train_standin(scene, device, steps=steps, seed=seed, keep_optimizer=keep_optimizer, cache_dir=cache_dir)      # cache hit
+            else:
+                from . import scenes as SC
+                field = SC.hip_field(scene, device)
+                est = NA.OccGridEstimator(torch.from_numpy(scene["aabb"]), resolution=scene["res"], levels=1).to(device)
+                info = {"received_by_broadcast": True}
+        if saved.item() == 0:
+            DD.broadcast_model(field, est, src=0, group=group)
+    return field.eval(), est.eval(), info

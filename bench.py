@@ -355,28 +355,14 @@ def main():
         if args.weights == "random":
             return scene, SC.hip_field(scene, dev), SC.hip_estimator(scene, dev)
         steps = args.standin_steps if steps is None else steps
-        saved = torch.zeros(1, device=dev)
-        field = est = None
         if rank == 0:
             log(f"stand-in {name} seed {seed}: training / loading")
-            field, est, info = SI.train_standin(scene, dev, steps=steps, seed=seed, keep_optimizer=keep_optimizer)
-            opt_states[name] = info.pop("optimizer_state", None)
-            log(f"stand-in {name} seed {seed}: {info}")
+        field, est, info = SI.shared_standin(scene, dev, steps=steps, seed=seed, keep_optimizer=keep_optimizer, group=None if distributed else False,
+                                             log=log if rank == 0 else None)
+        opt_states[name] = info.pop("optimizer_state", None)
+        if rank == 0:
             standin_info[f"{name}/seed{seed}"] = {k: info.get(k) for k in ("steps", "seconds", "loss_first", "loss_last", "skipped_steps",
                                                                           "occupied_cells", "cells", "cached")}
-            saved.fill_(1.0 if info.get("saved", info.get("cached")) else 0.0)
-        if distributed:
-            dist.broadcast(saved, src=0)
-            if rank != 0:
-                if saved.item() > 0:
-                    field, est, info = SI.train_standin(scene, dev, steps=steps, seed=seed, keep_optimizer=keep_optimizer)        # cache hit
-                    opt_states[name] = info.pop("optimizer_state", None)
-                else:
-                    from apnrf_amd.nerfacc import OccGridEstimator
-                    field = SC.hip_field(scene, dev)
-                    est = OccGridEstimator(torch.from_numpy(scene["aabb"]), resolution=scene["res"], levels=1).to(dev)
-            if saved.item() == 0:
-                DD.broadcast_model(field, est, src=0)
         return scene, field.eval(), est.eval()
 
     def timed(step_fn, steps, warmup, with_events, collect=None):
