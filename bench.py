@@ -468,15 +468,15 @@ def main():
             field_ms, launches = prof("field_render")
             if launches and samples2:
                 achieved = ALGO_BYTES_PER_SAMPLE * samples2 / (field_ms * 1e-3) / 1e9
-                traffic, traffic_note = None, "no PMC profile of this kernel build is committed (profiles/r04_pmc.json)"
-                pj = os.path.join(REPO, "profiles", "r04_pmc.json")
+                traffic, traffic_note = None, "no PMC profile of this kernel build is committed (profiles/r05_pmc.json)"
+                pj = os.path.join(REPO, "profiles", "r05_pmc.json")
                 if os.path.exists(pj):
                     pm = json.load(open(pj))
                     if pm.get("field_sources_md5") == field_source_id():
                         traffic = pm["field_kernel"]["hbm_bytes_per_sample"] * samples2 / launches
-                        traffic_note = "rocprofv3 --pmc passes of this kernel build (profiles/r04_pmc.json: FETCH_SIZE + WRITE_SIZE per evaluated sample), scaled to this run's samples per launch"
+                        traffic_note = "rocprofv3 --pmc passes of this kernel build (profiles/r05_pmc.json: FETCH_SIZE + WRITE_SIZE per evaluated sample), scaled to this run's samples per launch"
                     else:
-                        traffic_note = "profiles/r04_pmc.json was measured on a different build of the kernel sources: not quoted"
+                        traffic_note = "profiles/r05_pmc.json was measured on a different build of the kernel sources: not quoted"
                 line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                     "traffic": traffic, "traffic_source": traffic_note,
                                     "kernel": "mnf::field_kernel<128,2,2,false> (hash gather + MLPs + fused compositing)",

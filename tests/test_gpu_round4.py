@@ -44,7 +44,7 @@ def test_train_step_c_call_is_repeatable_and_matches_oracle_autograd():
     loss = F.smooth_l1_loss(ref[0], pix) * 10 + F.smooth_l1_loss(ref[2], dep.unsqueeze(1)) / 5 + F.cross_entropy(ref[3], lab) / 2
     loss.backward()
     assert ref[4] == res[2][0]
-    assert abs(float(loss) - res[2][1]) < 5e-4 * max(1.0, abs(float(loss)))
+    assert abs(float(loss.detach()) - res[2][1]) < 5e-4 * max(1.0, abs(float(loss.detach())))
     for got, want in zip(res[2][2], (orc.p_base.grad, orc.p_head.grad, orc.p_sem.grad)):
         w = want.to(DEV)
         assert _rel(got, w) < 5e-2 and torch.nn.functional.cosine_similarity(got, w, dim=0) > 0.998, (_rel(got, w),)

@@ -31,15 +31,16 @@ if has pmc; then
   pmc fetch --workload render800 -- FETCH_SIZE
   pmc write --workload render800 -- WRITE_SIZE
   pmc sq --workload render800 -- SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY
-  python tools/reduce_pmc.py /tmp/pmc_fetch_counter_collection.csv /tmp/pmc_write_counter_collection.csv $out/pmc_fetch.json $out/r04_pmc.json "field_kernel<128, 2, 2, false, 0, 0, false" field_kernel
+  python tools/reduce_pmc.py /tmp/pmc_fetch_counter_collection.csv /tmp/pmc_write_counter_collection.csv $out/pmc_fetch.json $out/r05_pmc.json "field_kernel<128, 2, 2, false, 0, 0, false" field_kernel
 fi
 if has pmc_score; then
   pmc score_fetch --workload score256 -- FETCH_SIZE
   pmc score_write --workload score256 -- WRITE_SIZE
   pmc score_sq --workload score256 -- SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY
-  python tools/reduce_pmc.py /tmp/pmc_score_fetch_counter_collection.csv /tmp/pmc_score_write_counter_collection.csv $out/pmc_score_fetch.json $out/r04_pmc.json "field_kernel<128, 2, 2, false, 0, 0, false" field_kernel_scoring
+  python tools/reduce_pmc.py /tmp/pmc_score_fetch_counter_collection.csv /tmp/pmc_score_write_counter_collection.csv $out/pmc_score_fetch.json $out/r05_pmc.json "field_kernel<128, 2, 2, false, 0, 0, false" field_kernel_scoring
 fi
-if has pmc_train; then
+if has pmc_train_atomic; then
   pmc train_atomic --workload train --train-dtypes f16 -- TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum
 fi
 ls $out
+if has pmc_train; then bash tools/r05_pmc_train.sh 8192 > $out/pmc_train.txt 2>&1; cp gpurun_out/r05_pmc_train_8192.json $out/r05_pmc_train.json; tail -25 $out/pmc_train.txt; fi
