@@ -132,7 +132,10 @@ def _render_jobs(specs, rpv, max_samples, near_plane, far_plane, render_step_siz
         rgb_var = torch.empty(n, 3, device=dev) if probabilistic else None
         depth_var = torch.empty(n, 1, device=dev) if probabilistic else None
         V = n // rpv
-        G = max(1, min(int(n_split), V))
+        # n_split=None: the measured optimum for the shape — small views (the scorer's 64 x 64 sub-samples: a round is latency-bound) advance as four jobs, full
+        # images as two (profiles/r03_hw_queues.txt: one member, 256 scoring views 54.3 -> 50.4 ms with four; 800 x 800 views: two and four tie)
+        want = (4 if rpv <= 16384 else 2) if n_split is None else int(n_split)
+        G = max(1, min(want, V))
         totals = torch.zeros(G, 2, dtype=torch.int64, device=dev)   # per job: [kept (reference total_samples), evaluated]
         keep += [binaries, bits, o, d, totals]
         for g in range(G):
@@ -926,7 +929,7 @@ def render_image_from_pose(radiance_field, estimator, poses, width, height, foca
     poses = np.asarray(poses)
     o, d, h, w = _pose_rays(poses, width, height, focal, scale, device)
     r = render_views(radiance_field, estimator, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
-                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, image_hw=(h, w))
+                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, image_hw=(h, w), n_split=None)
     P, C = poses.shape[0], radiance_field.num_semantic_classes
     return _host_stacks_f64([(r["rgb"], (P, h, w, 3)), (r["depth"], (P, h, w)), (r["acc"], (P, h, w)), (r["sem"], (P, h, w, C))])
 
@@ -939,7 +942,7 @@ def render_probablistic_image_from_pose(radiance_field, estimator, poses, width,
     poses = np.asarray(poses)
     o, d, h, w = _pose_rays(poses, width, height, focal, scale, device)
     r = render_views(radiance_field, estimator, o, d, h * w, 1024, near_plane=near_plane, render_step_size=render_step_size,
-                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, probabilistic=True, image_hw=(h, w))
+                     render_bkgd=torch.zeros(3), cone_angle=cone_angle, alpha_thre=alpha_thre, probabilistic=True, image_hw=(h, w), n_split=None)
     P, C = poses.shape[0], radiance_field.num_semantic_classes
     return _host_stacks_f64([(r["rgb"], (P, h, w, 3)), (r["rgb_var"], (P, h, w, 3)), (r["depth"], (P, h, w)), (r["depth_var"], (P, h, w)), (r["acc"], (P, h, w)),
                              (r["sem"], (P, h, w, C))])
