@@ -492,6 +492,29 @@ def gen_glue_ngp():
         rec.update(pose_whf=np.asarray([W, H, focal]), pose_idx=np.asarray([2, 6]), pose_images=images, pose_depths=depths, pose_accs=accs, pose_sems=sems)
         images, images_var, depths, depths_var, accs, sems = h2d.Dataset.render_probablistic_image_from_pose(*args)
         rec.update(ppose_images=images, ppose_images_var=images_var, ppose_depths=depths, ppose_depths_var=depths_var, ppose_accs=accs, ppose_sems=sems)
+    # --- two occupancy levels (occ_grid.py:37-55; utils.py:637-644 sorts the 2L entry / exit distances and hands them to traverse_grids): the
+    #     estimator covers an inner region, level 1 is twice as large about its centre, the field covers the largest level (pipeline.py:167-172)
+    from nerfacc import OccGridEstimator
+    from oracle.field import FieldConfig, OracleField
+    from apnrf_amd import synthetic as S
+    roi = np.array([-16.0, 0.0, -16.0, -6.0, 2.4, -6.0], np.float32)
+    est2 = OccGridEstimator(roi_aabb=torch.from_numpy(roi), resolution=[50, 12, 50], levels=2)
+    rng = np.random.default_rng(7)
+    occ2 = rng.random((2, 50, 12, 50)) < np.array([0.12, 0.08])[:, None, None, None]
+    est2.binaries = torch.from_numpy(occ2)
+    est2 = est2.eval()
+    aabbs2 = est2.aabbs.numpy()
+    params = S.make_field_params(128, 2, 29, seed=0, log2_hashmap_size=14)
+    cfg = FieldConfig(aabb=tuple(float(x) for x in aabbs2[-1]), neurons=128, layers=2, num_semantic_classes=29, log2_hashmap_size=14)
+    f2 = type(field)(OracleField(cfg, params, "f16"))
+    o2, d2 = _view(sc, 3, 10, 12)
+    o2 = o2 + torch.tensor([3.0, 0.0, 3.0])                      # inside the roi
+    with torch.no_grad():
+        shim.traverse_log.clear()
+        rgb, rgb_var, acc, depth, depth_var, sem, tot = U.render_probablistic_image_with_occgrid_test(1024, f2, est2, Rays(o2, d2), render_bkgd=bk, **GLUE_KW)
+    rec.update(ml_roi=roi, ml_occ=np.packbits(occ2), ml_aabbs=aabbs2, ml_rays_o=o2.numpy(), ml_rays_d=d2.numpy(), ml_rgb=rgb.numpy(), ml_rgb_var=rgb_var.numpy(),
+               ml_acc=acc.numpy(), ml_depth=depth.numpy(), ml_depth_var=depth_var.numpy(), ml_sem=sem.numpy(), ml_total=np.int64(tot),
+               ml_rounds=np.asarray(shim.traverse_log, np.int64))
     np.savez_compressed(os.path.join(OUT, "glue_ngp.npz"), **rec)
 
 

@@ -203,6 +203,27 @@ def test_oracle_with_ngp_field_equals_reference_glue_and_pose_drivers(golden):
         _close(g["pose_images"][k], g["ppose_images"][k], "deterministic driver == probabilistic driver")
 
 
+def multilevel_of(g):
+    occ = np.unpackbits(g["ml_occ"])[: 2 * 50 * 12 * 50].reshape(2, 50, 12, 50).astype(bool)
+    return occ, g["ml_aabbs"]
+
+
+def test_oracle_two_occupancy_levels_equal_reference_glue(golden):
+    """utils.py:637-644 with n_grids = 2: the reference sorts the 2L entry / exit distances (torch.sort) and traverse_grids takes the ray's segments level by level."""
+    from apnrf_amd import synthetic as S
+    from oracle import render as R
+    from oracle.field import FieldConfig, OracleField
+    g = golden("glue_ngp")
+    sc = scene_of(g)
+    occ, aabbs = multilevel_of(g)
+    params = S.make_field_params(128, 2, 29, seed=int(g["param_seed"]), log2_hashmap_size=int(g["log2_hashmap_size"]))
+    cfg = FieldConfig(aabb=tuple(float(x) for x in aabbs[-1]), neurons=128, layers=2, num_semantic_classes=29, log2_hashmap_size=int(g["log2_hashmap_size"]))
+    f = OracleField(cfg, params, "f16")
+    out = R.render_prob_test(1024, f, occ, aabbs, _t(g["ml_rays_o"]), _t(g["ml_rays_d"]), render_bkgd=_t(g["bkgd"]), **sc["kw"])
+    _check_test_render(out, g, "ml", True)
+    assert out["total_samples"] > 3000 and len(out["rounds"]) > 10
+
+
 def scorer_stacks(g):
     """[M,1,V,h,w,.] as pipeline.py:720-725 builds them"""
     st = lambda nm: np.stack([g[f"m{m}_{nm}"].astype(np.float64)[None] for m in range(2)])

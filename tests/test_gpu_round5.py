@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import helpers as H
-from test_glue_golden_cpu import AnalyticField, pipeline_loss, scene_of, scorer_stacks
+from test_glue_golden_cpu import AnalyticField, multilevel_of, pipeline_loss, scene_of, scorer_stacks
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -164,6 +164,29 @@ def test_fused_renderers_equal_reference_glue_golden(golden):
     assert abs(n - int(g["tre_n"])) <= 3
     for got, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (sem, "sem")):
         _check(got.cpu().numpy(), g["tre_" + k], k, rtol=1e-3 if k == "depth" else 0.0)
+
+
+def test_fused_renderer_two_occupancy_levels_equals_reference_glue_golden(golden):
+    """The reference's probabilistic render loop over an estimator with TWO occupancy levels (glue_ngp.npz `ml_*`) against the fused renderer."""
+    from apnrf_amd import render as RD
+    from apnrf_amd import synthetic as S
+    from apnrf_amd.nerfacc import OccGridEstimator
+    g = golden("glue_ngp")
+    kw = scene_of(g)["kw"]
+    occ, aabbs = multilevel_of(g)
+    est = OccGridEstimator(torch.from_numpy(g["ml_roi"]), resolution=[50, 12, 50], levels=2)
+    est.binaries = torch.from_numpy(occ)
+    est = est.to(DEV).eval()
+    np.testing.assert_array_equal(est.aabbs.cpu().numpy(), aabbs)
+    lh = int(g["log2_hashmap_size"])
+    scene = dict(aabb=aabbs[-1].astype(np.float32), neurons=128, layers=2, C=29, log2_hashmap_size=lh,
+                 params=S.make_field_params(128, 2, 29, seed=int(g["param_seed"]), log2_hashmap_size=lh))
+    hip = H.hip_field(scene)
+    rgb, rgb_var, acc, depth, depth_var, sem, tot = RD.render_probablistic_image_with_occgrid_test(
+        1024, hip, est, RD.Rays(_cu(g["ml_rays_o"]), _cu(g["ml_rays_d"])), render_bkgd=_cu(g["bkgd"]), **kw)
+    assert abs(tot - int(g["ml_total"])) <= 3
+    for got, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (sem, "sem"), (rgb_var, "rgb_var"), (depth_var, "depth_var")):
+        _check(got.cpu().numpy(), g["ml_" + k], k, atol=2e-3 if k == "depth_var" else 1e-3, rtol=2e-3 if k == "depth_var" else (1e-3 if k == "depth" else 0.0))
 
 
 def test_pose_drivers_equal_reference_dataset_golden(golden):
