@@ -76,6 +76,8 @@ SIGNATURES = {
     "mnf_render_weight_from_density": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_run_bounds": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mnf_visible_samples": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "mnf_composite_train_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p]),

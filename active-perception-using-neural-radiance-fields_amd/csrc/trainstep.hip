@@ -367,6 +367,24 @@ int sample_stage(const SampleWs &w, const uint8_t *binaries, const uint32_t *bit
 
 using namespace mnf;
 
+extern "C" int mnf_visible_samples(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays, const float *t_starts, const float *t_ends,
+                                   const float *sigmas, float early_stop_eps, const float *alpha_thre_dev, int64_t *kept_cnts, const int64_t *kept_starts,
+                                   float *o_t_starts, float *o_t_ends, int64_t *o_ray_indices, mnf_stream_t stream) {
+    if (n_rays <= 0) return MNF_OK;
+    MNF_REQUIRE(chunk_starts && chunk_cnts && t_starts && t_ends && sigmas && alpha_thre_dev, "visible_samples: null pointer");
+    const int vgrid = n_rays < 65535 ? n_rays : 65535;
+    if (!o_t_starts) {
+        MNF_REQUIRE(kept_cnts, "visible_samples: the count pass needs kept_cnts");
+        hipLaunchKernelGGL(visibility_kernel<false>, dim3(vgrid), dim3(64), 0, as_stream(stream), n_rays, chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, early_stop_eps,
+                           alpha_thre_dev, kept_cnts, (const int64_t *)nullptr, (float *)nullptr, (float *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
+    } else {
+        MNF_REQUIRE(kept_starts && o_t_ends && o_ray_indices, "visible_samples: the write pass needs kept_starts and the three outputs");
+        hipLaunchKernelGGL(visibility_kernel<true>, dim3(vgrid), dim3(64), 0, as_stream(stream), n_rays, chunk_starts, chunk_cnts, t_starts, t_ends, sigmas, early_stop_eps,
+                           alpha_thre_dev, (int64_t *)nullptr, kept_starts, o_t_starts, o_t_ends, o_ray_indices, (int64_t *)nullptr);
+    }
+    return launch_status("visibility_kernel");
+}
+
 extern "C" int64_t mnf_train_step_workspace_bytes(mnf_field_t f, int32_t n_rays, int64_t max_marched, int64_t max_kept) {
     if (!f || n_rays <= 0 || max_marched <= 0 || max_kept <= 0) return -1;
     return carve_step(nullptr, f, n_rays, scratch_cap(n_rays), max_marched, max_kept).bytes;

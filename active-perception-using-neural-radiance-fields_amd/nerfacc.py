@@ -187,6 +187,27 @@ def exclusive_scan_counts(counts: Tensor, want_total: bool = False):
     return (starts, total) if want_total else starts
 
 
+@torch.no_grad()
+def _select_visible(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, packed_info: Tensor, early_stop_eps: float, alpha_thre_dev: Tensor):
+    """occ_grid.py:209-236 after the density pass: (ray_indices, t_starts, t_ends) of the samples with T >= early_stop_eps and alpha >= alpha_thre
+    (`mnf_visible_samples`: count pass, prefix sum, write pass)."""
+    lib, dev = L.load_library(), t_starts.device
+    starts, cnts = (L.contig(x, torch.int64) for x in packed_info.to(torch.int64).unbind(-1))
+    ts, te = L.contig(t_starts, torch.float32), L.contig(t_ends, torch.float32)
+    n_rays = starts.shape[0]
+    kept = torch.empty((n_rays,), device=dev, dtype=torch.int64)
+    L.launch(lib.mnf_visible_samples, L.ptr(starts), L.ptr(cnts), n_rays, L.ptr(ts), L.ptr(te), L.ptr(sigmas), early_stop_eps, L.ptr(alpha_thre_dev),
+             L.ptr(kept), None, None, None, None)
+    kept_starts, total_t = exclusive_scan_counts(kept, want_total=True)
+    total = int(total_t.item())
+    o_ts, o_te = torch.empty((total,), device=dev), torch.empty((total,), device=dev)
+    o_ray = torch.empty((total,), device=dev, dtype=torch.int64)
+    if total:
+        L.launch(lib.mnf_visible_samples, L.ptr(starts), L.ptr(cnts), n_rays, L.ptr(ts), L.ptr(te), L.ptr(sigmas), early_stop_eps, L.ptr(alpha_thre_dev),
+                 None, L.ptr(kept_starts), L.ptr(o_ts), L.ptr(o_te), L.ptr(o_ray))
+    return o_ray, o_ts, o_te
+
+
 def pack_info_grouped(ray_indices: Tensor, n_rays: int) -> Tensor:
     """`pack_info` for ray indices grouped by ray (every output of `traverse_grids` / `sampling`, masked or not): same
     [n_rays, 2] result, from run boundaries instead of one atomic per sample."""
@@ -520,6 +541,16 @@ class OccGridEstimator(torch.nn.Module):
             ray_indices = samples.ray_indices
             packed_info = samples.packed_info
         self.last_sampling = {"n_marched": int(t_starts.shape[0])}     # samples the density pre-pass sees (measurement only)
+        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None and t_starts.is_cuda and t_starts.shape[0] > 0:
+            # visibility test and the three mask selections on the device: two passes around one prefix sum, ONE host round trip (the survivor count)
+            # instead of occs.mean().item() plus one per boolean index.  Same T / alpha arithmetic as render_visibility_from_density.
+            thre = torch.clamp(self.occs.mean(), max=float(alpha_thre)).to(torch.float32).reshape(1)
+            if hasattr(sigma_fn, "ray_major") and early_stop_eps > 0.0:
+                sigmas = sigma_fn.ray_major(t_starts, t_ends, ray_indices, packed_info, early_stop_eps)
+            else:
+                sigmas = sigma_fn(t_starts, t_ends, ray_indices)
+            assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+            return _select_visible(t_starts, t_ends, L.contig(sigmas, torch.float32), packed_info, float(early_stop_eps), thre)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             alpha_thre = min(alpha_thre, self.occs.mean().item())
             if sigma_fn is not None:

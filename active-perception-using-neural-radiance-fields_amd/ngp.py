@@ -76,6 +76,33 @@ class _FieldFunction(torch.autograd.Function):
         return None, None, None, g_base, g_head, g_s
 
 
+class _FieldSamplesFunction(torch.autograd.Function):
+    """`_FieldFunction` for packed samples given as (ray, t_start, t_end): the closure of utils.py:122-137 (ray gathers, `origins + dirs * (t_starts + t_ends) / 2`)
+    happens inside the forward kernel (`mnf_field_forward_train_samples`), which also leaves the positions the backward's hash-table scatter reads."""
+
+    @staticmethod
+    def forward(ctx, module, rays_o, rays_d, ray_indices, t_starts, t_ends, p_base, p_head, p_sem):
+        lib = L.load_library()
+        h = module._ensure_handle()
+        n = t_starts.shape[0]
+        dev = t_starts.device
+        rgb = torch.empty(n, 3, device=dev); sigma = torch.empty(n, 1, device=dev)
+        sem = torch.empty(n, module.num_semantic_classes, device=dev)
+        pos = torch.empty(n, 3, device=dev)
+        nbytes = lib.mnf_field_train_workspace_bytes(h, n)
+        ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+        if n:
+            L.launch(lib.mnf_field_forward_train_samples, h, L.ptr(rays_o), L.ptr(rays_d), L.ptr(ray_indices), L.ptr(t_starts), L.ptr(t_ends), n,
+                     L.ptr(rgb), L.ptr(sigma), L.ptr(sem), L.ptr(pos), L.ptr(ws), nbytes)
+        ctx.module, ctx.ws, ctx.nbytes, ctx.n = module, ws, nbytes, n
+        ctx.save_for_backward(pos, rgb, sigma)
+        return rgb, sigma, sem
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_sigma, g_sem):
+        return (None, None, None, None, None, None) + _FieldFunction.backward(ctx, g_rgb, g_sigma, g_sem)[3:]
+
+
 class RaySigmaFn:
     """The `sigma_fn` closure of perception/models/utils.py:89-101 (`radiance_field.query_density(origins + dirs * t_mid)`) as
     an object: called like the closure it evaluates every sample; `OccGridEstimator.sampling` recognises it and asks for the
@@ -263,6 +290,14 @@ class NGPRadianceField(torch.nn.Module):
         sem = torch.empty(n, self.num_semantic_classes, device=pos.device, dtype=torch.float32)
         L.launch(L.load_library().mnf_field_forward, h, L.ptr(pos), L.ptr(dirs), n, L.ptr(rgb), L.ptr(sigma), L.ptr(sem))
         return rgb.view(*shp, 3), sigma.view(*shp, 1), sem.view(*shp, self.num_semantic_classes)
+
+    def forward_samples_grad(self, rays_o, rays_d, ray_indices, t_starts, t_ends):
+        """`forward(origins[ray_indices] + viewdirs[ray_indices] * (t_starts + t_ends)[:, None] / 2, viewdirs[ray_indices])` (utils.py:122-137) with the
+        gathers and the positions formed inside the kernel; differentiable w.r.t. the three parameter vectors -> (rgb [N,3], density [N,1], sem [N,C])."""
+        L.require_gpu(rays_o, rays_d, ray_indices, t_starts, t_ends)
+        o, d = L.contig(rays_o.detach(), torch.float32), L.contig(rays_d.detach(), torch.float32)
+        ri, ts, te = L.contig(ray_indices, torch.int64), L.contig(t_starts.detach(), torch.float32), L.contig(t_ends.detach(), torch.float32)
+        return _FieldSamplesFunction.apply(self, o, d, ri, ts, te, self.mlp_base.params, self.mlp_head.params, self.mlp_sem.params)
 
     @torch.no_grad()
     def forward_samples(self, rays_o, rays_d, ray_indices, t_starts, t_ends, density_only: bool = False):

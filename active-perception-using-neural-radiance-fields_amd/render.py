@@ -250,13 +250,17 @@ _CompositeTrain = NA._CompositeTrain     # csrc/composite_train.hip behind autog
 
 
 def sem_rendering(radiance_field, rays: Rays, t_starts, t_ends, ray_indices, n_rays, render_bkgd=None):
-    """utils.py:362-461 on packed samples.  With autograd enabled the field is evaluated through its differentiable
-    forward (positions formed as in the closure utils.py:122-137) and the compositing below is plain torch autograd,
-    as in the reference; otherwise the fused no-grad kernel forms the positions itself."""
+    """utils.py:362-461 on packed samples.  With autograd enabled the field is evaluated through its differentiable forward — the closure of
+    utils.py:122-137 inside the kernel (`forward_samples_grad`), or in torch for a field without it or for rays / distances that themselves want
+    gradients (none come back through the field, as in the reference) — and composited by `_CompositeTrain`; otherwise the fused no-grad kernel."""
     C = radiance_field.num_semantic_classes
     dev = t_starts.device
     differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in radiance_field.parameters())
-    if t_starts.shape[0] != 0 and differentiable:
+    if t_starts.shape[0] != 0 and differentiable and hasattr(radiance_field, "forward_samples_grad") and not (
+            rays.origins.requires_grad or rays.viewdirs.requires_grad or t_starts.requires_grad or t_ends.requires_grad):
+        rgbs, sigmas, sems = radiance_field.forward_samples_grad(rays.origins, rays.viewdirs, ray_indices, t_starts, t_ends)
+        sigmas = sigmas.squeeze(-1)
+    elif t_starts.shape[0] != 0 and differentiable:
         t_dirs = rays.viewdirs[ray_indices]
         positions = rays.origins[ray_indices] + t_dirs * (t_starts + t_ends)[:, None] / 2.0
         rgbs, sigmas, sems = radiance_field(positions, t_dirs)

@@ -104,6 +104,15 @@ int mnf_render_weight_from_density(const int64_t *chunk_starts, const int64_t *c
                                    const float *prefix_trans, int64_t n_samples,
                                    float *weights, float *trans, float *alphas, mnf_stream_t stream);
 
+/* The tail of `OccGridEstimator.sampling` (occ_grid.py:209-236): render_visibility_from_density (volrend.py:424-483: T >= early_stop_eps and
+ * alpha >= alpha_thre) and the three boolean-mask selections after it, on packed samples, in two passes around one prefix sum:
+ *   count pass (o_t_starts NULL): kept_cnts[r] = survivors of ray r;
+ *   write pass: kept_starts = exclusive scan of kept_cnts; survivors go to o_*[kept_starts[r] ...], grouped by ray in marching order.
+ * alpha_thre_dev: ONE float on the device — min(alpha_thre, occs.mean()) of occ_grid.py:211 without the host round trip. */
+int mnf_visible_samples(const int64_t *chunk_starts, const int64_t *chunk_cnts, int32_t n_rays, const float *t_starts, const float *t_ends,
+                        const float *sigmas, float early_stop_eps, const float *alpha_thre_dev, int64_t *kept_cnts, const int64_t *kept_starts,
+                        float *o_t_starts, float *o_t_ends, int64_t *o_ray_indices, mnf_stream_t stream);
+
 /* Run boundaries of ray indices that are grouped by ray (the marcher's output order): first[r] = index of the
  * first sample of ray r, last[r] = one past its last sample; both must be zero-filled by the caller, rays without
  * samples stay (0, 0).  cnts = last - first is `pack_info`'s second column (nerfacc/pack.py:10-38). */

@@ -136,6 +136,43 @@ def test_train_render_golden_through_compositing_with_recorded_jitter(golden):
     np.testing.assert_allclose(sems.grad.cpu().numpy()[::4], g["trt_g_sems_every4"], atol=1e-8, rtol=1e-4)
 
 
+def test_differentiable_render_forms_positions_in_the_kernel_like_the_closure():
+    """utils.py:122-137 inside `mnf_field_forward_train_samples` (what `sem_rendering` now calls under autograd) against the closure typed in torch
+    in front of `NGPRadianceField.forward`: same per-sample outputs, same rendered values, parameter gradients within the scatter's atomic order."""
+    from apnrf_amd import render as RD
+    sc = H.make_scene(log2_hashmap_size=15)
+    f, est = H.hip_field(sc).train(), H.hip_estimator(sc).train()
+    g = torch.Generator().manual_seed(5)
+    o = (torch.from_numpy(sc["aabb"][:3]) + (torch.rand(300, 3, generator=g) * 0.6 + 0.2) * torch.from_numpy(sc["aabb"][3:] - sc["aabb"][:3])).float().to(DEV)
+    d = torch.nn.functional.normalize(torch.randn(300, 3, generator=g), dim=-1).to(DEV)
+    ri, ts, te = est.sampling(o, d, sigma_fn=None, render_step_size=0.02, near_plane=0.05, stratified=False)
+    assert len(ri) > 1000
+    bk = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+
+    def closure_route():
+        t_dirs = d[ri]
+        positions = o[ri] + t_dirs * (ts + te)[:, None] / 2.0
+        return f(positions, t_dirs)
+
+    outs, grads = [], []
+    for route in (closure_route, lambda: f.forward_samples_grad(o, d, ri, ts, te)):
+        f.zero_grad()
+        rgbs, sig, sems = route()
+        (rgbs.sum() * 0.5 + sig.clamp(max=50).sum() * 0.01 + (sems * sems).sum() * 0.1).backward()
+        outs.append([t.detach().clone() for t in (rgbs, sig, sems)])
+        grads.append([p.grad.detach().clone() for p in (f.mlp_base.params, f.mlp_head.params, f.mlp_sem.params)])
+    for a, b, name in zip(outs[0], outs[1], ("rgb", "sigma", "sem")):
+        assert torch.equal(a, b), name
+    for a, b, name in zip(grads[0], grads[1], ("base", "head", "sem")):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-3, atol=2e-4 * float(a.abs().max()), err_msg=name)
+    # and sem_rendering takes that route by itself
+    f.zero_grad()
+    rgb, acc, dep, sem, extra = RD.sem_rendering(f, RD.Rays(o, d), ts, te, ri, len(o), bk)
+    assert torch.equal(extra["rgbs"].detach(), outs[0][0]) and torch.equal(extra["sigmas"].detach(), outs[0][1].squeeze(-1))
+    (rgb.sum() + dep.sum() + sem.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in (f.mlp_base.params, f.mlp_head.params, f.mlp_sem.params))
+
+
 # ------------------------------------------------------------------ NGP field: the fused renderers (a14-a17) and the scorer (a18)
 def _check(got, want, name, atol=1e-3, rtol=0.0):
     np.testing.assert_allclose(np.asarray(got), np.asarray(want), atol=atol, rtol=rtol, err_msg=name)
