@@ -71,6 +71,8 @@ struct FieldIO {
     int64_t n_cap;                           // mode 2: capacity of the column arrays (the device count is clamped to it)
     int32_t grid_limit;                      // mode 2: workgroups of this launch (0 = one per CU).  Render jobs that advance side by side share the chip:
                                              // each job's launch takes its share of the CUs, so the jobs' field kernels run BESIDE each other
+    uint32_t *tickets;                       // mode 2, optional: eight zeroed counters 64 bytes apart.  The waves then take their tiles in the order they get to
+                                             // them (one ticket per tile, range of XCD x first, then the next ranges) instead of a fixed stride
     const int64_t *n_dev64;                  // modes 0, 1, optional: the sample count lives on the device (`n` is then its upper
                                              // bound and sizes the launch): the train step never brings a count to the host
     // mode 3: packed samples walked ray by ray (ray_idx64 / t_starts / t_ends as mode 1) with early termination

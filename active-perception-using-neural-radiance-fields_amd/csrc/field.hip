@@ -129,6 +129,25 @@ __device__ __forceinline__ void group_range(int64_t n_groups, int64_t &g_first, 
     }
 }
 
+// Dynamic tile order (FieldIO::tickets, the render rounds): a wave takes the next tile of its XCD's eighth with one atomic per tile and, when that eighth is used up,
+// goes on with the following eighths.  Consecutive tickets are consecutive tiles, so an XCD still walks neighbouring rays together; what changes is that no wave
+// owns a fixed share: the workgroups of a launch that starts while another job's kernel drains (or whose tiles hit the caches less) no longer finish last.
+constexpr int kTicketStride = 16;            // counters 64 bytes apart
+__device__ __forceinline__ int ticket_tile(uint32_t t, int x, int64_t n_tiles) {
+    const int64_t lo = n_tiles * x / 8, hi = n_tiles * (x + 1) / 8;
+    return lo + (int64_t)t < hi ? (int)(lo + (int64_t)t) : -1;
+}
+__device__ __forceinline__ int ticket_take(uint32_t *tk, int &x, int &seen, int64_t n_tiles, int lane) {      // synchronous; -1 once all eight ranges are used up
+    while (seen < 8) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(tk + kTicketStride * x, 1u);
+        const int tile = ticket_tile(__builtin_amdgcn_readfirstlane(t), x, n_tiles);
+        if (tile >= 0) return tile;
+        x = (x + 1) & 7; ++seen;
+    }
+    return -1;
+}
+
 // ------------------------------------------------------------------ hash-grid encode as its own launch (diagnostic path)
 // MNF_FIELD_SPLIT=1 runs the multiresolution gather and the MLP chain as two launches, which separates their costs:
 // on the 800x800 workload the gather alone takes 64 % of the fused kernel's time and is insensitive to occupancy
@@ -282,7 +301,11 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     // at the zeros the entry point filled in, which leaves the visibility mask (volrend.py:424-483) unchanged.
     int64_t ray_start = 0, ray_cnt = 0, ray_base = 0;
     float ray_sdt = 0.0f;
-    for (int64_t grp = g_first; MODE == 3 || grp < g_end; grp += g_step) {
+    // (the render rounds only: on the train step's forward — uniform tiles, two per wave at the reference's batch size — the per-tile ticket cost 0.110 -> 0.129 ms)
+    const bool dyn = MODE == 2 && ENC == 0 && args.io.tickets != nullptr;
+    int dyn_x = blockIdx.x & 7, dyn_seen = 0, dyn_next = -1;
+    if (dyn) dyn_next = ticket_take(args.io.tickets, dyn_x, dyn_seen, n_tiles, lane);
+    for (int64_t grp = g_first; MODE == 3 || dyn || grp < g_end; grp += g_step) {
         // Everything the tile reads from the kernel arguments is re-read from the kernel-argument segment (scalar loads, scalar cache) where it is used: kept in SGPRs for
         // the whole launch these ~60 dwords pushed the kernel over the 102 SGPRs (spills to VGPR lanes: ~220 v_readlane with their wait states per tile, and to scratch).
         KArgs *lp = kp;
@@ -301,9 +324,12 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
             col = ray_start + ray_base + lane; n_eff = ray_start + ray_cnt; ray_base += kWaveSamples;
             tile = 0;
         } else {
-            if (tile >= n_tiles) break;
+            if (MODE == 2 && dyn) tile = dyn_next;
+            if (tile < 0 || tile >= n_tiles) break;
             col = tile * kWaveSamples + lane;
         }
+        uint32_t dyn_pf = 0;
+        if (MODE == 2 && dyn && lane == 0) dyn_pf = atomicAdd(la.io.tickets + kTicketStride * dyn_x, 1u);   // the ticket of the tile after this one: back long before the gathers are
         // ---- this lane's sample ----
         ColData cd = {-1, 64, 0, 0.f, 0.f};
         if (MODE == 2) {
@@ -412,6 +438,11 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
                     if (col - lane + row < n_eff) dst[piece] = v;
                 }
             }
+        }
+
+        if (MODE == 2 && dyn) {      // the next tile: the ticket asked for at the top of this one has arrived behind the tile's feature loads
+            dyn_next = ticket_tile(__builtin_amdgcn_readfirstlane(dyn_pf), dyn_x, n_tiles);
+            if (dyn_next < 0) { dyn_x = (dyn_x + 1) & 7; ++dyn_seen; dyn_next = ticket_take(la.io.tickets, dyn_x, dyn_seen, n_tiles, lane); }
         }
 
         // the mask-dump base of this tile

@@ -34,6 +34,7 @@ struct RenderWs {
     // global
     int32_t *n_cols, *any_active, *overflow;   // overflow: set if a round ever asked for more columns than col_cap (never, by construction)
     uint32_t *bitgrid;   // bit-packed copy of the occupancy grid (built once per call)
+    uint32_t *tickets;   // eight tile counters of the round's field launch (FieldIO::tickets), zeroed by round_prep_kernel
     // per column
     int32_t *col_ray;
     float *col_ts, *col_te;
@@ -84,6 +85,7 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     p = take(n_views * 4); if (ws) ws->iter_samples = (int32_t *)p;
     p = take(n_views * 4); if (ws) ws->active = (int32_t *)p;
     p = take(256); if (ws) { ws->n_cols = (int32_t *)p; ws->any_active = (int32_t *)p + 1; ws->overflow = (int32_t *)p + 2; }
+    p = take(512); if (ws) ws->tickets = (uint32_t *)p;
     p = take(kMaxGridWords * 4); if (ws) ws->bitgrid = (uint32_t *)p;
     p = take(col_cap * 4); if (ws) ws->col_ray = (int32_t *)p;
     p = take(col_cap * 4); if (ws) ws->col_ts = (float *)p;
@@ -149,6 +151,7 @@ __global__ void __launch_bounds__(256) round_prep_kernel(int32_t n_views, int32_
     if (any) atomicOr(&s_any, 1);
     __syncthreads();
     if (threadIdx.x == 0) { *ws.any_active = s_any; *ws.n_cols = 0; }
+    if (threadIdx.x < 8) ws.tickets[16 * threadIdx.x] = 0u;
 }
 
 struct RoundSink {
@@ -187,93 +190,86 @@ __global__ void __launch_bounds__(256) pack_grid_kernel(const uint8_t *__restric
 
 // utils.py:674-696: one traversal of <= n_samples steps per alive ray (over-allocated mode of grid.cu:364-404).
 // The occupancy grid is read from a bit-packed copy staged in LDS (<= 64 KB) once per workgroup.
+#ifndef MNF_MARCH_WAVES
+#define MNF_MARCH_WAVES 8      /* waves per SIMD the single-level LDS variant is compiled for: 8 = two 16-wave workgroups per compute unit (42 VGPRs, 69 KB of LDS each) */
+#endif
 template <bool LDS_GRID, bool MULTI>
-__global__ void __launch_bounds__(kMarchThreads) round_march_kernel(int64_t n_rays, int32_t rays_per_view,
+__global__ void __launch_bounds__(kMarchThreads, (LDS_GRID && !MULTI) ? MNF_MARCH_WAVES : 4) round_march_kernel(int64_t n_rays, int32_t rays_per_view,
                                                                     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                                     const uint8_t *__restrict__ binaries, I3 res, int n_words,
                                                                     float a0, float a1, float a2, float a3, float a4, float a5,
                                                                     float far_plane, float step_size, float cone_angle, RenderWs ws,
                                                                     const int32_t *__restrict__ view_order, int32_t blocks_per_view, LevelBoxes boxes) {
-    __shared__ int s_wave_tot[kMarchThreads / 64], s_wave_max[kMarchThreads / 64];
-    __shared__ int s_base, s_stride, s_total;
-    __shared__ uint32_t s_bits[LDS_GRID ? kMaxGridWords : 1];
+    __shared__ int s_wave_tot[kMarchThreads / 64];
+    __shared__ int s_base;
+    __shared__ int s_list[kMarchThreads];       // the workgroup's marching rays (index inside the view), in thread order
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[LDS_GRID ? kMaxGridWords : 1];
     // workgroup -> (view, slice of the view): a workgroup never mixes views, so all its marching rays share one budget.
     // thread -> ray inside the view: identity, or the caller's order (neighbouring rays into the same tile)
     const int v = (int)(blockIdx.x / blocks_per_view);
-    const int in_view = (int)(blockIdx.x - (int64_t)v * blocks_per_view) * kMarchThreads + (int)threadIdx.x;
-    const bool in_range = in_view < rays_per_view;
-    int64_t r = (int64_t)v * rays_per_view + (in_range ? (view_order ? view_order[in_view] : in_view) : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // The occupancy bits are requested first, 16 bytes per lane, so that they travel while the prologue (alive flags, scan,
-    // column reservation) runs; they go to LDS once the workgroup knows that it marches.  (Staged after the prologue in a
-    // one-word-per-lane loop, every iteration waited for its own load: ~10 serial round trips per workgroup, and with 2-3
-    // workgroups per CU a round's march cost 65 us however few rays were alive.)
-    constexpr int kStageVec = kMaxGridWords / 4 / kMarchThreads;
-    uint4 pre[kStageVec];
-    if (LDS_GRID) {
-#pragma unroll
-        for (int j = 0; j < kStageVec; ++j) {
-            const int q = (int)threadIdx.x + j * kMarchThreads;
-            if (4 * q + 3 < n_words) pre[j] = reinterpret_cast<const uint4 *>(ws.bitgrid)[q];
+    if (!ws.active[v]) return;                  // uniform: the view has no round to run
+    int rv = 0;
+    bool go = false;
+    {
+        const int in_view = (int)(blockIdx.x - (int64_t)v * blocks_per_view) * kMarchThreads + (int)threadIdx.x;
+        if (in_view < rays_per_view) {
+            rv = view_order ? view_order[in_view] : in_view;
+            go = ws.alive[(int64_t)v * rays_per_view + rv] != 0;
         }
     }
-    bool go = false;
-    int ns = 0;
-    if (in_range) {
-        go = ws.alive[r] && ws.active[v];
-        ns = go ? ws.n_samples[v] : 0;
-    }
-    // This ray's record, requested before the column reservation below (two barriers and an atomic round trip): it is there
-    // by the time the ray marches.
-    float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 1.f}, ray_near = 0.f, ray_tmin = 0.f, ray_tmax = 0.f;
-    bool ray_hit = false;
-    if (go) {
+    // The workgroup's marching rays are packed to the front of the workgroup (rank k among them, in thread order -> thread k): late in a render one ray in ten is
+    // still alive, and a wave with six busy lanes costs what a full one does.  Waves behind the last marching ray leave.
+    const int incl = wave_inclusive_scan(go ? 1 : 0, lane);
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    int s_total = 0, before = 0;      // every thread adds the sixteen wave totals up itself (broadcast reads)
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { ro[d] = rays_o[3 * r + d]; rd[d] = rays_d[3 * r + d]; }
-        ray_near = ws.near_plane[r]; ray_hit = ws.hit[r]; ray_tmin = ws.t_min[r]; ray_tmax = ws.t_max[r];
+    for (int w = 0; w < kMarchThreads / 64; ++w) {
+        const int t = s_wave_tot[w];
+        before += w < wave ? t : 0;
+        s_total += t;
     }
-    // Column allocation.  All marching rays of the workgroup get `stride` = the largest per-ray budget in the
-    // workgroup (budgets are per view, so almost always uniform); a 64-column tile holds cap = 64/stride rays, so no
+    if (s_total == 0) return;   // uniform: no ray of this workgroup marches this round — and nothing of the occupancy grid was touched
+    if (go) s_list[incl - 1 + before] = rv;
+    // Column allocation.  All marching rays of the workgroup get `stride` = the view's budget of this round; a 64-column tile holds cap = 64/stride rays, so no
     // ray straddles a tile and the field kernel can composite a ray inside one wave.  Ray with rank k among the
     // workgroup's marching rays -> tile k / cap, columns (k % cap) * stride ...
-    int wmax = ns;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
-    const int incl = wave_inclusive_scan(go ? 1 : 0, lane);
-    if (lane == 63) { s_wave_tot[wave] = incl; s_wave_max[wave] = wmax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0, smax = 0;
-        for (int w = 0; w < kMarchThreads / 64; ++w) { tot += s_wave_tot[w]; smax = max(smax, s_wave_max[w]); }
-        s_stride = smax;
-        if (tot) {
-            const int cap = 64 / smax;
-            const int need = ((tot + cap - 1) / cap) * 64;
-            s_base = atomicAdd(ws.n_cols, need);
-            if ((int64_t)s_base + need > ws.col_cap) {   // cannot happen with one view per workgroup (carve()); never write past the workspace
-                atomicExch(ws.overflow, 1);
-                s_base = -1;
-            }
-        } else {
-            s_base = -1;
-        }
-        s_total = tot;
-    }
-    __syncthreads();
-    if (s_base < 0) return;   // uniform: no ray of this workgroup marches this round (or the workspace guard fired)
+    const int stride = ws.n_samples[v];
     if (LDS_GRID) {
+        // The occupancy bits go from L2 straight into LDS (global_load_lds, 16 bytes per lane, no registers in between) while thread 0 reserves the columns.  Through
+        // registers the 64 KB were 64 VGPRs per thread, requested by workgroups that march nothing as well.
+        constexpr int kStageVec = kMaxGridWords / 4 / kMarchThreads;
 #pragma unroll
         for (int j = 0; j < kStageVec; ++j) {
             const int q = (int)threadIdx.x + j * kMarchThreads;
-            if (4 * q + 3 < n_words) reinterpret_cast<uint4 *>(s_bits)[q] = pre[j];
+            if (4 * q + 3 < n_words)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(ws.bitgrid) + q,
+                                                 (__attribute__((address_space(3))) uint32_t *)(s_bits) + 4 * (j * kMarchThreads + wave * 64), 16, 0, 0);
         }
         for (int i = (n_words & ~3) + (int)threadIdx.x; i < n_words; i += kMarchThreads) s_bits[i] = ws.bitgrid[i];
-        __syncthreads();
     }
-    if (!go) return;
-    const int stride = s_stride, cap = 64 / stride;
-    int k = incl - 1;
-    for (int w = 0; w < wave; ++w) k += s_wave_tot[w];
+    if (threadIdx.x == 0) {
+        const int cap = 64 / stride;
+        const int need = ((s_total + cap - 1) / cap) * 64;
+        int base = atomicAdd(ws.n_cols, need);
+        if ((int64_t)base + need > ws.col_cap) {   // cannot happen with one view per workgroup (carve()); never write past the workspace
+            atomicExch(ws.overflow, 1);
+            base = -1;
+        }
+        s_base = base;
+    }
+    __syncthreads();            // (waits for the staged bits as well: hipcc drains vmcnt in front of the barrier)
+    if (s_base < 0) return;     // uniform: the workspace guard fired
+    const int k = (int)threadIdx.x;
+    if (k >= s_total) return;
+    const int64_t r = (int64_t)v * rays_per_view + s_list[k];
+    const int ns = stride, cap = 64 / stride;
+    float ro[3], rd[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { ro[d] = rays_o[3 * r + d]; rd[d] = rays_d[3 * r + d]; }
+    const float ray_near = ws.near_plane[r], ray_tmin = ws.t_min[r], ray_tmax = ws.t_max[r];
+    const bool ray_hit = ws.hit[r];
     const int tile_local = k / cap, slot = k - tile_local * cap;
     const int col0 = s_base + tile_local * 64 + slot * stride;
     if (slot == 0) {   // the first ray of a tile also describes the tile and blanks the columns no ray owns
@@ -531,6 +527,9 @@ int job_begin(RenderJob &j, mnf_field_t f, const uint8_t *binaries, int32_t res_
     FieldIO io = {};
     io.mode = 2; io.rays_o = rays_o; io.rays_d = rays_d; io.col_ray = j.ws.col_ray; io.t_starts = j.ws.col_ts; io.t_ends = j.ws.col_te;
     io.n_dev = j.ws.n_cols; io.n_cap = j.ws.col_cap;
+#ifndef MNF_STATIC_TILES
+    io.tickets = j.ws.tickets;      // tiles in arrival order (field.hip, ticket_take); -DMNF_STATIC_TILES: the fixed stride of rounds 1-4, for A/B
+#endif
     io.enc = split_field() ? j.ws.enc : nullptr;   // MNF_FIELD_SPLIT (diagnostic: gather and MLP as two launches on one stream)
     io.fr.tile_hdr = j.ws.tile_hdr; io.fr.alive = j.ws.alive; io.fr.alive_count = j.ws.alive_count;
     io.fr.n_samples = j.ws.n_samples; io.fr.rgb = rgb; io.fr.acc = acc; io.fr.depth = depth; io.fr.sem = sem;
