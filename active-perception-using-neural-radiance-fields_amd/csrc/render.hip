@@ -30,11 +30,12 @@ struct RenderWs {
     int32_t *col0, *cnt;
     uint8_t *alive, *hit;
     // per view
-    int32_t *alive_count, *n_samples, *iter_samples, *active;
+    int32_t *alive_count, *n_samples, *iter_samples, *active;   // alive_count, iter_samples: two copies [2][views], read at the round's parity, written at the other
+                                                                // (round k's marcher resets the copy that round k's compositing counts into)
     // global
-    int32_t *n_cols, *any_active, *overflow;   // overflow: set if a round ever asked for more columns than col_cap (never, by construction)
+    int32_t *n_cols, *any_active, *overflow;   // n_cols[2], any_active[2] by round parity; overflow: set if a round ever asked for more columns than col_cap (never, by construction)
     uint32_t *bitgrid;   // bit-packed copy of the occupancy grid (built once per call)
-    uint32_t *tickets;   // eight tile counters of the round's field launch (FieldIO::tickets), zeroed by round_prep_kernel
+    uint32_t *tickets;   // eight tile counters of the round's field launch (FieldIO::tickets), zeroed by the round's marcher
     // per column
     int32_t *col_ray;
     float *col_ts, *col_te;
@@ -80,11 +81,11 @@ static int64_t carve(RenderWs *ws, char *base, int64_t n_rays, int32_t rays_per_
     p = take(n_rays * 4); if (ws) ws->cnt = (int32_t *)p;
     p = take(n_rays); if (ws) ws->alive = (uint8_t *)p;
     p = take(n_rays); if (ws) ws->hit = (uint8_t *)p;
-    p = take(n_views * 4); if (ws) ws->alive_count = (int32_t *)p;
+    p = take(2 * n_views * 4); if (ws) ws->alive_count = (int32_t *)p;
     p = take(n_views * 4); if (ws) ws->n_samples = (int32_t *)p;
-    p = take(n_views * 4); if (ws) ws->iter_samples = (int32_t *)p;
+    p = take(2 * n_views * 4); if (ws) ws->iter_samples = (int32_t *)p;
     p = take(n_views * 4); if (ws) ws->active = (int32_t *)p;
-    p = take(256); if (ws) { ws->n_cols = (int32_t *)p; ws->any_active = (int32_t *)p + 1; ws->overflow = (int32_t *)p + 2; }
+    p = take(256); if (ws) { ws->n_cols = (int32_t *)p; ws->any_active = (int32_t *)p + 2; ws->overflow = (int32_t *)p + 4; }   // n_cols[2] | any_active[2] | overflow
     p = take(512); if (ws) ws->tickets = (uint32_t *)p;
     p = take(kMaxGridWords * 4); if (ws) ws->bitgrid = (uint32_t *)p;
     p = take(col_cap * 4); if (ws) ws->col_ray = (int32_t *)p;
@@ -109,8 +110,8 @@ __global__ void __launch_bounds__(kRayThreads) init_kernel(int64_t n_rays, int32
                                                            float a0, float a1, float a2, float a3, float a4, float a5,
                                                            float near_plane, RenderWs ws, RenderOut out) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r == 0) { out.total_samples[0] = 0; out.total_samples[1] = 0; *ws.overflow = 0; }
-    if (r < n_rays / rays_per_view) { ws.alive_count[r] = rays_per_view; ws.iter_samples[r] = 0; }
+    if (r == 0) { out.total_samples[0] = 0; out.total_samples[1] = 0; *ws.overflow = 0; ws.n_cols[0] = 0; ws.n_cols[1] = 0; ws.any_active[0] = 0; ws.any_active[1] = 0; }
+    if (r < n_rays / rays_per_view) { ws.alive_count[r] = rays_per_view; ws.iter_samples[r] = 0; }      // round 0 reads the copies of parity 0
     if (r >= n_rays) return;
     const float ab[6] = {a0, a1, a2, a3, a4, a5};
     const F3 o = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
@@ -126,32 +127,6 @@ __global__ void __launch_bounds__(kRayThreads) init_kernel(int64_t n_rays, int32
     out.acc[r] = 0.f; out.depth[r] = 0.f;
     if (out.rgb_var) { out.rgb_var[3 * r] = 0.f; out.rgb_var[3 * r + 1] = 0.f; out.rgb_var[3 * r + 2] = 0.f; }
     if (out.depth_var) out.depth_var[r] = 0.f;
-}
-
-// utils.py:666-672 per view: n_alive -> n_samples, iter_samples; also resets the round's counters
-__global__ void __launch_bounds__(256) round_prep_kernel(int32_t n_views, int32_t rays_per_view, int32_t max_samples,
-                                                         int32_t min_samples, RenderWs ws) {
-    __shared__ int s_any;
-    if (threadIdx.x == 0) s_any = 0;
-    __syncthreads();
-    int any = 0;
-    for (int v = threadIdx.x; v < n_views; v += blockDim.x) {
-        const int n_alive = ws.alive_count[v];
-        int act = 0;
-        if (ws.iter_samples[v] < max_samples && n_alive > 0) {
-            const int ns = max(min(rays_per_view / n_alive, 64), min_samples);
-            ws.n_samples[v] = ns;
-            ws.iter_samples[v] += ns;
-            act = 1;
-        }
-        ws.active[v] = act;
-        ws.alive_count[v] = 0;   // re-counted by the fused compositing epilogue; rays of inactive views are never marched again
-        any |= act;
-    }
-    if (any) atomicOr(&s_any, 1);
-    __syncthreads();
-    if (threadIdx.x == 0) { *ws.any_active = s_any; *ws.n_cols = 0; }
-    if (threadIdx.x < 8) ws.tickets[16 * threadIdx.x] = 0u;
 }
 
 struct RoundSink {
@@ -199,7 +174,8 @@ __global__ void __launch_bounds__(kMarchThreads, (LDS_GRID && !MULTI) ? MNF_MARC
                                                                     const uint8_t *__restrict__ binaries, I3 res, int n_words,
                                                                     float a0, float a1, float a2, float a3, float a4, float a5,
                                                                     float far_plane, float step_size, float cone_angle, RenderWs ws,
-                                                                    const int32_t *__restrict__ view_order, int32_t blocks_per_view, LevelBoxes boxes) {
+                                                                    const int32_t *__restrict__ view_order, int32_t blocks_per_view, LevelBoxes boxes,
+                                                                    int32_t n_views, int32_t parity, int32_t max_samples, int32_t min_samples) {
     __shared__ int s_wave_tot[kMarchThreads / 64];
     __shared__ int s_base;
     __shared__ int s_list[kMarchThreads];       // the workgroup's marching rays (index inside the view), in thread order
@@ -208,7 +184,24 @@ __global__ void __launch_bounds__(kMarchThreads, (LDS_GRID && !MULTI) ? MNF_MARC
     // thread -> ray inside the view: identity, or the caller's order (neighbouring rays into the same tile)
     const int v = (int)(blockIdx.x / blocks_per_view);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (!ws.active[v]) return;                  // uniform: the view has no round to run
+    // The round's budget of this view (utils.py:666-672: n_alive -> n_samples, until max_samples are spent), worked out by every workgroup of the view from the same two
+    // words — what a one-workgroup launch in front of every marcher did until round 5 (5 us of kernel, more of queue).  The per-view words the round changes have two copies:
+    // this round reads the copy of its parity; the view's first workgroup writes the other (samples spent so far; zero survivors, which this round's compositing counts up).
+    const int n_alive = ws.alive_count[parity * n_views + v], spent = ws.iter_samples[parity * n_views + v];
+    const bool act = spent < max_samples && n_alive > 0;
+    const int stride = act ? max(min(rays_per_view / n_alive, 64), min_samples) : 0;
+    if (threadIdx.x == 0 && blockIdx.x == (unsigned)v * blocks_per_view) {
+        if (act) { ws.n_samples[v] = stride; ws.any_active[parity] = 1; }
+        ws.active[v] = act ? 1 : 0;
+        ws.iter_samples[(parity ^ 1) * n_views + v] = spent + stride;
+        ws.alive_count[(parity ^ 1) * n_views + v] = 0;        // rays of inactive views are never marched again
+    }
+    if (blockIdx.x == 0) {      // the next round's column counter and flag, this round's tile tickets
+        if (threadIdx.x < 8) ws.tickets[16 * threadIdx.x] = 0u;
+        if (threadIdx.x == 8) ws.n_cols[parity ^ 1] = 0;
+        if (threadIdx.x == 9) ws.any_active[parity ^ 1] = 0;
+    }
+    if (!act) return;                           // uniform: the view has no round to run
     int rv = 0;
     bool go = false;
     {
@@ -235,7 +228,6 @@ __global__ void __launch_bounds__(kMarchThreads, (LDS_GRID && !MULTI) ? MNF_MARC
     // Column allocation.  All marching rays of the workgroup get `stride` = the view's budget of this round; a 64-column tile holds cap = 64/stride rays, so no
     // ray straddles a tile and the field kernel can composite a ray inside one wave.  Ray with rank k among the
     // workgroup's marching rays -> tile k / cap, columns (k % cap) * stride ...
-    const int stride = ws.n_samples[v];
     if (LDS_GRID) {
         // The occupancy bits go from L2 straight into LDS (global_load_lds, 16 bytes per lane, no registers in between) while thread 0 reserves the columns.  Through
         // registers the 64 KB were 64 VGPRs per thread, requested by workgroups that march nothing as well.
@@ -252,7 +244,7 @@ __global__ void __launch_bounds__(kMarchThreads, (LDS_GRID && !MULTI) ? MNF_MARC
     if (threadIdx.x == 0) {
         const int cap = 64 / stride;
         const int need = ((s_total + cap - 1) / cap) * 64;
-        int base = atomicAdd(ws.n_cols, need);
+        int base = atomicAdd(ws.n_cols + parity, need);
         if ((int64_t)base + need > ws.col_cap) {   // cannot happen with one view per workgroup (carve()); never write past the workspace
             atomicExch(ws.overflow, 1);
             base = -1;
@@ -471,6 +463,7 @@ struct RenderJob {
     LevelBoxes boxes;
     int n_words, max_rounds, round;
     bool lds_grid, done, flags_pending;
+    int flags_parity;
     int32_t n_views, bpv, min_samples, C;
 };
 
@@ -541,7 +534,7 @@ int job_begin(RenderJob &j, mnf_field_t f, const uint8_t *binaries, int32_t res_
     j.io = io;
     j.max_rounds = (int)ceil_div(opts->max_samples, j.min_samples);
     j.bpv = (int32_t)march_blocks_per_view(opts->rays_per_view);
-    j.round = 0; j.done = false; j.flags_pending = false;
+    j.round = 0; j.done = false; j.flags_pending = false; j.flags_parity = 0;
     return MNF_OK;
 }
 
@@ -554,21 +547,23 @@ int job_enqueue_block(RenderJob &j, int block) {
     const int last = j.round + block < j.max_rounds ? j.round + block : j.max_rounds;
     for (int k = 0; j.round < last; ++j.round, ++k) {
         const int round = j.round;
-        hipLaunchKernelGGL(round_prep_kernel, dim3(1), dim3(256), 0, s, j.n_views, opts->rays_per_view, opts->max_samples, j.min_samples, j.ws);
-        if (k == 0 && round > 0) {
-            // the prep just enqueued decided whether any view still has a round to run: any_active, overflow (adjacent words)
-            MNF_HIP(hipMemcpyAsync(j.res->flags, j.ws.any_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            MNF_HIP(hipEventRecord(j.res->ev_flags, s));
-            j.flags_pending = true;
-        }
+        const int parity = round & 1;
         if (round_log()) MNF_HIP(hipEventRecord(log_events()[2], s));
 #define MNF_MARCH(LDS, ML) hipLaunchKernelGGL((round_march_kernel<LDS, ML>), dim3(march_grid), dim3(kMarchThreads), 0, s, j.n_rays, opts->rays_per_view, j.rays_o, \
                                              j.rays_d, j.binaries, j.grid, j.n_words, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], opts->far_plane,                  \
-                                             opts->render_step_size, opts->cone_angle, j.ws, opts->view_order, j.bpv, j.boxes)
+                                             opts->render_step_size, opts->cone_angle, j.ws, opts->view_order, j.bpv, j.boxes, j.n_views, parity, opts->max_samples, j.min_samples)
         if (j.boxes.n > 1) { if (j.lds_grid) MNF_MARCH(true, true); else MNF_MARCH(false, true); }
         else { if (j.lds_grid) MNF_MARCH(true, false); else MNF_MARCH(false, false); }
 #undef MNF_MARCH
+        if (k == 0 && round > 0) {
+            // the marcher just enqueued decided whether any view still has a round to run: any_active[2], overflow (adjacent words)
+            MNF_HIP(hipMemcpyAsync(j.res->flags, j.ws.any_active, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipEventRecord(j.res->ev_flags, s));
+            j.flags_pending = true; j.flags_parity = parity;
+        }
         if (round_log()) MNF_HIP(hipEventRecord(log_events()[3], s));
+        j.io.n_dev = j.ws.n_cols + parity;
+        j.io.fr.alive_count = j.ws.alive_count + (parity ^ 1) * j.n_views;
         int rc;
         {
             ProfScope ps("field_render", s);
@@ -581,11 +576,11 @@ int job_enqueue_block(RenderJob &j, int block) {
             const int n_views = j.n_views;
             int32_t n_cols = 0, ns[8] = {0}, act[8] = {0};
             std::vector<int32_t> act_all(n_views), alive_all(n_views);
-            MNF_HIP(hipMemcpyAsync(&n_cols, j.ws.n_cols, 4, hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(&n_cols, j.ws.n_cols + parity, 4, hipMemcpyDeviceToHost, s));
             MNF_HIP(hipMemcpyAsync(ns, j.ws.n_samples, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
             MNF_HIP(hipMemcpyAsync(act, j.ws.active, 4 * (n_views < 8 ? n_views : 8), hipMemcpyDeviceToHost, s));
             MNF_HIP(hipMemcpyAsync(act_all.data(), j.ws.active, 4 * (size_t)n_views, hipMemcpyDeviceToHost, s));
-            MNF_HIP(hipMemcpyAsync(alive_all.data(), j.ws.alive_count, 4 * (size_t)n_views, hipMemcpyDeviceToHost, s));
+            MNF_HIP(hipMemcpyAsync(alive_all.data(), j.ws.alive_count + (parity ^ 1) * n_views, 4 * (size_t)n_views, hipMemcpyDeviceToHost, s));
             MNF_HIP(hipStreamSynchronize(s));
             int n_act = 0; long long n_alive_after = 0;
             for (int v = 0; v < n_views; ++v) { n_act += act_all[v] != 0; n_alive_after += alive_all[v]; }
@@ -605,11 +600,11 @@ int job_check(RenderJob &j) {
     if (j.flags_pending) {
         MNF_HIP(hipEventSynchronize(j.res->ev_flags));
         j.flags_pending = false;
-        if (j.res->flags[1]) {
+        if (j.res->flags[2]) {
             set_error("render_test: a round needed more sample columns than the workspace holds");
             return MNF_ERR_WORKSPACE;
         }
-        if (!j.res->flags[0]) j.done = true;        // the rounds of this block find nothing to do
+        if (!j.res->flags[j.flags_parity]) j.done = true;        // the rounds of this block find nothing to do
     }
     if (j.round >= j.max_rounds) j.done = true;
     return MNF_OK;

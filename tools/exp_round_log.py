@@ -16,6 +16,16 @@ from apnrf_amd import standin as SI
 
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dev = "cuda:0"
+if len(sys.argv) > 2 and sys.argv[2] == "score":      # one render job of a scoring pass: V views of 64 x 64 sub-sampled rays (BASELINE config 4's scene), probabilistic
+    scene = SC.make_scene("102344250", n_poses=40)
+    field, est, _ = SI.train_standin(scene, dev, seed=9)
+    field.eval(); est.eval()
+    poses = SI._free_space_poses(scene, 256, seed=9)[:V]
+    o, d, h, w = RD._pose_rays(poses, 640, 640, 320.0, 0.1, dev)
+    outs = RD._render_jobs([(field, est, o, d)], h * w, 1024, 0.1, 1e10, 1e-3, torch.zeros(3), 0.004, 0.01, 1e-4, True, 8, None, 1)
+    torch.cuda.synchronize()
+    print(f"[exp_round_log] score job, {V} views of {h * w} rays: {float(outs[0]['total'][1]) / (V * h * w):.2f} evaluated samples per ray", flush=True)
+    sys.exit(0)
 scene = SC.make_scene("102344529", n_poses=40)
 field, est, info = SI.shared_standin(scene, dev, steps=2000, seed=9, keep_optimizer=False, group=False)
 field.eval(); est.eval()

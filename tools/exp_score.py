@@ -1,6 +1,6 @@
 """Scoring-pass timing (GPU box): BASELINE config 4 (256 candidate views x 4096 rays x 2 members) and its shard-of-8 share
 (32 views), through `render.score_views` and through the single C call `render.score_poses`.
-    python tools/exp_score.py [n_views,...] [passes]"""
+    python tools/exp_score.py [n_views,...] [passes] [groups of views per member (A/B of render._render_jobs' n_split; score_views only)]"""
 import os
 import sys
 import time
@@ -16,6 +16,9 @@ from apnrf_amd import standin as SI
 
 views = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [256, 32]
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+if len(sys.argv) > 3:
+    _jobs, _n = RD._render_jobs, int(sys.argv[3])
+    RD._render_jobs = lambda *a, **k: _jobs(*a[:13], _n) if len(a) > 13 else _jobs(*a, **dict(k, n_split=_n))
 dev = "cuda:0"
 scene = SC.make_scene("102344250", n_poses=40)
 f0, e0, _ = SI.train_standin(scene, dev, seed=9)
