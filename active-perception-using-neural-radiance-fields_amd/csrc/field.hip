@@ -302,7 +302,13 @@ __global__ void __launch_bounds__(kThreads, 2) field_kernel(const KernelArgs arg
     int64_t ray_start = 0, ray_cnt = 0, ray_base = 0;
     float ray_sdt = 0.0f;
     // (the render rounds only: on the train step's forward — uniform tiles, two per wave at the reference's batch size — the per-tile ticket cost 0.110 -> 0.129 ms)
-    const bool dyn = MODE == 2 && ENC == 0 && args.io.tickets != nullptr;
+#ifndef MNF_TICKET_MIN_TILES
+#define MNF_TICKET_MIN_TILES 16384
+#endif
+    // launches of fewer than eight tiles per wave keep the fixed stride: little to balance, and every wave's eight refused tickets at the end of a launch (one atomic
+    // per range, the same eight addresses for all waves) weigh more the shorter the launch is.  Measured (256-view scoring pass / 32 views / 800x800 x4 / one 800x800 view):
+    // always tickets 99.8 / 22.4 / 64.7 / 19.7 ms; from 4096 tiles 98.2 / 21.3 / 64.6 / 19.7; from 16384 96.4 / 21.4 / 64.0 / 19.3; from 32768 99.0 / 21.3 / 63.4 / 19.6; from 65536 99.4 / 21.4 / 64.9 / 19.8
+    const bool dyn = MODE == 2 && ENC == 0 && args.io.tickets != nullptr && n_tiles >= MNF_TICKET_MIN_TILES;
     int dyn_x = blockIdx.x & 7, dyn_seen = 0, dyn_next = -1;
     if (dyn) dyn_next = ticket_take(args.io.tickets, dyn_x, dyn_seen, n_tiles, lane);
     for (int64_t grp = g_first; MODE == 3 || dyn || grp < g_end; grp += g_step) {

@@ -11,7 +11,6 @@ stats() {   # stats <tag> <bench args...>: rocprofv3 kernel stats of one workloa
   tag=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -- python3 bench.py "$@" --no-cpu-baseline --no-kernel-timing > $out/bench_${tag}_under_rocprof.json 2> $out/rocprof_$tag.err
   find $out/prof_$tag -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
-  find $out/prof_$tag -name "*kernel_trace.csv" -exec cp {} $out/${tag}_kernel_trace.csv \;
   rm -rf $out/prof_$tag
 }
 if has prof; then
