@@ -521,7 +521,9 @@ int job_begin(RenderJob &j, mnf_field_t f, const uint8_t *binaries, int32_t res_
     io.mode = 2; io.rays_o = rays_o; io.rays_d = rays_d; io.col_ray = j.ws.col_ray; io.t_starts = j.ws.col_ts; io.t_ends = j.ws.col_te;
     io.n_dev = j.ws.n_cols; io.n_cap = j.ws.col_cap;
 #ifndef MNF_STATIC_TILES
-    io.tickets = j.ws.tickets;      // tiles in arrival order (field.hip, ticket_take); -DMNF_STATIC_TILES: the fixed stride of rounds 1-4, for A/B
+    // tiles in arrival order (field.hip, ticket_take).  -DMNF_STATIC_TILES, or MNF_FIELD_STATIC_TILES in the diagnostic library: the fixed stride of rounds 1-4
+    // (A/B builds; tests/diag_tile_order.py: the two orders render the same bits)
+    if (!diag_env("MNF_FIELD_STATIC_TILES")) io.tickets = j.ws.tickets;
 #endif
     io.enc = split_field() ? j.ws.enc : nullptr;   // MNF_FIELD_SPLIT (diagnostic: gather and MLP as two launches on one stream)
     io.fr.tile_hdr = j.ws.tile_hdr; io.fr.alive = j.ws.alive; io.fr.alive_count = j.ws.alive_count;

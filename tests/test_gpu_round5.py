@@ -300,6 +300,17 @@ def test_batched_small_views_are_repeatable_and_batch_independent():
 
 
 # ------------------------------------------------------------------ multi-GPU paths with real processes on the one GPU a test box has
+def test_ticket_tile_order_renders_the_same_bits():
+    """The field kernel of a large render round takes its tiles in arrival order (tickets, csrc/field.hip).  The order must not change a bit of the result: child
+    process on the diagnostic library (tests/diag_tile_order.py), the same view with tickets twice and with the fixed stride."""
+    import subprocess
+    from apnrf_amd import build as B
+    here = os.path.dirname(os.path.abspath(__file__))
+    assert os.path.exists(B.LIB_DIAG), "libmi355nerf_diag.so missing: run `python __graft_entry__.py build`"
+    r = subprocess.run([sys.executable, os.path.join(here, "diag_tile_order.py")], env=dict(os.environ, MNF_LIB_PATH=B.LIB_DIAG), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIAG_TILE_ORDER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
