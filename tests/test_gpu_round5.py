@@ -136,6 +136,32 @@ def test_train_render_golden_through_compositing_with_recorded_jitter(golden):
     np.testing.assert_allclose(sems.grad.cpu().numpy()[::4], g["trt_g_sems_every4"], atol=1e-8, rtol=1e-4)
 
 
+def test_device_side_visibility_selection_equals_mask_indexing():
+    """`sampling()`'s tail on the device (`mnf_visible_samples`: count pass, prefix sum, write pass) against the reference's own sequence — `render_visibility_from_density`
+    (volrend.py:424-483) and three boolean-mask selections (occ_grid.py:229-236) — on ragged packed samples: empty rays, a ray longer than a wave, every threshold
+    combination `sampling` can be called with, nothing visible at all, no rays."""
+    from apnrf_amd import nerfacc as NA
+    g = torch.Generator().manual_seed(3)
+    cnts = torch.tensor([0, 5, 64, 65, 0, 200, 1, 33, 0], dtype=torch.int64)
+    starts = torch.cumsum(cnts, 0) - cnts
+    packed = torch.stack([starts, cnts], -1).to(DEV)
+    n = int(cnts.sum())
+    ts = torch.rand(n, generator=g).to(DEV)
+    te = ts + 0.01 + 0.05 * torch.rand(n, generator=g).to(DEV)
+    ri = torch.repeat_interleave(torch.arange(len(cnts)), cnts).to(DEV)
+    for scale, eps, thre in ((40.0, 1e-4, 0.01), (40.0, 0.0, 0.05), (40.0, 1e-2, 0.0), (0.0, 1e-4, 0.01), (400.0, 0.5, 0.0)):
+        sig = (torch.rand(n, generator=g) * scale).to(DEV)
+        mask = NA.render_visibility_from_density(ts, te, sig, packed_info=packed, early_stop_eps=eps, alpha_thre=thre)
+        got = NA._select_visible(ts, te, sig, packed, eps, torch.tensor([thre], device=DEV))
+        for a, b, name in zip(got, (ri[mask], ts[mask], te[mask]), ("ray_indices", "t_starts", "t_ends")):
+            assert a.dtype == b.dtype and torch.equal(a, b), (scale, eps, thre, name)
+        if scale == 0.0:
+            assert got[0].numel() == 0
+    e = torch.empty(0, device=DEV)
+    got = NA._select_visible(e, e, e, torch.zeros((0, 2), dtype=torch.int64, device=DEV), 1e-4, torch.tensor([0.01], device=DEV))
+    assert all(t.numel() == 0 for t in got)
+
+
 def test_differentiable_render_forms_positions_in_the_kernel_like_the_closure():
     """utils.py:122-137 inside `mnf_field_forward_train_samples` (what `sem_rendering` now calls under autograd) against the closure typed in torch
     in front of `NGPRadianceField.forward`: same per-sample outputs, same rendered values, parameter gradients within the scatter's atomic order."""
