@@ -324,10 +324,11 @@ __device__ __forceinline__ double block_sum(double v, double *s_buf) {
     return t;
 }
 
-__global__ void __launch_bounds__(256) score_kernel(const float *__restrict__ rgb_var, const float *__restrict__ depth_var,
+constexpr int kScoreThreads = 1024;      // 16 waves per view: the 4096 pixels of a view are ~220 double-precision exp / log each; four waves per view left three of four issue slots to their latencies (1.07 ms per 256 views)
+__global__ void __launch_bounds__(kScoreThreads) score_kernel(const float *__restrict__ rgb_var, const float *__restrict__ depth_var,
                                                     const float *__restrict__ acc, const float *__restrict__ sem,
                                                     int M, int V, int P, int C, double *__restrict__ terms) {
-    __shared__ double s_buf[4];
+    __shared__ double s_buf[kScoreThreads / 64];
     const int v = blockIdx.x;
     const double k2pie = 2.0 * 3.14159265358979323846 * 2.71828182845904523536;
     double s_rgb = 0.0, s_dep = 0.0, s_sem = 0.0, s_occ = 0.0;
@@ -725,7 +726,7 @@ extern "C" int mnf_score_views(const float *rgb_var, const float *depth_var, con
     MNF_REQUIRE(n_members >= 1 && n_views >= 0 && n_pix > 0 && n_classes >= 1 && n_classes <= 32, "score_views: bad sizes");
     if (n_views == 0) return MNF_OK;
     MNF_REQUIRE(rgb_var && depth_var && acc && sem && terms, "score_views: null pointer");
-    hipLaunchKernelGGL(score_kernel, dim3(n_views), dim3(256), 0, as_stream(stream), rgb_var, depth_var, acc, sem, n_members, n_views,
+    hipLaunchKernelGGL(score_kernel, dim3(n_views), dim3(kScoreThreads), 0, as_stream(stream), rgb_var, depth_var, acc, sem, n_members, n_views,
                        n_pix, n_classes, terms);
     return launch_status("score_kernel");
 }
