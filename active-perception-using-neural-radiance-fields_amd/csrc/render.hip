@@ -324,7 +324,9 @@ __device__ __forceinline__ double block_sum(double v, double *s_buf) {
     return t;
 }
 
+constexpr int kScoreMaxM = 4;             // ensemble sizes the array-free form of the semantic term is unrolled for (the reference's ensemble has two members)
 constexpr int kScoreThreads = 1024;      // 16 waves per view: the 4096 pixels of a view are ~220 double-precision exp / log each; four waves per view left three of four issue slots to their latencies (1.07 ms per 256 views)
+template <bool SMALL_M>      // SMALL_M: M <= kScoreMaxM (checked by the host)
 __global__ void __launch_bounds__(kScoreThreads) score_kernel(const float *__restrict__ rgb_var, const float *__restrict__ depth_var,
                                                     const float *__restrict__ acc, const float *__restrict__ sem,
                                                     int M, int V, int P, int C, double *__restrict__ terms) {
@@ -353,7 +355,37 @@ __global__ void __launch_bounds__(kScoreThreads) score_kernel(const float *__res
             s_dep += log(k2pie * (sum_var / 2.0) + 1e-4) / 2.0 - mean_ce / M;
         }
         // semantics (pipeline.py:748-760)
-        {
+        if constexpr (SMALL_M) {
+            // class by class with the members' max / denominator worked out first: the same sums in the same order as the general form below, without its
+            // per-class array (dynamically indexed -> 272 bytes of scratch per lane, which was most of this kernel's time)
+            double mx[kScoreMaxM], den[kScoreMaxM], ce[kScoreMaxM];
+#pragma unroll
+            for (int m = 0; m < kScoreMaxM; ++m) {
+                mx[m] = -1e300; den[m] = 0.0; ce[m] = 0.0;
+                if (m < M) {
+                    const float *lg = sem + (((int64_t)m * V + v) * P + p) * C;
+                    for (int k = 0; k < C; ++k) mx[m] = fmax(mx[m], (double)lg[k]);
+                    for (int k = 0; k < C; ++k) den[m] += exp((double)lg[k] - mx[m]);
+                }
+            }
+            double ent = 0.0;
+            for (int k = 0; k < C; ++k) {
+                double pe = 0.0;
+#pragma unroll
+                for (int m = 0; m < kScoreMaxM; ++m)
+                    if (m < M) {
+                        const double pk = exp((double)sem[(((int64_t)m * V + v) * P + p) * C + k] - mx[m]) / den[m];
+                        pe += pk;
+                        ce[m] -= (pk + 1e-4) * log(pk + 1e-4);
+                    }
+                pe /= M;
+                ent -= (pe + 1e-4) * log(pe + 1e-4);
+            }
+            double mean_ce = 0.0;
+#pragma unroll
+            for (int m = 0; m < kScoreMaxM; ++m) if (m < M) mean_ce += ce[m];
+            s_sem += ent - mean_ce / M;
+        } else {
             double p_ens[32];
             for (int k = 0; k < C; ++k) p_ens[k] = 0.0;
             double mean_ce = 0.0;
@@ -726,7 +758,11 @@ extern "C" int mnf_score_views(const float *rgb_var, const float *depth_var, con
     MNF_REQUIRE(n_members >= 1 && n_views >= 0 && n_pix > 0 && n_classes >= 1 && n_classes <= 32, "score_views: bad sizes");
     if (n_views == 0) return MNF_OK;
     MNF_REQUIRE(rgb_var && depth_var && acc && sem && terms, "score_views: null pointer");
-    hipLaunchKernelGGL(score_kernel, dim3(n_views), dim3(kScoreThreads), 0, as_stream(stream), rgb_var, depth_var, acc, sem, n_members, n_views,
-                       n_pix, n_classes, terms);
+    if (n_members <= kScoreMaxM)
+        hipLaunchKernelGGL(score_kernel<true>, dim3(n_views), dim3(kScoreThreads), 0, as_stream(stream), rgb_var, depth_var, acc, sem, n_members, n_views,
+                           n_pix, n_classes, terms);
+    else
+        hipLaunchKernelGGL(score_kernel<false>, dim3(n_views), dim3(kScoreThreads), 0, as_stream(stream), rgb_var, depth_var, acc, sem, n_members, n_views,
+                           n_pix, n_classes, terms);
     return launch_status("score_kernel");
 }

@@ -521,8 +521,13 @@ def test_train_mode_forward_matches_oracle(scene, fields):
 def test_score_views_matches_oracle():
     from apnrf_amd import render as RD
     from oracle import scorer as SC
+    for M in (2, 3, 5):      # (the kernel has an unrolled form for ensembles of up to four members and a general one: csrc/render.hip score_kernel)
+        _check_score_views(RD, SC, M)
+
+
+def _check_score_views(RD, SC, M):
     rng = np.random.default_rng(4)
-    M, V, P, C = 2, 5, 300, 29
+    V, P, C = 5, 300, 29
     rgb_var = (rng.random((M, V, P, 3)) ** 4 * 0.1).astype(np.float32)
     depth_var = (rng.random((M, V, P)) ** 4).astype(np.float32)
     depth_var[0, 0, :10] = 0.0
