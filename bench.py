@@ -108,6 +108,9 @@ def train_traffic(rays):
     """HBM bytes of one train step from the committed counter passes (profiles/r05_pmc_train.json: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_ATOMIC_sum,
     tools/r05_pmc_train.sh) — quoted only for the kernel sources they were measured on (md5) and the shape they were measured at.  -> (bytes or None, note)"""
     pj = os.path.join(REPO, "profiles", "r05_pmc_train.json")
+    pj_shape = os.path.join(REPO, "profiles", f"r05_pmc_train_{int(rays)}.json")      # (a second pass set at another batch size, e.g. the reference yaml's 2000 rays)
+    if os.path.exists(pj_shape):
+        pj = pj_shape
     if not os.path.exists(pj):
         return None, "no PMC profile of the train step is committed"
     pm = json.load(open(pj))
@@ -116,10 +119,10 @@ def train_traffic(rays):
         with open(os.path.join(REPO, "active-perception-using-neural-radiance-fields_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     if pm.get("train_sources_md5") != h.hexdigest()[:12]:
-        return None, "profiles/r05_pmc_train.json was measured on a different build of the train kernels: not quoted"
+        return None, "profiles/" + os.path.basename(pj) + " was measured on a different build of the train kernels: not quoted"
     if int(pm.get("rays_per_step", 0)) != int(rays):
         return None, f"profiles/r05_pmc_train.json was measured at {pm.get('rays_per_step')} rays per step: not quoted for {rays}"
-    return pm["per_step"]["hbm_bytes"], ("rocprofv3 --pmc passes of these kernel sources (profiles/r05_pmc_train.json: FETCH_SIZE corrected x2 for the 16-byte-per-lane streaming kernels "
+    return pm["per_step"]["hbm_bytes"], ("rocprofv3 --pmc passes of these kernel sources (profiles/" + os.path.basename(pj) + ": FETCH_SIZE corrected x2 for the 16-byte-per-lane streaming kernels "
                                         "+ WRITE_SIZE, per train step at %s surviving samples; copied from the profile, not measured in this run)" % pm.get("surviving_samples_per_step"))
 
 
