@@ -251,7 +251,11 @@ __global__ void __launch_bounds__(kMarchThreads, (LDS_GRID && !MULTI) ? MNF_MARC
         }
         s_base = base;
     }
-    __syncthreads();            // (waits for the staged bits as well: hipcc drains vmcnt in front of the barrier)
+    // The LDS-DMA loads above are global loads whose data lands in LDS: they count on vmcnt, and nothing in a workgroup barrier or an LDS fence has to wait for
+    // them (gfx950's s_barrier does not drain counters by itself).  ROCm 7.2's hipcc happens to emit s_waitcnt vmcnt(0) here; the wait is written out so that every
+    // wave's share of the grid is in LDS before any wave passes the barrier whatever the compiler does.
+    if (LDS_GRID) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (s_base < 0) return;     // uniform: the workspace guard fired
     const int k = (int)threadIdx.x;
     if (k >= s_total) return;
