@@ -483,7 +483,11 @@ def presample(radiance_field, estimator, rays: Rays, near_plane=0.1, far_plane=1
     return tok
 
 
-def presampled_batches(batches, radiance_field, estimator, first_step: int = 0, refresh_every: int = 16, **render_kw):
+REFRESH_EVERY = 16      # the occupancy refresh cadence of `train_step` (pipeline.py:447-470 calls update_every_n_steps with its default n = 16): ONE constant for the refresh
+                        # itself, the presample wait in front of a refreshing step, and the batches `presampled_batches` leaves un-presampled
+
+
+def presampled_batches(batches, radiance_field, estimator, first_step: int = 0, refresh_every: int = REFRESH_EVERY, **render_kw):
     """The reference loop's batches with the march of each one done an iteration early: wraps any iterable of batches (each a tuple or list whose first element is
     the batch's `Rays`) and yields `(step, batch, token)`; pass `presampled=token` to `train_step`.  The next batch is drawn from `batches` and its march enqueued
     (`presample`) BEFORE the current one is yielded, i.e. before the caller enqueues the current step, beside which it then runs.  Batches on either side of an
@@ -497,6 +501,9 @@ def presampled_batches(batches, radiance_field, estimator, first_step: int = 0, 
         cur = next(it)
     except StopIteration:
         return
+    if refresh_every != REFRESH_EVERY:
+        raise ValueError(f"presampled_batches: train_step refreshes the occupancy grid every {REFRESH_EVERY} steps; a different cadence here would let a refresh "
+                         "rewrite the grid under a march in flight")
     step, tok = first_step, None
     while True:
         try:
@@ -676,7 +683,7 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
     from .optim import FusedAdam, count_nan_gradients
     radiance_field.train()
     estimator.train()
-    if presampled is not None and presampled.keep is not None and step % 16 == 0:
+    if presampled is not None and presampled.keep is not None and step % REFRESH_EVERY == 0:
         # only a step that refreshes the grid (update_every_n_steps: step % 16 == 0) needs the march finished before it starts: the refresh must not rewrite the
         # grid under it.  Every other step leaves the wait to mnf_train_step, which skips it when hipEventQuery says the march is done (a cross-queue wait costs
         # the stream ~18 us even then; ADVICE r04: waiting here unconditionally made that shortcut dead).
@@ -687,7 +694,7 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
 
     occ_eval_fn = NA.FieldDensityOcc(radiance_field, render_step_size)     # pipeline.py:376-378; one fused C call per refresh
 
-    estimator.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre)
+    estimator.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, n=REFRESH_EVERY)
     out = None
     if fused and sync and device_guard and not data_parallel:
         # The reference's loop form (n_rendering_samples and the skip decision on the host after every iteration) with ONE host round trip and no bubble on the GPU: render +
@@ -747,9 +754,18 @@ def train_step(radiance_field, estimator, optimizer, rays: Rays, pixels, dep, se
         loss, loss_rgb, loss_dep, loss_sem = out["loss"], out["loss_rgb"], out["loss_dep"], out["loss_sem"]
         skip = out["skip"]                         # device flag: raised by the C call for a step without samples
     else:
-        rgb, acc, depth, semantic, n_rendering_samples = render_image_with_occgrid_with_depth_guide(
-            radiance_field, estimator, rays, near_plane=near_plane, render_step_size=render_step_size, render_bkgd=render_bkgd,
-            cone_angle=cone_angle, alpha_thre=alpha_thre, depth=dep)
+        # the autograd route (fused=False, or the fused call handed the batch over: more than four occupancy levels / a ray past the sampler's scratch row).  The
+        # reference's signature has no jitter switch (it follows radiance_field.training, occ_grid.py:187-189): `stratified=False` is honoured by rendering in eval mode
+        no_jitter = stratified is False and radiance_field.training
+        if no_jitter:
+            radiance_field.eval()
+        try:
+            rgb, acc, depth, semantic, n_rendering_samples = render_image_with_occgrid_with_depth_guide(
+                radiance_field, estimator, rays, near_plane=near_plane, render_step_size=render_step_size, render_bkgd=render_bkgd,
+                cone_angle=cone_angle, alpha_thre=alpha_thre, depth=dep)
+        finally:
+            if no_jitter:
+                radiance_field.train()
         dev = rays.origins.device
         skip = torch.zeros((), dtype=torch.int32, device=dev)
         optimizer.zero_grad()

@@ -89,6 +89,8 @@ def parse(argv=None):
                     help="render jobs in flight in the timed 800x800 pass (2 = the reported configuration; 1 = launches back to back on one stream, the form "
                          "the roofline pass uses: a rocprofv3 --stats run with 1 gives per-launch durations that can be compared with roofline.avg_launch_ms)")
     ap.add_argument("--train-dtypes", default="f16,bf16", help="matrix-core operand types of the train leg")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of an N > 1 job (nccl = RCCL; gloo: test rigs)")
+    ap.add_argument("--one-device", action="store_true", help="test rigs: every rank uses cuda:0 (two ranks on a one-GPU box; RCCL refuses that, so with --dist-backend gloo)")
     return ap.parse_args(argv)
 
 
@@ -337,10 +339,16 @@ class Ctx:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.distributed = self.world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+        if args.one_device:
+            self.local_rank = 0
+        self.comm_dev = f"cuda:{self.local_rank}" if args.dist_backend == "nccl" else "cpu"      # where the harness's own small collectives live
         if self.distributed:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{self.local_rank}"))
-            self.world = dist.get_world_size()                     # the size RCCL actually formed
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{self.local_rank}"))
+            else:
+                dist.init_process_group("gloo")
+            self.world = dist.get_world_size()                     # the size the backend actually formed
         torch.cuda.set_device(self.local_rank)
         self.dev = f"cuda:{self.local_rank}"
         import __graft_entry__ as G
@@ -415,7 +423,7 @@ class Ctx:
             ms, n = ctypes.c_double(0), ctypes.c_int64(0)
             L.check(lib.mnf_profile_end(ctypes.byref(ms), ctypes.byref(n)))
         if self.distributed:
-            t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            t = torch.tensor([dt], device=self.comm_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -736,7 +744,7 @@ def leg_score256(cx, line):
     terms, score = sstep(0)
     evaluated = float(sum(int(t[1]) for t in RD.LAST_SCORE_TOTALS))          # this rank's share of the views, all members
     cx.timed(sstep_parts, 3, 1, False)
-    parts = torch.tensor([t_parts["compute"] / t_parts["n"], t_parts["gather"] / t_parts["n"]], dtype=torch.float64, device=dev)
+    parts = torch.tensor([t_parts["compute"] / t_parts["n"], t_parts["gather"] / t_parts["n"]], dtype=torch.float64, device=cx.comm_dev)
     per_rank = [parts.clone() for _ in range(world)]
     if cx.distributed:
         dist.all_gather(per_rank, parts)
