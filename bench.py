@@ -685,11 +685,12 @@ def leg_config2(cx, line):
     c2["render"] = {"ms_per_step": 1e3 * dt / args.steps, "views_per_step": V, "ms_per_view": 1e3 * dt / args.steps / V, "rays_per_s": w * h * V * cx.world * args.steps / dt,
                     "samples_per_ray": samples / (w * h * V * args.steps), "samples_per_s": samples * cx.world / dt}
     if not args.no_kernel_timing:
-        r = leg.roofline(V, args.steps, "mnf::field_kernel<64,4,2,false> (hash gather + MLPs + fused compositing)", traffic_key="field_kernel_64x4")
+        r = leg.roofline(V, args.steps, "mnf::field_kernel<64,4,2,false> (hash gather + MLPs + fused compositing)", traffic_key="field_kernel_64x4_config2")
         if r:
             c2["render"]["roofline"] = r
     dt1, s1 = leg.run(1, args.steps, 2, False)
     c2["render"]["one_view_per_call"] = {"ms_per_view": 1e3 * dt1 / args.steps, "rays_per_s": w * h * cx.world * args.steps / dt1}
+    c2["render"]["process_samples"] = int(leg.process_samples.item())
     tsteps = max(args.steps, 10)
     c2["train"] = tl.run("f16", 2000, False, tsteps, True)
     c2["train"]["host_synchronous_ms_per_step"] = tl.run("f16", 2000, True, tsteps, False)["ms_per_step"]

@@ -1,6 +1,7 @@
 """Train-step timing experiment (GPU box): ms per step for the synchronous (reference semantics: one host round trip at the end)
 and the fully asynchronous form, at BASELINE config 5's shape (8192 rays) and at the reference yaml's (2000 rays / ~262 k samples).
-    python tools/exp_train.py [f16|bf16] [steps] [lr] [shapes] [sync modes] [backward mode] [presample 0|1]"""
+    python tools/exp_train.py [f16|bf16] [steps] [lr] [shapes] [sync modes] [backward mode] [presample 0|1] [model: NEURONSxLAYERS@SCENE@IMAGE/SEED, default 128x2@102344280@640/11]
+    (64x4@102344250@256/9 = BASELINE config 2's train leg of bench.py)"""
 import os
 import sys
 import time
@@ -23,9 +24,13 @@ shapes = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [819
 modes = [bool(int(x)) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [True, False]
 bwd_mode = 0                                                     # (argv[6] was the backward mode of round 4's fused-backward experiment: tools/experiments/fused_backward.patch)
 presample = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False   # march batch k+1 beside step k (render.presample)
+model = sys.argv[8] if len(sys.argv) > 8 else "128x2@102344280@640/11"
+(_shape, _scene, _rest) = model.split("@")
+_im, _seed = (int(x) for x in _rest.split("/"))
+_neurons, _layers = (int(x) for x in _shape.split("x"))
 dev = "cuda:0"
-scene = SC.make_scene("102344280", n_poses=40)
-field, est, info = SI.train_standin(scene, dev, seed=11)     # the stand-in of bench.py's train legs
+scene = SC.make_scene(_scene, n_poses=40, neurons=_neurons, layers=_layers)
+field, est, info = SI.train_standin(scene, dev, seed=_seed)     # the stand-in of bench.py's train legs
 print("[exp_train] stand-in:", {k: v for k, v in info.items() if k != "optimizer_state"}, flush=True)
 if dtype == "bf16":
     f2 = SC.hip_field(scene, dev, mfma_bf16=True)
@@ -34,17 +39,18 @@ if dtype == "bf16":
 field.train(); est.train()
 proc = SI._procedural_estimator(scene, dev)
 c2w = np.stack([RD.pose_to_c2w(p) for p in scene["poses"][:8]]).astype(np.float32)
-K6 = np.array([[320.0, 0, 320], [0, 320.0, 320], [0, 0, 1.0]])
+K6 = np.array([[_im / 2.0, 0, _im / 2.0], [0, _im / 2.0, _im / 2.0], [0, 0, 1.0]])
+_blk = max(1, _im // 20)
 
 
 def batches(R):
     g = torch.Generator(device="cpu").manual_seed(100)
     out = []
     for k in range(8):
-        idx = torch.randint(0, 640 * 640, (R,), generator=g).numpy()
-        ys, xs = idx // 640, idx % 640
-        idx = idx[np.argsort((ys // 32) * 20 + xs // 32, kind="stable")]
-        r = RD.generate_image_rays(torch.from_numpy(c2w[k:k + 1]), 640, 640, K6, dev, idx)
+        idx = torch.randint(0, _im * _im, (R,), generator=g).numpy()
+        ys, xs = idx // _im, idx % _im
+        idx = idx[np.argsort((ys // _blk) * 20 + xs // _blk, kind="stable")]
+        r = RD.generate_image_rays(torch.from_numpy(c2w[k:k + 1]), _im, _im, K6, dev, idx)
         out.append((r,) + SI.analytic_targets(proc, scene["aabb"], r.origins, r.viewdirs))
     return out
 

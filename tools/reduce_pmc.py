@@ -26,8 +26,14 @@ def pick(d, sub):
 
 f_tot, f_n = sums(fetch_csv, "FETCH_SIZE")
 w_tot, w_n = sums(write_csv, "WRITE_SIZE")
-line = json.loads(open(bench_json).read().strip().splitlines()[-1])
+txt = open(bench_json).read().strip()
+try:
+    line = json.loads(txt)                                  # bench_detail.json (round 6: the stdout line is a < 4 KB summary, the full record is a file)
+except json.JSONDecodeError:
+    line = json.loads(txt.splitlines()[-1])
 samples = line["samples"]["process_total"] if "samples" in line else None
+if samples is None and "config2" in line and "config2" in label:
+    samples = line["config2"]["render"].get("process_samples")
 if samples is None and "score256" in line:
     samples = line["score256"].get("process_samples")
 fk_f, fk_w = pick(f_tot, kname), pick(w_tot, kname)

@@ -51,7 +51,7 @@ for s in TRAIN_SOURCES:
     h.update(open(os.path.join(REPO, "active-perception-using-neural-radiance-fields_amd", "csrc", s), "rb").read())
 out = {"train_sources_md5": h.hexdigest()[:12], "rays_per_step": int(rays), "steps_in_process": steps, "surviving_samples_per_step": kept,
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_ATOMIC_sum (three separate processes) of tools/exp_train.py (asynchronous steps, lr 0, "
-                 "stand-in of bench.py's train legs); tools/r05_pmc_train.sh; kernels below 1 MB per step omitted",
+                 "stand-in of bench.py's train legs); tools/pmc_train.sh; kernels below 1 MB per step omitted",
        "per_step": {"fetch_bytes_raw": tot["fetch_raw"], "fetch_bytes_corrected": tot["fetch_corrected"], "write_bytes": tot["write"],
                     "atomic_requests": tot["atomic_requests"], "atomic_bytes_64B_rmw": tot["atomic_requests"] * 128,
                     "hbm_bytes": tot["fetch_corrected"] + tot["write"],
