@@ -117,9 +117,10 @@ __global__ void __launch_bounds__(256) traverse_kernel(int32_t n_rays, const flo
 constexpr int kSamplerGridWords = 16384;   // 64 KB of LDS = 524 288 cells
 
 #ifndef MNF_SAMPLER_THREADS
-#define MNF_SAMPLER_THREADS 64       /* threads per workgroup of sample_rays_kernel.  The kernel is one dependent chain per ray (its time does not depend on the ray
-                                        count: 197 us for 8192 and for 2000 rays with 256 threads, 184 / 187 us with 64, tools/exp_sampler.py, profiles/r04_exp_sampler.txt):
-                                        one wave per workgroup spreads the waves over 4x more compute units */
+#define MNF_SAMPLER_THREADS 1024     /* threads per workgroup of sample_rays_kernel: sixteen waves share one LDS copy of the grid, two workgroups per compute unit (57 VGPRs).
+                                        The kernel is one dependent chain per ray and a wave pays for the union of its lanes' chains: with full waves its time did not depend on
+                                        the ray count or the workgroup size (197 us for 8192 and for 2000 rays with 256 threads, 184 / 187 us with 64, profiles/r04_exp_sampler.txt);
+                                        with ONE ray per wave (round 6, `rpw` below) 8192 rays take 0.179 instead of 0.234 ms, 2000 rays 0.145 instead of 0.242 */
 #endif
 #ifndef MNF_SAMPLER_EXP
 #define MNF_SAMPLER_EXP 0            /* timing experiments only: 1 = no sample stores (results invalid) */
@@ -138,12 +139,15 @@ struct ScratchSink {
     }
 };
 
+// `rpw` rays per wave (16 / 32 / 64): a wave pays for the UNION of its lanes' paths — empty-space stepping, sampling and cell steps have different trip counts in
+// every lane — so a batch that cannot fill the chip with full waves is marched with fewer rays per wave on more waves (lanes >= rpw idle).  Per-ray arithmetic is
+// unchanged: same samples, bit for bit.
 template <bool LDS_GRID, bool MULTI>
 __global__ void __launch_bounds__(MNF_SAMPLER_THREADS) sample_rays_kernel(int32_t n_rays, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                           I3 res, const uint8_t *__restrict__ binaries, const LevelBoxes boxes, const float *__restrict__ near_planes,
                                                           const float *__restrict__ far_planes, float step_size, float cone_angle,
                                                           int32_t cap, float *__restrict__ scratch_ts, float *__restrict__ scratch_te,
-                                                          int64_t *__restrict__ counts, const uint32_t *__restrict__ bitgrid) {
+                                                          int64_t *__restrict__ counts, const uint32_t *__restrict__ bitgrid, int32_t rpw) {
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[LDS_GRID ? kSamplerGridWords : 1];
     const int64_t cells = (int64_t)res.x * res.y * res.z;
     if (LDS_GRID) {   // every level's bits: level l at word l * words_per_level (the layout of mnf_pack_bitgrid)
@@ -172,7 +176,10 @@ __global__ void __launch_bounds__(MNF_SAMPLER_THREADS) sample_rays_kernel(int32_
 #if MNF_SAMPLER_EXP == 3
     if (n_rays > 0) { for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)blockDim.x * gridDim.x) counts[r] = s_bits[r & 1023] & 1; return; }   /* staging only */
 #endif
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)blockDim.x * gridDim.x) {
+    const int lane_ = threadIdx.x & 63;
+    if (lane_ >= rpw) return;
+    const int64_t wave_ = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves_ = ((int64_t)blockDim.x * gridDim.x) >> 6;
+    for (int64_t r = wave_ * rpw + lane_; r < n_rays; r += n_waves_ * rpw) {
         const F3 org = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
         const F3 dir = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
         const F3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
@@ -500,9 +507,16 @@ extern "C" int mnf_sample_rays_levels(const float *rays_o, const float *rays_d, 
         for (int k = 0; k < 6; ++k) boxes.ab[l][k] = aabb_host[6 * l + k];
     ProfScope ps("sample_rays", as_stream(stream));
     const bool lds = (int64_t)boxes.words_per_level * n_levels <= (int64_t)kSamplerGridWords;
-    const int grid = grid_for(n_rays, MNF_SAMPLER_THREADS);
+    // rays per wave: as few as keep the launch within the waves the chip holds at once (256 compute units x 2 workgroups x 16 waves = 8192): one ray per wave up to
+    // 8192 rays, two up to 16 384 ... (profiles/r06_sampler_rpw.txt: 0.179 / 0.188 / 0.222 / 0.249 / 0.234 ms for 8192 rays with 1 / 2 / 4 / 8 / 64 rays per wave)
+#ifndef MNF_SAMPLER_RPW
+#define MNF_SAMPLER_RPW 0            /* 0 = by batch size (below); 1 .. 64: fixed (A/B builds) */
+#endif
+    int rpw = MNF_SAMPLER_RPW ? MNF_SAMPLER_RPW : 1;
+    while (!MNF_SAMPLER_RPW && rpw < 64 && (int64_t)rpw * 8192 < n_rays) rpw <<= 1;
+    const int grid = grid_for((int64_t)ceil_div(n_rays, rpw) * 64, MNF_SAMPLER_THREADS);
 #define MNF_SAMPLE(LDS, ML) hipLaunchKernelGGL((sample_rays_kernel<LDS, ML>), dim3(grid), dim3(MNF_SAMPLER_THREADS), 0, as_stream(stream), n_rays, rays_o, rays_d, res, binaries, boxes, \
-                                               near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts, bitgrid)
+                                               near_planes, far_planes, step_size, cone_angle, cap, scratch_ts, scratch_te, counts, bitgrid, rpw)
     if (n_levels > 1) { if (lds) MNF_SAMPLE(true, true); else MNF_SAMPLE(false, true); }
     else { if (lds) MNF_SAMPLE(true, false); else MNF_SAMPLE(false, false); }
 #undef MNF_SAMPLE

@@ -257,7 +257,20 @@ __global__ void __launch_bounds__(kMarchThreads, (LDS_GRID && !MULTI) ? MNF_MARC
     if (LDS_GRID) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (s_base < 0) return;     // uniform: the workspace guard fired
-    const int k = (int)threadIdx.x;
+    // Rank k among the workgroup's marching rays -> lane.  A wave pays for the UNION of its lanes' paths (empty-space stepping, sampling, cell steps: different trip
+    // counts in every lane; measured on the sampler: 0.179 / 0.188 / 0.222 / 0.249 ms with 1 / 2 / 4 / 8 rays per wave, profiles/r06_sampler_rpw.txt), and late in a
+    // render a workgroup marches a few dozen rays: they are spread over the workgroup's sixteen waves, as few to a wave as that allows, instead of filling one
+    // wave completely (lanes >= rpw idle).  Which lane marches a ray changes nothing for the ray.
+#ifndef MNF_MARCH_RPW
+#define MNF_MARCH_RPW 0              /* 0 = by the number of marching rays; 64 = full waves (rounds 1-5; A/B builds) */
+#endif
+    // Only in launches the chip holds at once (<= 512 workgroups = two per compute unit: the scorer's jobs, small pose lists): there the marcher is latency-bound and
+    // the extra waves are free; in the large launches of full-resolution renders it is throughput-bound and sixteen waves for sixteen rays cost issue slots
+    // (800 x 800 x 4: 63.7 -> 64.0 ms per step with the spreading everywhere; scoring shard of 32 views 21.3 -> 20.7 ms, profiles/r06_rpw_ab.txt).
+    int rpw = MNF_MARCH_RPW ? MNF_MARCH_RPW : (gridDim.x <= 512 ? 1 : 64);       // the smallest power of two with sixteen waves x rpw >= s_total
+    while (!MNF_MARCH_RPW && rpw * (kMarchThreads / 64) < s_total) rpw <<= 1;
+    if (lane >= rpw) return;
+    const int k = wave * rpw + lane;
     if (k >= s_total) return;
     const int64_t r = (int64_t)v * rays_per_view + s_list[k];
     const int ns = stride, cap = 64 / stride;
