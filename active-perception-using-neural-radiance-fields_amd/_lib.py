@@ -37,8 +37,8 @@ class TrainOpts(_Sized):
                 ("presampled", c_void_p)]
 
 
-class VanillaConfig(ctypes.Structure):
-    _fields_ = [("net_depth", c_int32), ("net_width", c_int32), ("skip_layer", c_int32), ("net_depth_condition", c_int32),
+class VanillaConfig(_Sized):
+    _fields_ = [("struct_size", c_uint32), ("net_depth", c_int32), ("net_width", c_int32), ("skip_layer", c_int32), ("net_depth_condition", c_int32),
                 ("net_width_condition", c_int32)]
 
 
@@ -49,8 +49,8 @@ class RenderOpts(_Sized):
                 ("rays_per_view", c_int32), ("sync_every", c_int32), ("view_order", c_void_p), ("bitgrid", c_void_p), ("n_levels", c_int32)]
 
 
-class RenderJob(ctypes.Structure):
-    _fields_ = [("field", c_void_p), ("binaries", c_void_p), ("bitgrid", c_void_p), ("rays_o", c_void_p), ("rays_d", c_void_p),
+class RenderJob(_Sized):
+    _fields_ = [("struct_size", c_uint32), ("field", c_void_p), ("binaries", c_void_p), ("bitgrid", c_void_p), ("rays_o", c_void_p), ("rays_d", c_void_p),
                 ("n_rays", c_int64), ("rgb", c_void_p), ("acc", c_void_p), ("depth", c_void_p), ("sem", c_void_p), ("rgb_var", c_void_p),
                 ("depth_var", c_void_p), ("total_samples", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 

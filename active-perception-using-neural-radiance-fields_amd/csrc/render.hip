@@ -741,6 +741,9 @@ extern "C" int mnf_render_jobs(const mnf_render_job *jobs_host, int32_t n_jobs, 
     MNF_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= 64 && opts, "render_jobs: bad arguments");
     MNF_REQUIRE(opts->struct_size == sizeof(mnf_render_opts), "render_jobs: opts->struct_size is %u, this library's mnf_render_opts has %zu bytes (MNF_INIT)",
                 opts->struct_size, sizeof(mnf_render_opts));
+    for (int k = 0; k < n_jobs; ++k)      // before anything is enqueued or forked
+        MNF_REQUIRE(jobs_host[k].struct_size == sizeof(mnf_render_job), "render_jobs: jobs[%d].struct_size is %u, this library's mnf_render_job has %zu bytes (MNF_INIT)", k,
+                    jobs_host[k].struct_size, sizeof(mnf_render_job));
     JobPool *pp = job_pool();
     if (!pp) return MNF_ERR_HIP;
     JobPool &pool = *pp;

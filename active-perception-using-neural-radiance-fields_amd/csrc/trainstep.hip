@@ -628,6 +628,7 @@ extern "C" int mnf_score_poses(const mnf_field_t *fields_host, const uint8_t *co
         for (int g = 0; g < G; ++g) {
             const int64_t r0 = (int64_t)group_lo(n_views, g, G) * n_pix, r1 = (int64_t)group_lo(n_views, g + 1, G) * n_pix;
             mnf_render_job j = {};
+            j.struct_size = (uint32_t)sizeof(j);
             j.field = fields_host[m]; j.binaries = binaries_host[m]; j.bitgrid = bitgrids_host ? bitgrids_host[m] : nullptr;
             j.rays_o = o + 3 * r0; j.rays_d = d + 3 * r0; j.n_rays = r1 - r0;
             j.rgb = rgb + 3 * r0; j.depth = depth + r0;

@@ -485,6 +485,8 @@ extern "C" int mnf_vanilla_destroy(mnf_vanilla_t v) {
 
 extern "C" int mnf_vanilla_create(const mnf_vanilla_config *cfg, mnf_vanilla_t *out) {
     MNF_REQUIRE(cfg && out, "vanilla_create: null argument");
+    MNF_REQUIRE(cfg->struct_size == sizeof(mnf_vanilla_config), "vanilla_create: cfg->struct_size is %u, this library's mnf_vanilla_config has %zu bytes (MNF_INIT)",
+                cfg->struct_size, sizeof(mnf_vanilla_config));
     MNF_REQUIRE(cfg->net_depth >= 1 && cfg->net_depth_condition >= 1, "vanilla_create: net_depth and net_depth_condition must be >= 1");
     MNF_REQUIRE(cfg->net_depth + cfg->net_depth_condition + 2 <= kMaxLayers, "vanilla_create: too many layers (max %d)", kMaxLayers - 2);
     MNF_REQUIRE(cfg->net_width >= 32 && cfg->net_width % 32 == 0 && cfg->net_width <= 512 && cfg->net_width_condition >= 32 &&

@@ -24,7 +24,7 @@ from . import nerfacc as NA
 Rays = collections.namedtuple("Rays", ("origins", "viewdirs"))
 
 _WORKSPACES = collections.OrderedDict()
-MAX_CACHED_WORKSPACES = 12      # (device, slot, stream) entries kept; the least recently used one goes first
+MAX_CACHED_WORKSPACES = 12      # (device, slot, stream) entries kept; the least recently used one goes first.  Grows to the largest job count of a render call + 4
 
 
 def _workspace(key, nbytes: int) -> torch.Tensor:
@@ -143,6 +143,8 @@ def _render_jobs(specs, rpv, max_samples, near_plane, far_plane, render_step_siz
             if r1 == r0:
                 continue
             nbytes = lib.mnf_render_workspace_bytes(r1 - r0, rpv)
+            global MAX_CACHED_WORKSPACES
+            MAX_CACHED_WORKSPACES = max(MAX_CACHED_WORKSPACES, len(jobs) + 5)      # a call never evicts the slots it is still filling: the cap follows the largest job count seen
             ws = _workspace((dev, len(jobs)), nbytes)
             j = L.RenderJob()
             j.field, j.binaries, j.bitgrid = handle, binaries.data_ptr(), (None if bits is None else bits.data_ptr())

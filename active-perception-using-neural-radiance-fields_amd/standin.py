@@ -221,6 +221,26 @@ def shared_standin(scene, device, steps=2000, seed=9, keep_optimizer=False, grou
                 field = SC.hip_field(scene, device)
                 est = NA.OccGridEstimator(torch.from_numpy(scene["aabb"]), resolution=scene["res"], levels=1).to(device)
                 info = {"received_by_broadcast": True}
-        if saved.item() == 0:
+        # Ranks that loaded "the file rank 0 wrote" may have loaded nothing of the kind (a cache directory that is not shared between nodes: every rank then trained its
+        # own stand-in) — nothing above would notice, and view-sharded scoring would disagree across ranks.  One small collective settles it: every rank's parameter /
+        # grid checksum against rank 0's; any mismatch and the model travels by broadcast after all (ADVICE r05).
+        need = saved.clone().zero_()
+        if saved.item() > 0:
+            mine = _model_checksum(field, est).to(flag_dev)
+            ref = mine.clone()
+            dist.broadcast(ref, src=0, group=group)
+            need.fill_(0.0 if torch.equal(mine, ref) else 1.0)
+            dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
+            if need.item() > 0 and rank != 0:
+                info = dict(info, cache_mismatch=True, received_by_broadcast=True)
+                info.pop("optimizer_state", None)
+        if saved.item() == 0 or need.item() > 0:
             DD.broadcast_model(field, est, src=0, group=group)
     return field.eval(), est.eval(), info
+
+
+def _model_checksum(field, est) -> torch.Tensor:
+    """[4] float64: sums of the three parameter vectors (as int32 bit patterns: exact, order-independent) and the number of occupied cells"""
+    out = [p.detach().view(torch.int32).to(torch.float64).sum() for p in (field.mlp_base.params, field.mlp_head.params, field.mlp_sem.params)]
+    out.append(est.binaries.to(torch.float64).sum())
+    return torch.stack(out).cpu()

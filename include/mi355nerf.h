@@ -244,7 +244,8 @@ int mnf_gather_pixels(const uint8_t *images, const void *depths, int32_t depth_i
 
 /* ---------------------------------------------------------------- radiance field (tinycudann replacement) */
 
-/* Option structs that the library takes BY POINTER start with `struct_size`: set it to sizeof(the struct) (MNF_INIT below zero-fills and sets it).
+/* Structs that the library takes BY POINTER (mnf_field_config, mnf_vanilla_config, mnf_train_opts, mnf_render_opts, and every element of a mnf_render_job
+ * array) start with `struct_size`: set it to sizeof(the struct) (MNF_INIT below zero-fills and sets it).
  * The library refuses any other value (MNF_ERR_INVALID), so a caller compiled against an older header — whose struct is shorter than what this
  * library reads — is stopped at the boundary instead of having the tail of its struct read from whatever follows it.  Every field added after a
  * struct's first release reads 0 / NULL as "the previous behaviour". */
@@ -324,6 +325,7 @@ int mnf_field_density_rays(mnf_field_t f, const float *rays_o, const float *rays
  * rgb hidden layers, rgb output layer (mnf_vanilla_param_layout_host lists the tensors). */
 typedef struct mnf_vanilla_s *mnf_vanilla_t;
 typedef struct {
+    uint32_t struct_size;         /* sizeof(mnf_vanilla_config), see MNF_INIT */
     int32_t net_depth;            /* mlp.py:209 */
     int32_t net_width;            /* mlp.py:210 (multiple of 32) */
     int32_t skip_layer;           /* mlp.py:211; <= 0 = None */
@@ -499,6 +501,7 @@ int mnf_render_test(mnf_field_t f, const uint8_t *binaries, int32_t res_x, int32
  * streams of the library that fork from and join `stream`.  While one job's short kernels leave compute units idle the others'
  * launches use them.  Results are those of separate mnf_render_test calls, bit for bit.  `opts->bitgrid` is ignored (per job). */
 typedef struct {
+    uint32_t struct_size;         /* sizeof(mnf_render_job) in EVERY element of the array, see MNF_INIT */
     mnf_field_t field;
     const uint8_t *binaries;      /* [L,X,Y,Z] u8, L = opts->n_levels */
     const uint32_t *bitgrid;      /* optional packed form of `binaries` (see mnf_render_opts.bitgrid) */

@@ -106,7 +106,7 @@ def test_option_structs_carry_their_size_and_stale_callers_are_refused():
     did not initialise the struct, is refused at the boundary before anything is read from the struct's tail.  No GPU needed:
     the check comes first."""
     lib = apnrf_amd.load_library()
-    for cls in (L.FieldConfig, L.TrainOpts, L.RenderOpts):
+    for cls in (L.FieldConfig, L.TrainOpts, L.RenderOpts, L.VanillaConfig, L.RenderJob):
         s = cls()
         assert s.struct_size == ctypes.sizeof(cls) and cls._fields_[0][0] == "struct_size"
     cfg = L.FieldConfig()
@@ -117,8 +117,18 @@ def test_option_structs_carry_their_size_and_stale_callers_are_refused():
         cfg.struct_size = bad
         assert lib.mnf_field_create(ctypes.byref(cfg), ctypes.byref(h)) == -1          # MNF_ERR_INVALID
         assert b"struct_size" in lib.mnf_last_error()
+    vc = L.VanillaConfig()
+    vc.net_depth, vc.net_width, vc.skip_layer, vc.net_depth_condition, vc.net_width_condition = 2, 64, 0, 1, 64
+    vc.struct_size = ctypes.sizeof(L.VanillaConfig) - 4                                # a caller built against the round-5 header (no size field)
+    assert lib.mnf_vanilla_create(ctypes.byref(vc), ctypes.byref(h)) == -1 and b"struct_size" in lib.mnf_last_error()
+    jobs = (L.RenderJob * 2)()
+    jobs[0].struct_size = ctypes.sizeof(L.RenderJob)                                  # the second element left at 0: every element of the array is checked
+    ro = L.RenderOpts()
+    assert lib.mnf_render_jobs(jobs, 2, 8, 8, 8, (ctypes.c_float * 6)(0, 0, 0, 1, 1, 1), ctypes.byref(ro), None) == -1
+    assert b"jobs[1].struct_size" in lib.mnf_last_error()
     header = open(os.path.join(REPO, "include", "mi355nerf.h")).read()
-    for name in ("mnf_field_config", "mnf_train_opts", "mnf_render_opts"):            # every struct the library takes by pointer declares it first
+    assert header.count("typedef struct {") == 5                                       # ... and these five are ALL the structs of the header
+    for name in ("mnf_field_config", "mnf_vanilla_config", "mnf_train_opts", "mnf_render_opts", "mnf_render_job"):   # every struct the library takes by pointer declares it first
         body = header[:header.index("} " + name + ";")]
         body = body[body.rindex("typedef struct {"):]
         assert body.split("\n")[1].strip().startswith("uint32_t struct_size;"), name
