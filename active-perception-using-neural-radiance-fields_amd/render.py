@@ -922,28 +922,22 @@ def _pose_rays(poses, width, height, focal, scale, device):
     return rays.origins.reshape(V * h * w, 3), rays.viewdirs.reshape(V * h * w, 3), h, w
 
 
-HOST_WIDEN_MIN_THREADS = 16     # below this many torch CPU threads the float64 widening stays on the device (a single host thread widens 115 MB in ~12 ms)
-
-
 def _host_stacks_f64(outputs):
     """The float64 host arrays the reference's drivers return (habitat_to_data.py:376-409, :497-544: `np.zeros(...)` stacks filled from `.cpu().numpy()`), made
-    with ONE device-to-host transfer into one pinned block (torch's caching host allocator) and one stream synchronisation; the returned arrays are views of ONE
-    pinned float64 block, which they keep alive (a caller that retains one of them for long retains the block: copy it out).
-    The transfer carries the float32 outputs (55 MB for a 640 x 640 view, not 111) and torch's CPU threads widen them on the host side — the same values bit for
-    bit (float32 -> float64 is exact wherever it is done): 1.39 against 2.12 ms per 640 x 640 pose on the GPU box's 128 threads (profiles/r06_host_stacks.txt; numpy's
-    single-threaded astype: 11.6 ms).  With few CPU threads (torch.get_num_threads() < HOST_WIDEN_MIN_THREADS) the widening is done on the device as in round 5."""
+    with ONE device-to-host transfer: every output is widened to float64 on the device and lands in one pinned block (torch's caching host allocator), one stream
+    synchronisation, and the returned arrays are views of that ONE block, which they keep alive (a caller that retains one of them for long retains all 111 MB of a
+    640 x 640 pose: copy it out).  Six pageable `.double().cpu()` copies cost a 640 x 640 view more than its render (27.5 against 18.4 ms per pose, round 5).
+    Round 6 tried the other order — transfer the float32 outputs (55 MB) and widen on the host with torch's CPU threads: 1.39 against 2.12 ms for the hand-over alone
+    (profiles/r06_host_stacks.txt; numpy's single-threaded astype 11.6 ms), but inside the drivers the difference drowns in the thread pool's jitter (15.2-17.0 against
+    15.6-16.4 ms per 640 x 640 pose, the 40-pose probabilistic call 19.8-23.2 against 19.7-20.8: profiles/r06_pose_drivers.txt) — not kept."""
     total = sum(int(np.prod(shape)) for _, shape in outputs)
     host = torch.empty(total, dtype=torch.float64, pin_memory=True)
-    on_host = torch.get_num_threads() >= HOST_WIDEN_MIN_THREADS
-    stage = torch.empty(total, dtype=torch.float32, pin_memory=True) if on_host else host
     off = 0
     for t, shape in outputs:
         n = int(np.prod(shape))
-        stage[off:off + n].copy_(t.reshape(-1), non_blocking=True)
+        host[off:off + n].copy_(t.reshape(-1), non_blocking=True)
         off += n
     torch.cuda.current_stream(outputs[0][0].device).synchronize()
-    if on_host:
-        host.copy_(stage)
     arrays, off = [], 0
     for _, shape in outputs:
         n = int(np.prod(shape))
