@@ -7,5 +7,5 @@ for name in "$@"; do
    | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d.get('roofline',{})
-print('$name rep$rep: %.2f ms/step  %.1f Mrays/s  field %.4f ms/launch  frac %.3f  %.1f samples/ray  views1 %.2f ms' % (d['ms_per_step'], d['value']/1e6, r.get('avg_launch_ms',0), r.get('frac',0), d['config']['samples_per_ray'], d.get('render_views1',{}).get('ms_per_view',0)))"
+print('$name rep$rep: %.2f ms/step  %.1f Mrays/s  field %.4f ms/launch  frac %.3f  %.1f samples/ray  views1 %.2f ms' % (d['ms_per_step'], d['value']/1e6, r.get('avg_launch_ms',0), r.get('frac',0), d['config']['samples_per_ray'], (640000.0 * 1e3 / d['render_views1_rays_per_s'] if d.get('render_views1_rays_per_s') else 0)))"
 done; done
