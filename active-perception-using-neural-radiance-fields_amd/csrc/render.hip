@@ -21,7 +21,10 @@
 namespace mnf {
 
 constexpr int kRayThreads = 256;
-constexpr int kMarchThreads = 1024;            // one bit-packed occupancy grid in LDS shared by 16 waves
+#ifndef MNF_MARCH_THREADS
+#define MNF_MARCH_THREADS 1024
+#endif
+constexpr int kMarchThreads = MNF_MARCH_THREADS;   // one bit-packed occupancy grid in LDS shared by 16 waves (A/B builds: 256 / 512)
 constexpr int kMaxGridWords = 16384;           // 64 KB of LDS = 524 288 cells (largest reference grid: 396 900)
 
 struct RenderWs {
@@ -557,7 +560,11 @@ int job_begin(RenderJob &j, mnf_field_t f, const uint8_t *binaries, int32_t res_
     const int64_t cells = (int64_t)res_x * res_y * res_z;
     j.boxes.words_per_level = (int)ceil_div(cells, 32);
     j.n_words = j.boxes.words_per_level * n_levels;          // every level's bits side by side in LDS
+#ifdef MNF_NO_LDS_GRID
+    j.lds_grid = false;                                      // A/B builds: occupancy bytes straight from global memory
+#else
     j.lds_grid = j.n_words <= kMaxGridWords;
+#endif
     if (j.lds_grid) {
         if (opts->bitgrid) j.ws.bitgrid = const_cast<uint32_t *>(opts->bitgrid);   // the estimator's own packed grid: nothing to build
         else hipLaunchKernelGGL(pack_grid_kernel, dim3((int)ceil_div(j.n_words, 256)), dim3(256), 0, s, binaries, cells, j.ws.bitgrid, j.n_words, j.boxes.words_per_level);
