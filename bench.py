@@ -778,6 +778,13 @@ def leg_score256(cx, line):
                                    "bit_identical_to_full_pass_rows": bool(torch.equal(t8, terms[lo:hi])),
                                    "note": "views 0..31 of the same pass on one GPU = the per-rank work of --gpus 8; predicted 8-GPU pass = this + one 8 KB all-gather"}
         cx.log(f"score256 shard of 8: {1e3 * dt8 / ssteps:.2f} ms/pass")
+        # ... and of a 2- and a 4-GPU run: the predicted strong-scaling curve of config 4 (no node to measure it on), every rank's share timed on this GPU
+        curve = {"1": 1e3 * dt_s / ssteps, "8": 1e3 * dt8 / ssteps}
+        for n_ in (2, 4):
+            lo_, hi_, _ = RD.shard_views(256, n_, 0)
+            curve[str(n_)] = 1e3 * cx.timed(lambda i: score_call(poses256[lo_:hi_], False), ssteps, 1, False) / ssteps
+        line["score256_predicted_scaling"] = {"ms_per_pass_of_rank0_share": curve, "efficiency": {k: curve["1"] / (int(k) * v) for k, v in curve.items()},
+                                              "note": "rank 0's share of an N-GPU pass timed on ONE GPU (+ one 8 KB all-gather on a node): a prediction, not a measurement"}
     sc["process_samples"] = int(score_samples.item())
     if world == 1 and args.full:
         sys.path.insert(0, os.path.join(REPO, "tools"))
